@@ -1,0 +1,152 @@
+/*
+ * sdk_hip.h - C ABI of libsdk_hip.so, the MI355X (gfx950) speaker-embedding + assignment path.
+ *
+ * The reference (CLIAI/speaker-diarization-toolkit) is pure Python and calls no native code;
+ * its plug-in boundary is the Python class contract
+ *     speaker_detection_backends/base.py:22-200   (EmbeddingBackend)
+ *     speaker_detection_backends/base.py:272-293  (get_backend -> module.Backend())
+ * The entry points below are what a local backend behind that contract binds (ctypes stub in
+ * INTEGRATION.md).  Each one cites the reference interface whose work it performs.
+ *
+ * Conventions
+ *   - extern "C", plain pointers and sizes, no C++/torch types.
+ *   - every function returns 0 on success, non-zero on failure; sdk_last_error() then holds a
+ *     thread-local message.  Nothing falls back to the CPU.
+ *   - all data pointers are DEVICE pointers owned by the caller (e.g. torch tensors'
+ *     data_ptr()), unless a parameter is documented as host memory.
+ *   - `stream` is a hipStream_t passed as void*; work is enqueued, never synchronised.
+ *   - bf16 tensors are passed as uint16_t* (raw bfloat16 bits).
+ *   - "rows" of an activation tensor are frames: row m = segment (m / T), frame (m % T),
+ *     channel-last, row stride given explicitly (ld*, in elements).
+ */
+#ifndef SDK_HIP_H
+#define SDK_HIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define SDK_ABI_VERSION 1
+
+typedef struct sdk_ctx sdk_ctx;
+
+typedef struct sdk_device_info {
+  int device;
+  int compute_units;
+  int clock_khz;
+  int wavefront_size;
+  uint64_t hbm_bytes;
+  char name[128];
+  char arch[64];
+} sdk_device_info;
+
+/* ---- lifecycle (replaces Backend.__init__ of a reference backend: base.py:291-293) ---- */
+int sdk_abi_version(void);
+int sdk_init(int device, sdk_ctx** out);
+int sdk_shutdown(sdk_ctx* ctx);
+const char* sdk_last_error(void);
+int sdk_get_device_info(sdk_ctx* ctx, sdk_device_info* out);
+
+/* ---- k1: fbank.  Input contract = audio_profiles.py:25-29 (16 kHz mono s16le). --------
+ * pcm   [B, S] int16 (device)          T = 1 + S/160 frames per segment
+ * tabs  packed DFT/mel tables from sdk_fbank_tables_bytes()/sdk_fbank_tables_fill(), copied to
+ *       the device by the caller (16-byte aligned)
+ * ws    caller scratch of sdk_fbank_workspace_bytes(B, S)
+ * feats [B*T, ldf] bf16, channels 0..79 = mean-normalised log-mel, 80..ldf-1 = 0 (ldf >= 80)
+ */
+size_t sdk_fbank_tables_bytes(void);
+int sdk_fbank_tables_fill(void* host_dst, size_t bytes);          /* HOST buffer */
+size_t sdk_fbank_workspace_bytes(int B, int S);                    /* fp32 log-mel scratch */
+int sdk_fbank(sdk_ctx* ctx, const int16_t* pcm, int B, int S, const void* tabs,
+              uint16_t* feats, int ldf, void* ws, size_t ws_bytes, void* stream);
+
+/* ---- k2 building blocks (ECAPA-TDNN forward; behind EmbeddingBackend.enroll_speaker /
+ *      identify_speaker, base.py:107-151) -------------------------------------------------- */
+
+#define SDK_GEMM_RELU 1u
+#define SDK_GEMM_TANH 2u
+
+/* Dilated 1-D convolution over frames as one MFMA GEMM:
+ *   pre[m, n] = bias[n] + ubias[m / T, n] + sum_{j<taps} sum_{c<Cin}
+ *                 A[seg(m)*T + reflect(t(m) + (j - taps/2)*dil), c] * W[n, j*Cin + c]
+ *   v = RELU? max(pre,0) : pre;  v = v*scale[n] + shift[n];  v = TANH? tanh(v) : v
+ *   C[m,n] = bf16(v);  C32[m,n] = v;  S[m,n] = bf16(float(bf16(v)) + float(X2[m,n]))
+ * Requirements: Cin % 64 == 0, N % 128 == 0, T > (taps/2)*dil, M % T == 0.
+ * Any of bias/scale/shift/ubias/C/C32/X2+S may be NULL. */
+typedef struct sdk_conv_gemm_args {
+  const uint16_t* A;  int64_t lda;
+  const uint16_t* W;               /* [N, taps*Cin] bf16, K contiguous */
+  uint16_t* C;        int64_t ldc;
+  float* C32;         int64_t ldc32;
+  const float* bias;  const float* scale;  const float* shift;
+  const float* ubias; int64_t ldub;
+  const uint16_t* X2; int64_t ldx2;
+  uint16_t* S;        int64_t lds;
+  int M, N, Cin, taps, dil, T;
+  uint32_t flags;
+} sdk_conv_gemm_args;
+int sdk_conv_gemm(sdk_ctx* ctx, const sdk_conv_gemm_args* a, void* stream);
+
+/* Squeeze-excitation gate + residual, one workgroup per segment:
+ *   mean[c] = (1/T) sum_t z[b,t,c];  h = relu(W1 mean + b1);  g = sigmoid(W2 h + b2)
+ *   out[b,t,c] = bf16(g[c]*z[b,t,c] + x[b,t,c])
+ * w1t [C, Cse] fp32 (transposed), w2t [Cse, C] fp32 (transposed). C % 8 == 0, C <= 1024*?; */
+int sdk_se_gate_residual(sdk_ctx* ctx, const uint16_t* z, int64_t ldz, const uint16_t* x, int64_t ldx,
+                         const float* w1t, const float* b1, const float* w2t, const float* b2,
+                         uint16_t* out, int64_t ldo, int B, int T, int C, int Cse, void* stream);
+
+/* Attentive statistics pooling pieces.
+ *   sdk_asp_stats : ctx[b, 0:C] = mean_t h, ctx[b, C:2C] = sqrt(max(var_t h, 1e-12))   fp32
+ *   sdk_rows_fc   : out[b, j] = act(bias[j] + sum_c (in[b,c]*in_scale[c]+in_shift[c]) * wt[c, j])
+ *                   (wt [Cin, Nout] fp32 transposed; act 0 none, 1 relu, 2 sigmoid)
+ *   sdk_asp_pool  : softmax over t of logits[b,t,c] -> weighted mean / std of h -> pooled[b, 0:C | C:2C]
+ */
+int sdk_asp_stats(sdk_ctx* ctx, const uint16_t* h, int64_t ldh, int B, int T, int C, float* out_ctx, void* stream);
+int sdk_rows_fc(sdk_ctx* ctx, const float* in, int64_t ldin, const float* in_scale, const float* in_shift,
+                const float* wt, const float* bias, float* out, int64_t ldout,
+                int B, int Cin, int Nout, int act, void* stream);
+int sdk_asp_pool(sdk_ctx* ctx, const float* logits, int64_t ldl, const uint16_t* h, int64_t ldh,
+                 int B, int T, int C, float* pooled, void* stream);
+
+/* Whole forward: feats [B*T, ldf] bf16 -> raw embeddings emb [B, 192] fp32.
+ * `wblob` is the packed device weight blob and `wdesc` (HOST) its offset table, both produced by
+ * the host packer (weights_pack.py); `ws` is caller-owned scratch of sdk_ecapa_workspace_bytes(). */
+typedef struct sdk_ecapa_desc {
+  int32_t n_mels_padded, channels, sub_channels, scale, se_channels, attn_channels, mfa_channels, embed_dim;
+  int32_t n_blocks, kernel0;
+  int32_t dilation[4];
+  /* byte offsets into wblob; -1 = absent.  Layout of the index space: see weights_pack.py */
+  int64_t off[256];
+} sdk_ecapa_desc;
+size_t sdk_ecapa_workspace_bytes(const sdk_ecapa_desc* d, int B, int T);
+int sdk_ecapa_forward(sdk_ctx* ctx, const void* wblob, const sdk_ecapa_desc* wdesc,
+                      const uint16_t* feats, int ldf, int B, int T,
+                      void* ws, size_t ws_bytes, float* emb, void* stream);
+
+/* ---- k3: L2-normalise rows.  X [N, d] fp32 -> E fp32 unit rows, Eb bf16 copy,
+ *      resid[n] = || E[n] - float(Eb[n]) ||_2 (rigorous per-row bf16 rounding residual). -- */
+int sdk_l2norm(sdk_ctx* ctx, const float* X, int N, int d, float* E, uint16_t* Eb, float* resid, void* stream);
+
+/* ---- k4: segments x profiles cosine affinity with fused top-k (replaces the scoring a local
+ *      identify_speaker performs per candidate: base.py:130-151; rows consumed by
+ *      speaker_detection:1085-1127).
+ *   coarse pass : bf16 MFMA  Eb [N,d] x Pb [P,d]^T, fused per-row top-4 (no N x P matrix in HBM)
+ *   exact pass  : fp32 re-score of the candidates, sorted, ties -> lowest profile index
+ *   guarantee   : rows whose 4th coarse candidate is within the rounding margin of the best are
+ *                 re-scanned exactly in fp32 over all P, so idx/score equal an fp32 full scan.
+ * d must be 192 (= 12 MFMA k-steps), k <= 4.  idx [N,k] int32, score [N,k] fp32.
+ * n_rescanned (device int32, may be NULL) receives the number of rows that took the exact path.
+ * ws: sdk_affinity_workspace_bytes(N). */
+size_t sdk_affinity_workspace_bytes(int N);
+int sdk_affinity_topk(sdk_ctx* ctx, const float* E, const uint16_t* Eb, const float* resid_e,
+                      const float* P, const uint16_t* Pb, const float* resid_p,
+                      int N, int Pn, int d, int k, int32_t* idx, float* score,
+                      int32_t* n_rescanned, void* ws, size_t ws_bytes, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* SDK_HIP_H */

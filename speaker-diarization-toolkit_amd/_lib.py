@@ -1,0 +1,122 @@
+"""ctypes binding of libsdk_hip.so (the C ABI declared in include/sdk_hip.h).
+
+There is no CPU fallback: if the shared library has not been built, or no gfx950 device is
+present, every entry point raises.  torch is imported first on purpose - it brings the HIP
+runtime (libamdhip64.so.7) into the process, and libsdk_hip.so binds to that same runtime, so
+torch tensors' device pointers and torch's streams are valid inside the library.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+from pathlib import Path
+
+import torch  # noqa: F401  (must precede loading libsdk_hip.so, see module docstring)
+
+_HERE = Path(__file__).resolve().parent
+LIB_PATH = Path(os.environ.get("SDK_HIP_LIB", _HERE / "libsdk_hip.so"))
+
+
+class SdkError(RuntimeError):
+    """A libsdk_hip.so call returned non-zero (message from sdk_last_error())."""
+
+
+class DeviceInfo(C.Structure):
+    _fields_ = [("device", C.c_int), ("compute_units", C.c_int), ("clock_khz", C.c_int),
+                ("wavefront_size", C.c_int), ("hbm_bytes", C.c_uint64), ("name", C.c_char * 128),
+                ("arch", C.c_char * 64)]
+
+
+class ConvGemmArgs(C.Structure):
+    _fields_ = [("A", C.c_void_p), ("lda", C.c_int64), ("W", C.c_void_p),
+                ("C", C.c_void_p), ("ldc", C.c_int64), ("C32", C.c_void_p), ("ldc32", C.c_int64),
+                ("bias", C.c_void_p), ("scale", C.c_void_p), ("shift", C.c_void_p),
+                ("ubias", C.c_void_p), ("ldub", C.c_int64),
+                ("X2", C.c_void_p), ("ldx2", C.c_int64), ("S", C.c_void_p), ("lds", C.c_int64),
+                ("M", C.c_int), ("N", C.c_int), ("Cin", C.c_int), ("taps", C.c_int), ("dil", C.c_int),
+                ("T", C.c_int), ("flags", C.c_uint32)]
+
+
+class EcapaDesc(C.Structure):
+    _fields_ = [("n_mels_padded", C.c_int32), ("channels", C.c_int32), ("sub_channels", C.c_int32),
+                ("scale", C.c_int32), ("se_channels", C.c_int32), ("attn_channels", C.c_int32),
+                ("mfa_channels", C.c_int32), ("embed_dim", C.c_int32), ("n_blocks", C.c_int32),
+                ("kernel0", C.c_int32), ("dilation", C.c_int32 * 4), ("off", C.c_int64 * 256)]
+
+
+GEMM_RELU = 1
+GEMM_TANH = 2
+
+_vp, _i, _i64, _sz = C.c_void_p, C.c_int, C.c_int64, C.c_size_t
+
+# name -> (restype, argtypes); every symbol include/sdk_hip.h declares must be listed here
+SIGNATURES = {
+    "sdk_abi_version": (_i, []),
+    "sdk_init": (_i, [_i, C.POINTER(_vp)]),
+    "sdk_shutdown": (_i, [_vp]),
+    "sdk_last_error": (C.c_char_p, []),
+    "sdk_get_device_info": (_i, [_vp, C.POINTER(DeviceInfo)]),
+    "sdk_fbank_tables_bytes": (_sz, []),
+    "sdk_fbank_tables_fill": (_i, [_vp, _sz]),
+    "sdk_fbank_workspace_bytes": (_sz, [_i, _i]),
+    "sdk_fbank": (_i, [_vp, _vp, _i, _i, _vp, _vp, _i, _vp, _sz, _vp]),
+    "sdk_conv_gemm": (_i, [_vp, C.POINTER(ConvGemmArgs), _vp]),
+    "sdk_se_gate_residual": (_i, [_vp, _vp, _i64, _vp, _i64, _vp, _vp, _vp, _vp, _vp, _i64, _i, _i, _i, _i, _vp]),
+    "sdk_asp_stats": (_i, [_vp, _vp, _i64, _i, _i, _i, _vp, _vp]),
+    "sdk_rows_fc": (_i, [_vp, _vp, _i64, _vp, _vp, _vp, _vp, _vp, _i64, _i, _i, _i, _i, _vp]),
+    "sdk_asp_pool": (_i, [_vp, _vp, _i64, _vp, _i64, _i, _i, _i, _vp, _vp]),
+    "sdk_ecapa_workspace_bytes": (_sz, [C.POINTER(EcapaDesc), _i, _i]),
+    "sdk_ecapa_forward": (_i, [_vp, _vp, C.POINTER(EcapaDesc), _vp, _i, _i, _i, _vp, _sz, _vp, _vp]),
+    "sdk_l2norm": (_i, [_vp, _vp, _i, _i, _vp, _vp, _vp, _vp]),
+    "sdk_affinity_workspace_bytes": (_sz, [_i]),
+    "sdk_affinity_topk": (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _vp, _vp, _vp, _vp, _sz, _vp]),
+}
+
+_lib = None
+_ctx = {}
+
+
+def load_library() -> C.CDLL:
+    """dlopen libsdk_hip.so and type every entry point.  Raises if it has not been built."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not LIB_PATH.exists():
+        raise SdkError(
+            f"{LIB_PATH} not found: the HIP extension has not been built. Run "
+            f"`python -c 'import __graft_entry__ as g; g.build()'` (or `make -C {_HERE / 'csrc'}`). "
+            "This package has no CPU fallback.")
+    lib = C.CDLL(str(LIB_PATH))
+    for name, (res, args) in SIGNATURES.items():
+        fn = getattr(lib, name)  # AttributeError here = header/library mismatch
+        fn.restype = res
+        fn.argtypes = args
+    if lib.sdk_abi_version() != 1:
+        raise SdkError(f"libsdk_hip.so ABI {lib.sdk_abi_version()} != 1 expected by this host package")
+    _lib = lib
+    return lib
+
+
+def check(rc: int, what: str = "") -> None:
+    if rc != 0:
+        msg = load_library().sdk_last_error()
+        raise SdkError(f"{what or 'libsdk_hip'} failed (rc={rc}): {msg.decode() if msg else '?'}")
+
+
+def get_ctx(device: int = 0) -> C.c_void_p:
+    """One sdk_ctx per (process, device); raises SdkError when no MI355X is visible."""
+    if device not in _ctx:
+        lib = load_library()
+        h = C.c_void_p()
+        check(lib.sdk_init(int(device), C.byref(h)), "sdk_init")
+        _ctx[device] = h
+    return _ctx[device]
+
+
+def device_info(device: int = 0) -> dict:
+    lib = load_library()
+    info = DeviceInfo()
+    check(lib.sdk_get_device_info(get_ctx(device), C.byref(info)), "sdk_get_device_info")
+    return {"device": info.device, "compute_units": info.compute_units, "clock_khz": info.clock_khz,
+            "wavefront_size": info.wavefront_size, "hbm_bytes": int(info.hbm_bytes),
+            "name": info.name.decode(), "arch": info.arch.decode()}

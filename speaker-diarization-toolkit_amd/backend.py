@@ -1,0 +1,167 @@
+"""`Backend` - the MI355X-native implementation of the toolkit's EmbeddingBackend contract
+(speaker_detection_backends/base.py:22-200; registered through backends.yaml, loaded by
+get_backend -> module.Backend(), base.py:272-293).
+
+Audio windows (2 s, 16 kHz mono s16le) -> fbank -> ECAPA-TDNN -> L2-normalise -> cosine
+affinity vs the enrolled profiles, all inside libsdk_hip.so.  No CPU fallback: without the built
+library or without a gfx950 device the first compute call raises (the CLIs print
+"Error during identification: ..." and exit 1, speaker_detection:1072-1074).
+
+Environment:
+  SDK_DEVICE          GPU index (default: $LOCAL_RANK, else 0)
+  SDK_ECAPA_WEIGHTS   .npz checkpoint in the weights.py naming (default: seeded synthetic weights -
+                      there is no network here to fetch a pretrained model; a warning is printed)
+  SDK_WINDOW_S / SDK_HOP_S   analysis window / hop in seconds (default 2.0 / 1.0)
+"""
+from __future__ import annotations
+
+import os
+import sys
+from pathlib import Path
+from typing import Any, Dict, List, Optional, Tuple
+
+import numpy as np
+
+from . import BACKEND_NAME
+from .plugin_api import EmbeddingBackend
+from .store import load_profile_batch, save_vector, vector_path
+from .wav import cut_windows, read_wav_s16
+from .weights import DEFAULT_CONFIG, load_weights, synthetic_weights, weights_digest
+
+
+class Backend(EmbeddingBackend):
+    def __init__(self) -> None:
+        self._engine = None
+        self._weights = None
+        self._digest: Optional[str] = None
+        self.window_s = float(os.environ.get("SDK_WINDOW_S", "2.0"))
+        self.hop_s = float(os.environ.get("SDK_HOP_S", "1.0"))
+
+    # ---- metadata (base.py:25-105) -------------------------------------------------------
+    @property
+    def name(self) -> str:
+        return BACKEND_NAME
+
+    @property
+    def requires_api_key(self) -> bool:
+        return False
+
+    @property
+    def embedding_dim(self) -> Optional[int]:
+        return DEFAULT_CONFIG.embed_dim
+
+    @property
+    def model_version(self) -> str:
+        return f"{self.name}-ecapa1024-{self._weights_digest()}"
+
+    @property
+    def audio_profile(self):
+        return BACKEND_NAME
+
+    # ---- lazily built state --------------------------------------------------------------
+    def _host_weights(self):
+        if self._weights is None:
+            path = os.environ.get("SDK_ECAPA_WEIGHTS")
+            if path:
+                self._weights = load_weights(path)
+            else:
+                print("mi355x backend: SDK_ECAPA_WEIGHTS not set - using seeded synthetic ECAPA-TDNN weights "
+                      "(scores are self-consistent but not trained)", file=sys.stderr)
+                self._weights = synthetic_weights(0)
+        return self._weights
+
+    def _weights_digest(self) -> str:
+        if self._digest is None:
+            self._digest = weights_digest(self._host_weights())
+        return self._digest
+
+    def engine(self):
+        if self._engine is None:
+            from .ops import Engine   # imports torch + dlopens libsdk_hip.so; raises SdkError if absent
+            dev = int(os.environ.get("SDK_DEVICE", os.environ.get("LOCAL_RANK", "0")))
+            self._engine = Engine(dev, weights=self._host_weights())
+        return self._engine
+
+    # ---- the GPU path ----------------------------------------------------------------------
+    def embed_windows(self, pcm: np.ndarray):
+        """pcm [B, S] int16 (host) -> torch device tensors (E fp32, Eb bf16, resid)."""
+        import torch
+        eng = self.engine()
+        return eng.embed_pcm(torch.from_numpy(np.ascontiguousarray(pcm)).to(eng.device))
+
+    def _windows(self, audio_path: Path, segments):
+        samples = read_wav_s16(Path(audio_path), self.get_audio_profile())
+        pcm, spans = cut_windows(samples, segments, window_s=self.window_s, hop_s=self.hop_s)
+        if len(spans) == 0:
+            raise ValueError(f"{audio_path}: no analysable audio (every segment shorter than 0.5 s)")
+        return pcm, spans
+
+    # ---- a2: enroll (base.py:107-128) ---------------------------------------------------------
+    def enroll_speaker(self, audio_path: Path, segments: Optional[List[Tuple[float, float]]] = None) -> Dict[str, Any]:
+        pcm, spans = self._windows(audio_path, segments)
+        E, _, _ = self.embed_windows(pcm)
+        mean = E.double().mean(dim=0)
+        vec = (mean / mean.norm().clamp_min(1e-12)).float().cpu().numpy()
+        ext = save_vector(vec)
+        return {
+            "external_id": ext,                      # the only backend field cmd_enroll persists (speaker_detection:890-904)
+            "file": str(vector_path(ext)),
+            "model_version": self.model_version,
+            "source_audio": str(audio_path),
+            "source_segments": segments,
+            "embedding_dim": self.embedding_dim,
+            "n_windows": len(spans),
+        }
+
+    # ---- a1: identify (base.py:130-151) --------------------------------------------------------
+    def score_windows(self, E, Eb, re, batch, k: int = 1):
+        """Device scoring of embedded windows against a ProfileBatch -> (idx, score) on host."""
+        import torch
+        eng = self.engine()
+        P = torch.from_numpy(np.ascontiguousarray(batch.matrix)).to(eng.device)
+        Pn, Pb, rp = eng.l2norm(P)
+        idx, sc = eng.affinity_topk(E, Eb, re, Pn, Pb, rp.max().reshape(1), k=min(k, len(batch)))
+        return idx.cpu().numpy(), sc.cpu().numpy()
+
+    def identify_speaker(self, audio_path: Path, candidates: List[Dict[str, Any]], threshold: float = 0.354) -> List[Dict[str, Any]]:
+        batch = load_profile_batch(candidates, self.name, model_prefix=f"{self.name}-")
+        for why in batch.skipped:
+            print(f"mi355x backend: skipped embedding {why}", file=sys.stderr)
+        if len(batch) == 0:
+            return []
+        pcm, spans = self._windows(audio_path, None)
+        E, Eb, re = self.embed_windows(pcm)
+        idx, sc = self.score_windows(E, Eb, re, batch)
+        return aggregate_matches(idx[:, 0], sc[:, 0], spans, batch, threshold)
+
+    # ---- a3: verify - the CLI reads result['confidence'] (speaker_detection:1173-1174) ---------
+    def verify_speaker(self, audio_path: Path, speaker_profile: Dict[str, Any], threshold: float = 0.354) -> Dict[str, Any]:
+        hits = self.identify_speaker(audio_path, [speaker_profile], threshold)
+        if not hits:
+            return {"match": False, "similarity": 0.0, "confidence": 0.0, "embedding_id": None}
+        h = hits[0]
+        return {"match": True, "similarity": h["similarity"], "confidence": h["similarity"], "embedding_id": h.get("embedding_id")}
+
+
+def aggregate_matches(best_idx: np.ndarray, best_score: np.ndarray, spans, batch, threshold: float) -> List[Dict[str, Any]]:
+    """Per-window argmax (integer profile row, fp32 cosine) -> one result row per matched speaker.
+    A window votes for the speaker owning its best profile row if the cosine clears `threshold`;
+    similarity = float64 mean of the speaker's window scores; rows sorted by similarity desc, ties
+    by speaker id.  embedding_id = the speaker's embedding that won most windows (ties: first)."""
+    per: Dict[str, Dict[str, Any]] = {}
+    for w, (row, s) in enumerate(zip(best_idx.tolist(), best_score.tolist())):
+        if row < 0 or s < threshold:
+            continue
+        sid = batch.speaker_ids[row]
+        acc = per.setdefault(sid, {"scores": [], "rows": {}, "first": spans[w][0], "last": spans[w][1]})
+        acc["scores"].append(float(s))
+        acc["rows"][row] = acc["rows"].get(row, 0) + 1
+        acc["last"] = spans[w][1]
+    out = []
+    for sid, acc in per.items():
+        win_row = max(acc["rows"].items(), key=lambda kv: (kv[1], -kv[0]))[0]
+        sim = float(np.mean(np.asarray(acc["scores"], dtype=np.float64)))
+        out.append({"speaker_id": sid, "similarity": sim, "confidence": sim, "embedding_id": batch.embedding_ids[win_row],
+                    "segment": (acc["first"], acc["last"]), "n_segments": len(acc["scores"])})
+    out.sort(key=lambda r: (-r["similarity"], r["speaker_id"]))
+    return out

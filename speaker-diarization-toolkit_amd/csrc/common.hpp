@@ -1,0 +1,104 @@
+// Shared device/host helpers for libsdk_hip.so (gfx950 only; wave = 64 lanes).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <stdio.h>
+
+#include "../../include/sdk_hip.h"
+
+typedef __bf16 bf16_t;
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef __bf16 bf16x4 __attribute__((ext_vector_type(4)));
+typedef __bf16 bf16x2 __attribute__((ext_vector_type(2)));
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
+typedef uint32_t u32x2 __attribute__((ext_vector_type(2)));
+
+struct sdk_ctx {
+  int device;
+  int num_cu;
+  hipDeviceProp_t prop;
+};
+
+void sdk_set_error(const char* fmt, ...) __attribute__((format(printf, 1, 2)));
+
+#define SDK_HIP_OK(expr)                                                              \
+  do {                                                                                \
+    hipError_t _e = (expr);                                                           \
+    if (_e != hipSuccess) {                                                           \
+      sdk_set_error("%s failed: %s (%s:%d)", #expr, hipGetErrorString(_e), __FILE__, __LINE__); \
+      return 1;                                                                       \
+    }                                                                                 \
+  } while (0)
+
+#define SDK_REQUIRE(cond, ...)            \
+  do {                                    \
+    if (!(cond)) {                        \
+      sdk_set_error(__VA_ARGS__);         \
+      return 2;                           \
+    }                                     \
+  } while (0)
+
+#define SDK_LAUNCH_CHECK()                                                         \
+  do {                                                                             \
+    hipError_t _e = hipGetLastError();                                             \
+    if (_e != hipSuccess) {                                                        \
+      sdk_set_error("kernel launch failed: %s (%s:%d)", hipGetErrorString(_e), __FILE__, __LINE__); \
+      return 1;                                                                    \
+    }                                                                              \
+  } while (0)
+
+static inline int ceil_div(int a, int b) { return (a + b - 1) / b; }
+
+// ---------------------------------------------------------------- device helpers
+__device__ __forceinline__ float bf16_to_f32(bf16_t v) { return (float)v; }
+__device__ __forceinline__ bf16_t f32_to_bf16(float v) { return (bf16_t)v; }  // RNE (v_cvt_pk_bf16_f32)
+
+__device__ __forceinline__ float bf16_bits_to_f32(uint32_t lo16) { return __uint_as_float(lo16 << 16); }
+
+// 8 bf16 packed in a 16-byte vector -> 8 floats
+__device__ __forceinline__ void unpack8(const u32x4& v, float* f) {
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    f[2 * i] = __uint_as_float(v[i] << 16);
+    f[2 * i + 1] = __uint_as_float(v[i] & 0xffff0000u);
+  }
+}
+__device__ __forceinline__ uint32_t pack2(float a, float b) {
+  bf16x2 t;
+  t[0] = (bf16_t)a;
+  t[1] = (bf16_t)b;
+  return __builtin_bit_cast(uint32_t, t);
+}
+__device__ __forceinline__ u32x4 pack8(const float* f) {
+  u32x4 v;
+#pragma unroll
+  for (int i = 0; i < 4; ++i) v[i] = pack2(f[2 * i], f[2 * i + 1]);
+  return v;
+}
+
+__device__ __forceinline__ float wave_sum(float v) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+  return v;
+}
+__device__ __forceinline__ float wave_max(float v) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v = fmaxf(v, __shfl_xor(v, o, 64));
+  return v;
+}
+
+// reflect (no edge repeat) t into [0, T); valid for -T < t < 2T-1
+__device__ __forceinline__ int reflect_idx(int t, int T) {
+  t = t < 0 ? -t : t;
+  return t >= T ? 2 * (T - 1) - t : t;
+}
+
+// XCD-aware bijective block remap (8 XCDs, blocks dealt round-robin): blocks that share an XCD
+// get a contiguous run of logical tile ids, so neighbouring tiles hit the same L2.
+__device__ __forceinline__ int xcd_remap(int bid, int nwg) {
+  const int q = nwg >> 3, r = nwg & 7, xcd = bid & 7, local = bid >> 3;
+  const int base = xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q;
+  return base + local;
+}

@@ -1,0 +1,37 @@
+/* Index space of sdk_ecapa_desc.off[] (byte offsets into the packed device weight blob).
+ * Mirrored by weights_pack.py (slot() there must stay in sync with these macros).
+ *
+ * bf16 tensors ("W" slots of conv layers) are stored [C_out][taps * C_in_padded], tap-major,
+ * K contiguous; everything else is fp32.  scale/shift = eval-mode BatchNorm folded to an affine. */
+#ifndef SDK_ECAPA_LAYOUT_H
+#define SDK_ECAPA_LAYOUT_H
+
+#define EL_W 0
+#define EL_B 1
+#define EL_SCALE 2
+#define EL_SHIFT 3
+
+#define EL_BLK0 0                                   /* 4 slots */
+#define EL_BLOCK_BASE(i) (4 + ((i) - 1) * 40)       /* i = 1..n_blocks, 40 slots each */
+#define EL_TDNN1 0                                  /* +W,B,SCALE,SHIFT */
+#define EL_RES2NET(j) (4 + 4 * (j))                 /* j = 0..6 */
+#define EL_TDNN2 32
+#define EL_SE_W1T 36                                /* fp32 [C][Cse]   */
+#define EL_SE_B1 37
+#define EL_SE_W2T 38                                /* fp32 [Cse][C]   */
+#define EL_SE_B2 39
+#define EL_TAIL_BASE(nb) (4 + (nb) * 40)
+#define EL_MFA 0                                    /* +W,B,SCALE,SHIFT */
+#define EL_ASP_WH 4                                 /* bf16 [A][Cm]    */
+#define EL_ASP_WMS_T 5                              /* fp32 [2Cm][A]   */
+#define EL_ASP_B 6
+#define EL_ASP_SCALE 7
+#define EL_ASP_SHIFT 8
+#define EL_ASP_W2 9                                 /* bf16 [Cm][A]    */
+#define EL_ASP_B2 10
+#define EL_ASPBN_SCALE 11
+#define EL_ASPBN_SHIFT 12
+#define EL_FC_WT 13                                 /* fp32 [2Cm][E]   */
+#define EL_FC_B 14
+
+#endif

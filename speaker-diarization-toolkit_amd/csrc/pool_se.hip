@@ -1,0 +1,326 @@
+// Per-utterance (HBM-streaming) pieces of the ECAPA-TDNN forward: squeeze-excitation gate +
+// residual, attentive-statistics pooling, small fp32 fully-connected layers, L2-normalise.
+// All of them are bandwidth-bound row sweeps: 16-byte loads per lane, channels on lanes so
+// that every wave-instruction touches whole 128-B lines, fp32 accumulation.
+#include "common.hpp"
+
+namespace {
+
+constexpr int NT = 256;
+
+// ------------------------------------------------------------------------------------------
+// SE: one workgroup per segment.  Thread (grp, c8) owns 8 channels and every ngrp-th frame.
+__global__ __launch_bounds__(NT) void se_gate_residual_kernel(
+    const bf16_t* __restrict__ z, int64_t ldz, const bf16_t* __restrict__ x, int64_t ldx,
+    const float* __restrict__ w1t, const float* __restrict__ b1, const float* __restrict__ w2t,
+    const float* __restrict__ b2, bf16_t* __restrict__ out, int64_t ldo, int T, int C, int Cse) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  const int nch8 = C >> 3;
+  const int ngrp = NT / nch8;
+  float* part = reinterpret_cast<float*>(smem);   // [ngrp][C]  (reused as FC1 partials)
+  float* mean = part + ngrp * C;                  // [C]         (reused as gate g[C])
+  float* hbuf = mean + C;                         // [Cse]
+
+  const int tid = threadIdx.x;
+  const int c8 = tid % nch8, grp = tid / nch8;
+  const int64_t base = (int64_t)blockIdx.x * T;
+
+  float s[8];
+#pragma unroll
+  for (int e = 0; e < 8; ++e) s[e] = 0.f;
+  for (int t = grp; t < T; t += ngrp) {
+    const u32x4 v = *reinterpret_cast<const u32x4*>(z + (base + t) * ldz + c8 * 8);
+    float f[8];
+    unpack8(v, f);
+#pragma unroll
+    for (int e = 0; e < 8; ++e) s[e] += f[e];
+  }
+#pragma unroll
+  for (int e = 0; e < 8; ++e) part[grp * C + c8 * 8 + e] = s[e];
+  __syncthreads();
+  const float invT = 1.0f / (float)T;
+  for (int c = tid; c < C; c += NT) {
+    float m = 0.f;
+    for (int g = 0; g < ngrp; ++g) m += part[g * C + c];
+    mean[c] = m * invT;
+  }
+  __syncthreads();
+  // FC1 (C -> Cse) : thread = (output j, slice k of the input range)
+  {
+    const int nsl = NT / Cse;              // Cse divides NT
+    const int j = tid % Cse, k = tid / Cse;
+    const int c_lo = (int)((int64_t)C * k / nsl), c_hi = (int)((int64_t)C * (k + 1) / nsl);
+    float a = 0.f;
+    for (int c = c_lo; c < c_hi; ++c) a += mean[c] * w1t[(int64_t)c * Cse + j];
+    part[k * Cse + j] = a;                 // part is free again (mean already reduced)
+    __syncthreads();
+    if (tid < Cse) {
+      float v = b1[tid];
+      for (int kk = 0; kk < nsl; ++kk) v += part[kk * Cse + tid];
+      hbuf[tid] = fmaxf(v, 0.f);
+    }
+    __syncthreads();
+  }
+  // FC2 (Cse -> C) + sigmoid; gate stored over `mean`
+  for (int c = tid; c < C; c += NT) {
+    float a = b2[c];
+    for (int j = 0; j < Cse; ++j) a += hbuf[j] * w2t[(int64_t)j * C + c];
+    mean[c] = 1.0f / (1.0f + __expf(-a));
+  }
+  __syncthreads();
+  float g[8];
+#pragma unroll
+  for (int e = 0; e < 8; ++e) g[e] = mean[c8 * 8 + e];
+  for (int t = grp; t < T; t += ngrp) {
+    const u32x4 zv = *reinterpret_cast<const u32x4*>(z + (base + t) * ldz + c8 * 8);
+    const u32x4 xv = *reinterpret_cast<const u32x4*>(x + (base + t) * ldx + c8 * 8);
+    float fz[8], fx[8];
+    unpack8(zv, fz);
+    unpack8(xv, fx);
+#pragma unroll
+    for (int e = 0; e < 8; ++e) fz[e] = g[e] * fz[e] + fx[e];
+    *reinterpret_cast<u32x4*>(out + (base + t) * ldo + c8 * 8) = pack8(fz);
+  }
+}
+
+// ------------------------------------------------------------------------------------------
+// ASP global context: mean / std over frames.  grid (B, C/1024) ; 128 chunk-columns x 2 frame groups.
+__global__ __launch_bounds__(NT) void asp_stats_kernel(const bf16_t* __restrict__ h, int64_t ldh, int T, int C,
+                                                      float* __restrict__ out) {
+  __shared__ float red[2][2][1024];
+  const int tid = threadIdx.x;
+  const int c8 = tid & 127, grp = tid >> 7;
+  const int cbase = blockIdx.y * 1024 + c8 * 8;
+  const int64_t base = (int64_t)blockIdx.x * T;
+  const bool live = cbase < C;
+  float K[8], s1[8], s2[8];
+#pragma unroll
+  for (int e = 0; e < 8; ++e) { K[e] = 0.f; s1[e] = 0.f; s2[e] = 0.f; }
+  if (live) {
+    unpack8(*reinterpret_cast<const u32x4*>(h + base * ldh + cbase), K);   // shift = frame 0
+    for (int t = grp; t < T; t += 2) {
+      float f[8];
+      unpack8(*reinterpret_cast<const u32x4*>(h + (base + t) * ldh + cbase), f);
+#pragma unroll
+      for (int e = 0; e < 8; ++e) {
+        const float d = f[e] - K[e];
+        s1[e] += d;
+        s2[e] += d * d;
+      }
+    }
+  }
+#pragma unroll
+  for (int e = 0; e < 8; ++e) {
+    red[grp][0][c8 * 8 + e] = s1[e];
+    red[grp][1][c8 * 8 + e] = s2[e];
+  }
+  __syncthreads();
+  if (grp == 0 && live) {
+    const float invT = 1.0f / (float)T;
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+      const float a = (red[0][0][c8 * 8 + e] + red[1][0][c8 * 8 + e]) * invT;
+      const float q = (red[0][1][c8 * 8 + e] + red[1][1][c8 * 8 + e]) * invT;
+      const float var = fmaxf(q - a * a, 1e-12f);
+      out[(int64_t)blockIdx.x * 2 * C + cbase + e] = K[e] + a;
+      out[(int64_t)blockIdx.x * 2 * C + C + cbase + e] = sqrtf(var);
+    }
+  }
+}
+
+// ------------------------------------------------------------------------------------------
+// Small fp32 fully-connected layer over rows.  grid (ceil(B/4), ceil(Nout/128)); thread =
+// (output j, half k of each 512-wide input chunk); 4 rows share every weight load.
+constexpr int FC_ROWS = 4, FC_CHUNK = 512;
+__global__ __launch_bounds__(NT) void rows_fc_kernel(const float* __restrict__ in, int64_t ldin,
+                                                    const float* __restrict__ isc, const float* __restrict__ ish,
+                                                    const float* __restrict__ wt, const float* __restrict__ bias,
+                                                    float* __restrict__ out, int64_t ldout, int B, int Cin, int Nout,
+                                                    int act) {
+  __shared__ float xs[FC_ROWS][FC_CHUNK];
+  __shared__ float comb[FC_ROWS][128];
+  const int tid = threadIdx.x;
+  const int jl = tid & 127, k = tid >> 7;
+  const int j = blockIdx.y * 128 + jl;
+  const int b0 = blockIdx.x * FC_ROWS;
+  float acc[FC_ROWS];
+#pragma unroll
+  for (int r = 0; r < FC_ROWS; ++r) acc[r] = 0.f;
+  for (int c0 = 0; c0 < Cin; c0 += FC_CHUNK) {
+    const int n = min(FC_CHUNK, Cin - c0);
+    for (int i = tid; i < FC_ROWS * FC_CHUNK; i += NT) {
+      const int r = i / FC_CHUNK, c = i - r * FC_CHUNK;
+      float v = 0.f;
+      if (c < n && b0 + r < B) {
+        v = in[(int64_t)(b0 + r) * ldin + c0 + c];
+        if (isc) v = v * isc[c0 + c] + ish[c0 + c];
+      }
+      xs[r][c] = v;
+    }
+    __syncthreads();
+    if (j < Nout) {
+      const int lo = k * (FC_CHUNK / 2), hi = min(n, lo + FC_CHUNK / 2);
+      for (int c = lo; c < hi; ++c) {
+        const float w = wt[(int64_t)(c0 + c) * Nout + j];
+#pragma unroll
+        for (int r = 0; r < FC_ROWS; ++r) acc[r] += xs[r][c] * w;
+      }
+    }
+    __syncthreads();
+  }
+  if (k == 1) {
+#pragma unroll
+    for (int r = 0; r < FC_ROWS; ++r) comb[r][jl] = acc[r];
+  }
+  __syncthreads();
+  if (k == 0 && j < Nout) {
+#pragma unroll
+    for (int r = 0; r < FC_ROWS; ++r) {
+      if (b0 + r < B) {
+        float v = acc[r] + comb[r][jl] + (bias ? bias[j] : 0.f);
+        if (act == 1) v = fmaxf(v, 0.f);
+        else if (act == 2) v = 1.0f / (1.0f + __expf(-v));
+        out[(int64_t)(b0 + r) * ldout + j] = v;
+      }
+    }
+  }
+}
+
+// ------------------------------------------------------------------------------------------
+// ASP pooling: softmax over frames per (segment, channel), attention-weighted mean and std.
+// grid (B, C/64); thread = (channel cl = tid & 63, frame group g = tid >> 6); three sweeps
+// (max; sum-exp + weighted sum; weighted variance) - the 77-KB working set stays in L2.
+__global__ __launch_bounds__(NT) void asp_pool_kernel(const float* __restrict__ logits, int64_t ldl,
+                                                     const bf16_t* __restrict__ h, int64_t ldh, int T, int C,
+                                                     float* __restrict__ pooled) {
+  __shared__ float red[4][64];
+  __shared__ float red2[4][64];
+  const int tid = threadIdx.x;
+  const int cl = tid & 63, g = tid >> 6;
+  const int c = blockIdx.y * 64 + cl;
+  const int64_t base = (int64_t)blockIdx.x * T;
+  const float* lp = logits + base * ldl + c;
+  const bf16_t* hp = h + base * ldh + c;
+
+  float mx = -INFINITY;
+  for (int t = g; t < T; t += 4) mx = fmaxf(mx, lp[(int64_t)t * ldl]);
+  red[g][cl] = mx;
+  __syncthreads();
+  mx = fmaxf(fmaxf(red[0][cl], red[1][cl]), fmaxf(red[2][cl], red[3][cl]));
+  __syncthreads();
+
+  float l = 0.f, s1 = 0.f;
+  for (int t = g; t < T; t += 4) {
+    const float w = __expf(lp[(int64_t)t * ldl] - mx);
+    l += w;
+    s1 += w * bf16_to_f32(hp[(int64_t)t * ldh]);
+  }
+  red[g][cl] = l;
+  red2[g][cl] = s1;
+  __syncthreads();
+  l = (red[0][cl] + red[1][cl]) + (red[2][cl] + red[3][cl]);
+  s1 = (red2[0][cl] + red2[1][cl]) + (red2[2][cl] + red2[3][cl]);
+  __syncthreads();
+  const float mu = s1 / l;
+
+  float s2 = 0.f;
+  for (int t = g; t < T; t += 4) {
+    const float w = __expf(lp[(int64_t)t * ldl] - mx);
+    const float d = bf16_to_f32(hp[(int64_t)t * ldh]) - mu;
+    s2 += w * d * d;
+  }
+  red[g][cl] = s2;
+  __syncthreads();
+  if (g == 0) {
+    s2 = (red[0][cl] + red[1][cl]) + (red[2][cl] + red[3][cl]);
+    pooled[(int64_t)blockIdx.x * 2 * C + c] = mu;
+    pooled[(int64_t)blockIdx.x * 2 * C + C + c] = sqrtf(fmaxf(s2 / l, 1e-12f));
+  }
+}
+
+// ------------------------------------------------------------------------------------------
+// k3: L2-normalise rows; one wave per row.
+__global__ __launch_bounds__(NT) void l2norm_kernel(const float* __restrict__ X, int N, int d, float* __restrict__ E,
+                                                   bf16_t* __restrict__ Eb, float* __restrict__ resid) {
+  const int lane = threadIdx.x & 63;
+  const int row = blockIdx.x * (NT / 64) + (threadIdx.x >> 6);
+  if (row >= N) return;
+  const float* x = X + (int64_t)row * d;
+  float ss = 0.f;
+  for (int i = lane; i < d; i += 64) ss += x[i] * x[i];
+  ss = wave_sum(ss);
+  const float inv = 1.0f / fmaxf(sqrtf(ss), 1e-12f);
+  float rr = 0.f;
+  for (int i = lane; i < d; i += 64) {
+    const float e = x[i] * inv;
+    const bf16_t eb = f32_to_bf16(e);
+    if (E) E[(int64_t)row * d + i] = e;
+    if (Eb) Eb[(int64_t)row * d + i] = eb;
+    const float dd = e - bf16_to_f32(eb);
+    rr += dd * dd;
+  }
+  rr = wave_sum(rr);
+  if (resid && lane == 0) resid[row] = sqrtf(rr);
+}
+
+}  // namespace
+
+extern "C" int sdk_se_gate_residual(sdk_ctx* ctx, const uint16_t* z, int64_t ldz, const uint16_t* x, int64_t ldx,
+                                    const float* w1t, const float* b1, const float* w2t, const float* b2,
+                                    uint16_t* out, int64_t ldo, int B, int T, int C, int Cse, void* stream) {
+  SDK_REQUIRE(ctx && z && x && w1t && b1 && w2t && b2 && out, "sdk_se_gate_residual: null argument");
+  SDK_REQUIRE(B > 0 && T > 0, "sdk_se_gate_residual: empty batch");
+  SDK_REQUIRE(C % 8 == 0 && C / 8 <= NT && NT % (C / 8) == 0, "sdk_se_gate_residual: C=%d unsupported (need C/8 | 256)", C);
+  SDK_REQUIRE(Cse > 0 && Cse <= NT && NT % Cse == 0 && Cse <= C, "sdk_se_gate_residual: Cse=%d unsupported (need Cse | 256)", Cse);
+  SDK_REQUIRE(ldz % 8 == 0 && ldx % 8 == 0 && ldo % 8 == 0, "sdk_se_gate_residual: row strides must be multiples of 8");
+  const int ngrp = NT / (C / 8);
+  const size_t lds = (size_t)(ngrp * C + C + Cse) * sizeof(float);
+  SDK_REQUIRE((size_t)(NT / Cse) * Cse <= (size_t)ngrp * C, "sdk_se_gate_residual: scratch too small");
+  hipLaunchKernelGGL(se_gate_residual_kernel, dim3(B), dim3(NT), lds, (hipStream_t)stream, (const bf16_t*)z, ldz,
+                     (const bf16_t*)x, ldx, w1t, b1, w2t, b2, (bf16_t*)out, ldo, T, C, Cse);
+  SDK_LAUNCH_CHECK();
+  return 0;
+}
+
+extern "C" int sdk_asp_stats(sdk_ctx* ctx, const uint16_t* h, int64_t ldh, int B, int T, int C, float* out_ctx,
+                             void* stream) {
+  SDK_REQUIRE(ctx && h && out_ctx, "sdk_asp_stats: null argument");
+  SDK_REQUIRE(B > 0 && T > 0 && C % 8 == 0 && ldh % 8 == 0, "sdk_asp_stats: bad shape (C=%d ldh=%lld)", C, (long long)ldh);
+  hipLaunchKernelGGL(asp_stats_kernel, dim3(B, ceil_div(C, 1024)), dim3(NT), 0, (hipStream_t)stream, (const bf16_t*)h,
+                     ldh, T, C, out_ctx);
+  SDK_LAUNCH_CHECK();
+  return 0;
+}
+
+extern "C" int sdk_rows_fc(sdk_ctx* ctx, const float* in, int64_t ldin, const float* in_scale, const float* in_shift,
+                           const float* wt, const float* bias, float* out, int64_t ldout, int B, int Cin, int Nout,
+                           int act, void* stream) {
+  SDK_REQUIRE(ctx && in && wt && out, "sdk_rows_fc: null argument");
+  SDK_REQUIRE(B > 0 && Cin > 0 && Nout > 0, "sdk_rows_fc: empty problem");
+  SDK_REQUIRE((in_scale == nullptr) == (in_shift == nullptr), "sdk_rows_fc: in_scale and in_shift go together");
+  SDK_REQUIRE(act >= 0 && act <= 2, "sdk_rows_fc: act=%d", act);
+  hipLaunchKernelGGL(rows_fc_kernel, dim3(ceil_div(B, FC_ROWS), ceil_div(Nout, 128)), dim3(NT), 0, (hipStream_t)stream,
+                     in, ldin, in_scale, in_shift, wt, bias, out, ldout, B, Cin, Nout, act);
+  SDK_LAUNCH_CHECK();
+  return 0;
+}
+
+extern "C" int sdk_asp_pool(sdk_ctx* ctx, const float* logits, int64_t ldl, const uint16_t* h, int64_t ldh, int B,
+                            int T, int C, float* pooled, void* stream) {
+  SDK_REQUIRE(ctx && logits && h && pooled, "sdk_asp_pool: null argument");
+  SDK_REQUIRE(B > 0 && T > 0 && C % 64 == 0, "sdk_asp_pool: C=%d must be a multiple of 64", C);
+  hipLaunchKernelGGL(asp_pool_kernel, dim3(B, C / 64), dim3(NT), 0, (hipStream_t)stream, logits, ldl,
+                     (const bf16_t*)h, ldh, T, C, pooled);
+  SDK_LAUNCH_CHECK();
+  return 0;
+}
+
+extern "C" int sdk_l2norm(sdk_ctx* ctx, const float* X, int N, int d, float* E, uint16_t* Eb, float* resid,
+                          void* stream) {
+  SDK_REQUIRE(ctx && X, "sdk_l2norm: null argument");
+  SDK_REQUIRE(N > 0 && d > 0, "sdk_l2norm: empty problem");
+  hipLaunchKernelGGL(l2norm_kernel, dim3(ceil_div(N, NT / 64)), dim3(NT), 0, (hipStream_t)stream, X, N, d, E,
+                     (bf16_t*)Eb, resid);
+  SDK_LAUNCH_CHECK();
+  return 0;
+}

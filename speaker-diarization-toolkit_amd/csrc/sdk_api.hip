@@ -1,0 +1,204 @@
+// libsdk_hip.so: context / error plumbing and the ECAPA-TDNN forward schedule (one C call per
+// batch of segments; every step is an asynchronous launch on the caller's stream, so the whole
+// forward can be captured in a hipGraph by the host).
+#include <stdarg.h>
+#include <string.h>
+
+#include "common.hpp"
+#include "ecapa_layout.h"
+
+static thread_local char g_err[512] = "";
+
+void sdk_set_error(const char* fmt, ...) {
+  va_list ap;
+  va_start(ap, fmt);
+  vsnprintf(g_err, sizeof(g_err), fmt, ap);
+  va_end(ap);
+}
+
+extern "C" const char* sdk_last_error(void) { return g_err; }
+extern "C" int sdk_abi_version(void) { return SDK_ABI_VERSION; }
+
+extern "C" int sdk_init(int device, sdk_ctx** out) {
+  SDK_REQUIRE(out, "sdk_init: out is null");
+  *out = nullptr;
+  int n = 0;
+  hipError_t e = hipGetDeviceCount(&n);
+  if (e != hipSuccess || n <= 0) {
+    sdk_set_error("sdk_init: no HIP device available (%s); this library has no CPU fallback",
+                  e != hipSuccess ? hipGetErrorString(e) : "device count is 0");
+    return 1;
+  }
+  SDK_REQUIRE(device >= 0 && device < n, "sdk_init: device %d out of range (0..%d)", device, n - 1);
+  sdk_ctx* c = new sdk_ctx();
+  c->device = device;
+  if (hipGetDeviceProperties(&c->prop, device) != hipSuccess) {
+    delete c;
+    sdk_set_error("sdk_init: hipGetDeviceProperties failed");
+    return 1;
+  }
+  if (strncmp(c->prop.gcnArchName, "gfx950", 6) != 0) {
+    sdk_set_error("sdk_init: device %d is %s; libsdk_hip.so carries gfx950 (MI355X) code objects only", device,
+                  c->prop.gcnArchName);
+    delete c;
+    return 1;
+  }
+  c->num_cu = c->prop.multiProcessorCount;
+  SDK_HIP_OK(hipSetDevice(device));
+  *out = c;
+  return 0;
+}
+
+extern "C" int sdk_shutdown(sdk_ctx* ctx) {
+  delete ctx;
+  return 0;
+}
+
+extern "C" int sdk_get_device_info(sdk_ctx* ctx, sdk_device_info* out) {
+  SDK_REQUIRE(ctx && out, "sdk_get_device_info: null argument");
+  memset(out, 0, sizeof(*out));
+  out->device = ctx->device;
+  out->compute_units = ctx->prop.multiProcessorCount;
+  out->clock_khz = ctx->prop.clockRate;
+  out->wavefront_size = ctx->prop.warpSize;
+  out->hbm_bytes = ctx->prop.totalGlobalMem;
+  strncpy(out->name, ctx->prop.name, sizeof(out->name) - 1);
+  strncpy(out->arch, ctx->prop.gcnArchName, sizeof(out->arch) - 1);
+  return 0;
+}
+
+// ------------------------------------------------------------------------------ ECAPA forward
+namespace {
+
+inline size_t a256(size_t v) { return (v + 255) & ~(size_t)255; }
+
+struct FwdWs {
+  uint16_t *X0, *U, *R, *Z, *Sa, *Sb, *CAT, *H, *AH;
+  float *ctx, *ubias, *logits, *pooled;
+};
+
+size_t fwd_layout(const sdk_ecapa_desc* d, int B, int T, char* base, FwdWs* w) {
+  const size_t M = (size_t)B * T, C = d->channels, Cm = d->mfa_channels, S = d->sub_channels, A = d->attn_channels;
+  size_t off = 0;
+  auto take = [&](size_t bytes) { char* p = base ? base + off : nullptr; off += a256(bytes); return p; };
+  char* x0 = take(M * C * 2);
+  char* u = take(M * C * 2);
+  char* r = take(M * C * 2);
+  char* z = take(M * C * 2);
+  char* sa = take(M * S * 2);
+  char* sb = take(M * S * 2);
+  char* cat = take(M * Cm * 2);
+  char* h = take(M * Cm * 2);
+  char* ah = take(M * A * 2);
+  char* cx = take((size_t)B * 2 * Cm * 4);
+  char* ub = take((size_t)B * A * 4);
+  char* lg = take(M * Cm * 4);
+  char* po = take((size_t)B * 2 * Cm * 4);
+  if (w) {
+    w->X0 = (uint16_t*)x0; w->U = (uint16_t*)u; w->R = (uint16_t*)r; w->Z = (uint16_t*)z;
+    w->Sa = (uint16_t*)sa; w->Sb = (uint16_t*)sb; w->CAT = (uint16_t*)cat; w->H = (uint16_t*)h; w->AH = (uint16_t*)ah;
+    w->ctx = (float*)cx; w->ubias = (float*)ub; w->logits = (float*)lg; w->pooled = (float*)po;
+  }
+  return off;
+}
+
+int check_desc(const sdk_ecapa_desc* d) {
+  SDK_REQUIRE(d, "ecapa desc is null");
+  SDK_REQUIRE(d->n_blocks >= 1 && d->n_blocks <= 4, "ecapa desc: n_blocks=%d", d->n_blocks);
+  SDK_REQUIRE(d->channels % 128 == 0 && d->mfa_channels == d->n_blocks * d->channels, "ecapa desc: channels=%d mfa=%d", d->channels, d->mfa_channels);
+  SDK_REQUIRE(d->scale >= 2 && d->sub_channels * d->scale == d->channels && d->sub_channels % 128 == 0, "ecapa desc: res2net scale=%d sub=%d", d->scale, d->sub_channels);
+  SDK_REQUIRE(d->attn_channels % 128 == 0 && d->n_mels_padded % 64 == 0, "ecapa desc: attn=%d mels=%d", d->attn_channels, d->n_mels_padded);
+  SDK_REQUIRE((d->kernel0 & 1) == 1, "ecapa desc: kernel0=%d must be odd", d->kernel0);
+  return 0;
+}
+
+}  // namespace
+
+extern "C" size_t sdk_ecapa_workspace_bytes(const sdk_ecapa_desc* d, int B, int T) {
+  if (!d || B <= 0 || T <= 0) return 0;
+  return fwd_layout(d, B, T, nullptr, nullptr);
+}
+
+extern "C" int sdk_ecapa_forward(sdk_ctx* ctx, const void* wblob, const sdk_ecapa_desc* d, const uint16_t* feats, int ldf,
+                                 int B, int T, void* ws, size_t ws_bytes, float* emb, void* stream) {
+  SDK_REQUIRE(ctx && wblob && feats && ws && emb, "sdk_ecapa_forward: null argument");
+  if (int rc = check_desc(d)) return rc;
+  SDK_REQUIRE(B > 0 && T > 0, "sdk_ecapa_forward: empty batch (B=%d T=%d)", B, T);
+  SDK_REQUIRE((int64_t)B * T < (1ll << 31), "sdk_ecapa_forward: B*T overflows int32; split the batch");
+  SDK_REQUIRE(ldf >= d->n_mels_padded && ldf % 8 == 0, "sdk_ecapa_forward: ldf=%d < padded mel width %d", ldf, d->n_mels_padded);
+  int maxhalo = d->kernel0 / 2;
+  for (int i = 0; i < d->n_blocks; ++i) maxhalo = d->dilation[i] > maxhalo ? d->dilation[i] : maxhalo;
+  SDK_REQUIRE(T > maxhalo, "sdk_ecapa_forward: segments of %d frames are shorter than the receptive halo %d", T, maxhalo);
+  SDK_REQUIRE(ws_bytes >= sdk_ecapa_workspace_bytes(d, B, T), "sdk_ecapa_forward: workspace too small (%zu < %zu)", ws_bytes,
+              sdk_ecapa_workspace_bytes(d, B, T));
+  SDK_REQUIRE(((uintptr_t)ws % 256) == 0 && ((uintptr_t)wblob % 256) == 0, "sdk_ecapa_forward: ws/wblob must be 256-byte aligned");
+
+  FwdWs w;
+  fwd_layout(d, B, T, (char*)ws, &w);
+  const char* wb = (const char*)wblob;
+  auto P16 = [&](int slot) -> const uint16_t* { return d->off[slot] < 0 ? nullptr : (const uint16_t*)(wb + d->off[slot]); };
+  auto P32 = [&](int slot) -> const float* { return d->off[slot] < 0 ? nullptr : (const float*)(wb + d->off[slot]); };
+  const int M = B * T, C = d->channels, Cm = d->mfa_channels, S = d->sub_channels, A = d->attn_channels;
+  hipStream_t st = (hipStream_t)stream;
+
+  auto tdnn = [&](const uint16_t* Ain, int64_t lda, int Cin, int taps, int dil, int slot, int N, uint16_t* Cout, int64_t ldc,
+                  const uint16_t* X2, int64_t ldx2, uint16_t* Sout, int64_t lds) -> int {
+    sdk_conv_gemm_args g;
+    memset(&g, 0, sizeof(g));
+    g.A = Ain; g.lda = lda; g.W = P16(slot + EL_W); g.C = Cout; g.ldc = ldc;
+    g.bias = P32(slot + EL_B); g.scale = P32(slot + EL_SCALE); g.shift = P32(slot + EL_SHIFT);
+    g.X2 = X2; g.ldx2 = ldx2; g.S = Sout; g.lds = lds;
+    g.M = M; g.N = N; g.Cin = Cin; g.taps = taps; g.dil = dil; g.T = T; g.flags = SDK_GEMM_RELU;
+    SDK_REQUIRE(g.W && g.bias && g.scale && g.shift, "sdk_ecapa_forward: weight slot %d missing", slot);
+    return sdk_conv_gemm(ctx, &g, stream);
+  };
+
+  // blk0: k5 conv over the (zero-padded) mel channels
+  if (int rc = tdnn(feats, ldf, d->n_mels_padded, d->kernel0, 1, EL_BLK0, C, w.X0, C, nullptr, 0, nullptr, 0)) return rc;
+
+  const uint16_t* xin = w.X0;
+  int64_t ldx = C;
+  for (int i = 1; i <= d->n_blocks; ++i) {
+    const int base = EL_BLOCK_BASE(i), dil = d->dilation[i - 1];
+    if (int rc = tdnn(xin, ldx, C, 1, 1, base + EL_TDNN1, C, w.U, C, nullptr, 0, nullptr, 0)) return rc;
+    // Res2Net: chunk 0 passes through, chunk c>=1 = TDNN(chunk c + y_{c-1}); the running sum is
+    // produced by the previous conv's epilogue (S output), ping-ponging between two [M, S] buffers.
+    SDK_HIP_OK(hipMemcpy2DAsync(w.R, (size_t)C * 2, w.U, (size_t)C * 2, (size_t)S * 2, (size_t)M, hipMemcpyDeviceToDevice, st));
+    for (int j = 0; j < d->scale - 1; ++j) {
+      const uint16_t* Ain = j == 0 ? w.U + S : ((j & 1) ? w.Sa : w.Sb);
+      const int64_t lda = j == 0 ? C : S;
+      const bool more = j + 1 < d->scale - 1;
+      uint16_t* Sout = more ? ((j & 1) ? w.Sb : w.Sa) : nullptr;
+      const uint16_t* X2 = more ? w.U + (int64_t)S * (j + 2) : nullptr;
+      if (int rc = tdnn(Ain, lda, S, 3, dil, base + EL_RES2NET(j), S, w.R + (int64_t)S * (j + 1), C, X2, C, Sout, S)) return rc;
+    }
+    if (int rc = tdnn(w.R, C, C, 1, 1, base + EL_TDNN2, C, w.Z, C, nullptr, 0, nullptr, 0)) return rc;
+    uint16_t* slab = w.CAT + (int64_t)C * (i - 1);
+    if (int rc = sdk_se_gate_residual(ctx, w.Z, C, xin, ldx, P32(base + EL_SE_W1T), P32(base + EL_SE_B1), P32(base + EL_SE_W2T),
+                                      P32(base + EL_SE_B2), slab, Cm, B, T, C, d->se_channels, stream)) return rc;
+    xin = slab;
+    ldx = Cm;
+  }
+
+  const int tb = EL_TAIL_BASE(d->n_blocks);
+  if (int rc = tdnn(w.CAT, Cm, Cm, 1, 1, tb + EL_MFA, Cm, w.H, Cm, nullptr, 0, nullptr, 0)) return rc;
+
+  // attentive statistics pooling with global context
+  if (int rc = sdk_asp_stats(ctx, w.H, Cm, B, T, Cm, w.ctx, stream)) return rc;
+  if (int rc = sdk_rows_fc(ctx, w.ctx, 2 * Cm, nullptr, nullptr, P32(tb + EL_ASP_WMS_T), P32(tb + EL_ASP_B), w.ubias, A, B, 2 * Cm, A, 0, stream)) return rc;
+  {
+    sdk_conv_gemm_args g;
+    memset(&g, 0, sizeof(g));
+    g.A = w.H; g.lda = Cm; g.W = P16(tb + EL_ASP_WH); g.C = w.AH; g.ldc = A;
+    g.ubias = w.ubias; g.ldub = A; g.scale = P32(tb + EL_ASP_SCALE); g.shift = P32(tb + EL_ASP_SHIFT);
+    g.M = M; g.N = A; g.Cin = Cm; g.taps = 1; g.dil = 1; g.T = T; g.flags = SDK_GEMM_RELU | SDK_GEMM_TANH;
+    if (int rc = sdk_conv_gemm(ctx, &g, stream)) return rc;
+    memset(&g, 0, sizeof(g));
+    g.A = w.AH; g.lda = A; g.W = P16(tb + EL_ASP_W2); g.C32 = w.logits; g.ldc32 = Cm; g.bias = P32(tb + EL_ASP_B2);
+    g.M = M; g.N = Cm; g.Cin = A; g.taps = 1; g.dil = 1; g.T = T; g.flags = 0;
+    if (int rc = sdk_conv_gemm(ctx, &g, stream)) return rc;
+  }
+  if (int rc = sdk_asp_pool(ctx, w.logits, Cm, w.H, Cm, B, T, Cm, w.pooled, stream)) return rc;
+  return sdk_rows_fc(ctx, w.pooled, 2 * Cm, P32(tb + EL_ASPBN_SCALE), P32(tb + EL_ASPBN_SHIFT), P32(tb + EL_FC_WT),
+                     P32(tb + EL_FC_B), emb, d->embed_dim, B, 2 * Cm, d->embed_dim, 0, stream);
+}

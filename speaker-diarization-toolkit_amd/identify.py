@@ -1,0 +1,63 @@
+"""In-process counterpart of `speaker_detection identify <audio> --format json`
+(speaker_detection:1031-1133) for the assignment driver: load db/*.json, filter, call the backend,
+attach trust levels - without a subprocess per transcript label (speaker-assign:283-294)."""
+from __future__ import annotations
+
+import json
+import os
+import sys
+from pathlib import Path
+from typing import Any, Dict, List, Optional
+
+from . import BACKEND_NAME
+from .assign import rows_with_trust
+
+
+def db_dir() -> Path:
+    return Path(os.environ.get("SPEAKERS_EMBEDDINGS_DIR", os.path.expanduser("~/.config/speakers_embeddings"))) / "db"
+
+
+def list_all_speakers() -> List[Dict[str, Any]]:
+    out = []
+    d = db_dir()
+    if d.exists():
+        for p in sorted(d.glob("*.json")):
+            try:
+                out.append(json.loads(p.read_text()))
+            except (json.JSONDecodeError, OSError) as exc:
+                print(f"Warning: Failed to load {p}: {exc}", file=sys.stderr)
+    return out
+
+
+def candidates_for(backend_name: str, tags: Optional[List[str]] = None) -> List[Dict[str, Any]]:
+    speakers = list_all_speakers()
+    if tags:
+        want = set(tags)
+        speakers = [s for s in speakers if want <= set(s.get("tags", []))]   # AND logic (speaker_detection:241-243)
+    return [s for s in speakers if s.get("embeddings", {}).get(backend_name)]
+
+
+def make_rows_fn(audio_path: Path, tags: Optional[List[str]] = None, per_label: bool = False, threshold: float = 0.354,
+                 backend=None):
+    """Return rows_fn(label, segments) for assign.assign_recording.  Whole-recording mode (the
+    reference's behaviour) runs the GPU path once and serves every label from that result."""
+    from .backend import Backend, aggregate_matches
+    from .store import load_profile_batch
+    be = backend or Backend()
+    cands = candidates_for(be.name, tags)
+    by_id = {c["id"]: c for c in cands}
+    if not cands:
+        return lambda label, segs: []
+    if not per_label:
+        rows = rows_with_trust(be.identify_speaker(audio_path, cands, threshold), by_id, be.name)
+        return lambda label, segs: rows
+
+    batch = load_profile_batch(cands, be.name, model_prefix=f"{be.name}-")
+
+    def rows_fn(label, segs):
+        spans_in = [(s["start"], s["end"]) for s in segs]
+        pcm, spans = be._windows(audio_path, spans_in)
+        E, Eb, re = be.embed_windows(pcm)
+        idx, sc = be.score_windows(E, Eb, re, batch)
+        return rows_with_trust(aggregate_matches(idx[:, 0], sc[:, 0], spans, batch, threshold), by_id, be.name)
+    return rows_fn

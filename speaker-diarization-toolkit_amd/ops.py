@@ -1,0 +1,221 @@
+"""Host-side wrappers over the C ABI: torch tensors in, torch tensors out, every byte of compute
+inside libsdk_hip.so.  torch supplies device memory and the current HIP stream only.
+
+`Engine` is the long-lived per-process, per-GPU object (context + resident weights + fbank
+tables + reusable scratch): the reference constructs its backend once per CLI process
+(speaker_detection_backends/base.py:291-293), so everything expensive lives here and is built
+lazily exactly once.
+"""
+from __future__ import annotations
+
+import ctypes as C
+from typing import Dict, Optional, Tuple
+
+import numpy as np
+import torch
+
+from . import _lib
+from ._lib import ConvGemmArgs, EcapaDesc, SdkError, check
+from .weights import DEFAULT_CONFIG, EcapaConfig, synthetic_weights
+from .weights_pack import N_MELS_PADDED, pack_weights
+
+HOP = 160
+EMBED_DIM = 192
+
+
+def _ptr(t: Optional[torch.Tensor]) -> Optional[int]:
+    return None if t is None else t.data_ptr()
+
+
+def _stream() -> int:
+    return torch.cuda.current_stream().cuda_stream
+
+
+def _need(t: torch.Tensor, dtype, name: str) -> torch.Tensor:
+    if not t.is_cuda:
+        raise SdkError(f"{name} must live in device memory (got {t.device}); there is no CPU path")
+    if t.dtype != dtype:
+        raise SdkError(f"{name} must be {dtype}, got {t.dtype}")
+    return t
+
+
+def num_frames(n_samples: int) -> int:
+    return 1 + n_samples // HOP
+
+
+class Engine:
+    def __init__(self, device: int = 0, weights: Optional[Dict[str, np.ndarray]] = None,
+                 cfg: EcapaConfig = DEFAULT_CONFIG, seed: int = 0):
+        self.lib = _lib.load_library()
+        self.ctx = _lib.get_ctx(device)        # raises SdkError without a gfx950 device
+        self.device = torch.device("cuda", device)
+        self.cfg = cfg
+        self._weights_host = weights
+        self._seed = seed
+        self._wblob = None
+        self._desc = None
+        self._fbank_tabs = None
+        self._scratch: Dict[str, torch.Tensor] = {}
+
+    # ------------------------------------------------------------------ resident state
+    def _scratch_bytes(self, key: str, nbytes: int) -> torch.Tensor:
+        buf = self._scratch.get(key)
+        if buf is None or buf.numel() < nbytes:
+            self._scratch[key] = buf = torch.empty(max(nbytes, 256), dtype=torch.uint8, device=self.device)
+        return buf
+
+    def fbank_tables(self) -> torch.Tensor:
+        if self._fbank_tabs is None:
+            n = self.lib.sdk_fbank_tables_bytes()
+            host = np.zeros(n, dtype=np.uint8)
+            check(self.lib.sdk_fbank_tables_fill(host.ctypes.data, n), "sdk_fbank_tables_fill")
+            self._fbank_tabs = torch.from_numpy(host).to(self.device)
+        return self._fbank_tabs
+
+    def load_weights(self, weights: Optional[Dict[str, np.ndarray]] = None) -> None:
+        if weights is not None:
+            self._weights_host = weights
+        if self._weights_host is None:
+            self._weights_host = synthetic_weights(self._seed, self.cfg)
+        blob, f = pack_weights(self._weights_host, self.cfg)
+        self._wblob = torch.from_numpy(blob).to(self.device)
+        d = EcapaDesc()
+        for k, v in f.items():
+            if k == "dilation":
+                d.dilation = (C.c_int32 * 4)(*v)
+            elif k == "off":
+                d.off = (C.c_int64 * 256)(*v)
+            else:
+                setattr(d, k, v)
+        self._desc = d
+
+    @property
+    def desc(self) -> EcapaDesc:
+        if self._desc is None:
+            self.load_weights()
+        return self._desc
+
+    # ------------------------------------------------------------------ k1
+    def fbank(self, pcm: torch.Tensor, ldf: int = N_MELS_PADDED) -> torch.Tensor:
+        """pcm [B, S] int16 (device) -> feats [B*T, ldf] bf16 (channels >= 80 are zero)."""
+        _need(pcm, torch.int16, "pcm")
+        pcm = pcm.contiguous()
+        B, S = pcm.shape
+        T = num_frames(S)
+        feats = torch.empty((B * T, ldf), dtype=torch.bfloat16, device=self.device)
+        wsb = self.lib.sdk_fbank_workspace_bytes(B, S)
+        ws = self._scratch_bytes("fbank", wsb)
+        check(self.lib.sdk_fbank(self.ctx, pcm.data_ptr(), B, S, self.fbank_tables().data_ptr(), feats.data_ptr(), ldf,
+                                 ws.data_ptr(), ws.numel(), _stream()), "sdk_fbank")
+        return feats
+
+    # ------------------------------------------------------------------ k2
+    def ecapa_forward(self, feats: torch.Tensor, B: int, T: int) -> torch.Tensor:
+        """feats [B*T, ldf] bf16 -> raw embeddings [B, 192] fp32."""
+        _need(feats, torch.bfloat16, "feats")
+        if feats.shape[0] != B * T or feats.stride(1) != 1:
+            raise SdkError(f"feats must be [B*T={B * T}, ldf] row-major, got {tuple(feats.shape)}")
+        d = self.desc
+        wsb = self.lib.sdk_ecapa_workspace_bytes(C.byref(d), B, T)
+        ws = self._scratch_bytes("ecapa", wsb)
+        emb = torch.empty((B, self.cfg.embed_dim), dtype=torch.float32, device=self.device)
+        check(self.lib.sdk_ecapa_forward(self.ctx, self._wblob.data_ptr(), C.byref(d), feats.data_ptr(), feats.stride(0),
+                                         B, T, ws.data_ptr(), ws.numel(), emb.data_ptr(), _stream()), "sdk_ecapa_forward")
+        return emb
+
+    # ------------------------------------------------------------------ k3
+    def l2norm(self, X: torch.Tensor) -> Tuple[torch.Tensor, torch.Tensor, torch.Tensor]:
+        """X [N, d] fp32 -> (E fp32 unit rows, Eb bf16 copy, resid [N] = ||E - Eb||)."""
+        _need(X, torch.float32, "X")
+        X = X.contiguous()
+        N, d = X.shape
+        E = torch.empty_like(X)
+        Eb = torch.empty((N, d), dtype=torch.bfloat16, device=self.device)
+        r = torch.empty((N,), dtype=torch.float32, device=self.device)
+        check(self.lib.sdk_l2norm(self.ctx, X.data_ptr(), N, d, E.data_ptr(), Eb.data_ptr(), r.data_ptr(), _stream()), "sdk_l2norm")
+        return E, Eb, r
+
+    # ------------------------------------------------------------------ k4
+    def affinity_topk(self, E, Eb, re, P, Pb, rp_max, k: int = 1, want_count: bool = False):
+        """Cosine affinity of unit rows E [N,192] vs P [Pn,192] -> (idx [N,k] int32, score [N,k] fp32).
+        rp_max: device tensor [1] = max profile residual (from l2norm)."""
+        for t, dt, nm in ((E, torch.float32, "E"), (Eb, torch.bfloat16, "Eb"), (re, torch.float32, "resid_e"),
+                          (P, torch.float32, "P"), (Pb, torch.bfloat16, "Pb"), (rp_max, torch.float32, "resid_p")):
+            _need(t, dt, nm)
+        N, d = E.shape
+        Pn = P.shape[0]
+        idx = torch.empty((N, k), dtype=torch.int32, device=self.device)
+        sc = torch.empty((N, k), dtype=torch.float32, device=self.device)
+        cnt = torch.zeros((1,), dtype=torch.int32, device=self.device) if want_count else None
+        ws = self._scratch_bytes("affinity", self.lib.sdk_affinity_workspace_bytes(N))
+        check(self.lib.sdk_affinity_topk(self.ctx, E.data_ptr(), Eb.data_ptr(), re.data_ptr(), P.data_ptr(), Pb.data_ptr(),
+                                         rp_max.data_ptr(), N, Pn, d, k, idx.data_ptr(), sc.data_ptr(), _ptr(cnt),
+                                         ws.data_ptr(), ws.numel(), _stream()), "sdk_affinity_topk")
+        return (idx, sc, cnt) if want_count else (idx, sc)
+
+    # ------------------------------------------------------------------ whole path
+    def embed_pcm(self, pcm: torch.Tensor):
+        """pcm [B, S] int16 on device -> (E, Eb, resid) L2-normalised embeddings."""
+        B, S = pcm.shape
+        feats = self.fbank(pcm)
+        emb = self.ecapa_forward(feats, B, num_frames(S))
+        return self.l2norm(emb)
+
+    # ------------------------------------------------------------------ building blocks (tests / tuning)
+    def conv_gemm(self, A, W, N, Cin, taps=1, dil=1, T=None, bias=None, scale=None, shift=None, ubias=None,
+                  relu=False, tanh=False, out_bf16=True, out_f32=False, X2=None):
+        _need(A, torch.bfloat16, "A"); _need(W, torch.bfloat16, "W")
+        M = A.shape[0]
+        T = T or M
+        g = ConvGemmArgs()
+        g.A, g.lda, g.W = A.data_ptr(), A.stride(0), W.data_ptr()
+        Cout = torch.empty((M, N), dtype=torch.bfloat16, device=self.device) if out_bf16 else None
+        C32 = torch.empty((M, N), dtype=torch.float32, device=self.device) if out_f32 else None
+        S = torch.empty((M, N), dtype=torch.bfloat16, device=self.device) if X2 is not None else None
+        g.C, g.ldc, g.C32, g.ldc32 = _ptr(Cout), N, _ptr(C32), N
+        g.bias, g.scale, g.shift = _ptr(bias), _ptr(scale), _ptr(shift)
+        g.ubias, g.ldub = _ptr(ubias), (ubias.stride(0) if ubias is not None else 0)
+        g.X2, g.ldx2 = _ptr(X2), (X2.stride(0) if X2 is not None else 0)
+        g.S, g.lds = _ptr(S), N
+        g.M, g.N, g.Cin, g.taps, g.dil, g.T = M, N, Cin, taps, dil, T
+        g.flags = (_lib.GEMM_RELU if relu else 0) | (_lib.GEMM_TANH if tanh else 0)
+        check(self.lib.sdk_conv_gemm(self.ctx, C.byref(g), _stream()), "sdk_conv_gemm")
+        return Cout, C32, S
+
+    def se_gate_residual(self, z, x, w1t, b1, w2t, b2, B, T):
+        C_ = z.shape[1]
+        out = torch.empty_like(z)
+        check(self.lib.sdk_se_gate_residual(self.ctx, z.data_ptr(), z.stride(0), x.data_ptr(), x.stride(0), w1t.data_ptr(),
+                                            b1.data_ptr(), w2t.data_ptr(), b2.data_ptr(), out.data_ptr(), out.stride(0),
+                                            B, T, C_, w1t.shape[1], _stream()), "sdk_se_gate_residual")
+        return out
+
+    def asp_stats(self, h, B, T):
+        Cm = h.shape[1]
+        out = torch.empty((B, 2 * Cm), dtype=torch.float32, device=self.device)
+        check(self.lib.sdk_asp_stats(self.ctx, h.data_ptr(), h.stride(0), B, T, Cm, out.data_ptr(), _stream()), "sdk_asp_stats")
+        return out
+
+    def rows_fc(self, x, wt, bias=None, in_scale=None, in_shift=None, act=0):
+        B, Cin = x.shape
+        Nout = wt.shape[1]
+        out = torch.empty((B, Nout), dtype=torch.float32, device=self.device)
+        check(self.lib.sdk_rows_fc(self.ctx, x.data_ptr(), x.stride(0), _ptr(in_scale), _ptr(in_shift), wt.data_ptr(), _ptr(bias),
+                                   out.data_ptr(), Nout, B, Cin, Nout, act, _stream()), "sdk_rows_fc")
+        return out
+
+    def asp_pool(self, logits, h, B, T):
+        Cm = h.shape[1]
+        out = torch.empty((B, 2 * Cm), dtype=torch.float32, device=self.device)
+        check(self.lib.sdk_asp_pool(self.ctx, logits.data_ptr(), logits.stride(0), h.data_ptr(), h.stride(0), B, T, Cm,
+                                    out.data_ptr(), _stream()), "sdk_asp_pool")
+        return out
+
+
+_engines: Dict[int, Engine] = {}
+
+
+def get_engine(device: int = 0, **kw) -> Engine:
+    if device not in _engines:
+        _engines[device] = Engine(device, **kw)
+    return _engines[device]

@@ -1,0 +1,161 @@
+"""ECAPA-TDNN (C=1024) parameter table: seeded synthetic weights, load/save, and
+the device packing the HIP kernels consume.
+
+The reference ships no local embedding model (ECAPA-TDNN exists
+there only as the word "future", speaker_detection_backends/backends.yaml:22-31),
+so the architecture is the public one and the weights are
+either loaded from an ``.npz`` the user supplies (same key names as below) or
+generated here from a seed.  No network, no checkpoint download.
+
+Key naming (fp32 host arrays, conv weights in torch layout [C_out, C_in, k]):
+
+    blk0.conv.{w,b}  blk0.bn.{gamma,beta,mean,var}
+    blk{1,2,3}.tdnn1.conv.{w,b} / .bn.*          1x1 1024->1024
+    blk{i}.res2net.{0..6}.conv.{w,b} / .bn.*     128->128 k3, dilation i+1
+    blk{i}.tdnn2.conv.{w,b} / .bn.*              1x1 1024->1024
+    blk{i}.se.conv1.{w,b}  blk{i}.se.conv2.{w,b} 1024->128->1024 (per utterance)
+    mfa.conv.{w,b} / mfa.bn.*                    1x1 3072->3072
+    asp.tdnn.conv.{w,b} / asp.tdnn.bn.*          1x1 9216->128  ([h, mean, std])
+    asp.conv.{w,b}                               1x1 128->3072
+    asp_bn.{gamma,beta,mean,var}                 6144
+    fc.{w,b}                                     6144->192
+"""
+from __future__ import annotations
+
+from dataclasses import dataclass
+from typing import Dict, Tuple
+
+import numpy as np
+
+BN_EPS = 1e-5
+
+
+@dataclass(frozen=True)
+class EcapaConfig:
+    n_mels: int = 80
+    channels: int = 1024
+    mfa_channels: int = 3072
+    res2net_scale: int = 8
+    se_channels: int = 128
+    attn_channels: int = 128
+    embed_dim: int = 192
+    kernel0: int = 5
+    dilations: Tuple[int, ...] = (2, 3, 4)
+
+    @property
+    def sub_channels(self) -> int:
+        return self.channels // self.res2net_scale
+
+    def macs_per_frame(self) -> int:
+        c, s = self.channels, self.sub_channels
+        blk = 2 * c * c + (self.res2net_scale - 1) * s * s * 3
+        return (self.n_mels * self.kernel0 * c + len(self.dilations) * blk + self.mfa_channels ** 2
+                + 3 * self.mfa_channels * self.attn_channels + self.attn_channels * self.mfa_channels)
+
+    def macs_per_utterance(self) -> int:
+        c = self.channels
+        return len(self.dilations) * 2 * c * self.se_channels + 2 * self.mfa_channels * self.embed_dim
+
+    def param_count(self) -> int:
+        return sum(int(np.prod(s)) for n, s in param_shapes(self).items()
+                   if not (n.endswith(".mean") or n.endswith(".var")))
+
+
+DEFAULT_CONFIG = EcapaConfig()
+
+
+def param_shapes(cfg: EcapaConfig = DEFAULT_CONFIG) -> Dict[str, Tuple[int, ...]]:
+    """Ordered name -> shape table (the order fixes the RNG stream of synthetic_weights)."""
+    sh: Dict[str, Tuple[int, ...]] = {}
+
+    def conv(name, co, ci, k):
+        sh[f"{name}.conv.w"] = (co, ci, k)
+        sh[f"{name}.conv.b"] = (co,)
+
+    def bn(name, c):
+        for f in ("gamma", "beta", "mean", "var"):
+            sh[f"{name}.{f}"] = (c,)
+
+    c, s = cfg.channels, cfg.sub_channels
+    conv("blk0", c, cfg.n_mels, cfg.kernel0); bn("blk0.bn", c)
+    for i in range(1, len(cfg.dilations) + 1):
+        conv(f"blk{i}.tdnn1", c, c, 1); bn(f"blk{i}.tdnn1.bn", c)
+        for j in range(cfg.res2net_scale - 1):
+            conv(f"blk{i}.res2net.{j}", s, s, 3); bn(f"blk{i}.res2net.{j}.bn", s)
+        conv(f"blk{i}.tdnn2", c, c, 1); bn(f"blk{i}.tdnn2.bn", c)
+        sh[f"blk{i}.se.conv1.w"] = (cfg.se_channels, c, 1); sh[f"blk{i}.se.conv1.b"] = (cfg.se_channels,)
+        sh[f"blk{i}.se.conv2.w"] = (c, cfg.se_channels, 1); sh[f"blk{i}.se.conv2.b"] = (c,)
+    m = cfg.mfa_channels
+    conv("mfa", m, m, 1); bn("mfa.bn", m)
+    conv("asp.tdnn", cfg.attn_channels, 3 * m, 1); bn("asp.tdnn.bn", cfg.attn_channels)
+    sh["asp.conv.w"] = (m, cfg.attn_channels, 1); sh["asp.conv.b"] = (m,)
+    bn("asp_bn", 2 * m)
+    sh["fc.w"] = (cfg.embed_dim, 2 * m, 1); sh["fc.b"] = (cfg.embed_dim,)
+    return sh
+
+
+def synthetic_weights(seed: int = 0, cfg: EcapaConfig = DEFAULT_CONFIG) -> Dict[str, np.ndarray]:
+    """Deterministic random-init weights (numpy Generator PCG64, one stream, table order).
+
+    Conv weights are Kaiming-normal (std = sqrt(2/fan_in)) so activations keep O(1)
+    scale through the depth; BN statistics are mildly perturbed so BN is not the identity.
+    """
+    rng = np.random.default_rng(seed)
+    out: Dict[str, np.ndarray] = {}
+    for name, shape in param_shapes(cfg).items():
+        if name.endswith(".w"):
+            fan_in = shape[1] * shape[2]
+            gain = 1.0 if name.startswith(("fc", "asp.conv")) or ".se.conv2" in name else 2.0
+            a = rng.standard_normal(shape, dtype=np.float32) * np.float32(np.sqrt(gain / fan_in))
+        elif name.endswith(".b") or name.endswith(".beta") or name.endswith(".mean"):
+            a = rng.standard_normal(shape, dtype=np.float32) * np.float32(0.1)
+        elif name.endswith(".gamma"):
+            a = rng.uniform(0.8, 1.2, shape).astype(np.float32)
+        elif name.endswith(".var"):
+            a = rng.uniform(0.5, 1.5, shape).astype(np.float32)
+        else:  # pragma: no cover
+            raise KeyError(name)
+        out[name] = np.ascontiguousarray(a, dtype=np.float32)
+    return out
+
+
+def save_weights(path, weights: Dict[str, np.ndarray]) -> None:
+    np.savez(path, **weights)
+
+
+def load_weights(path, cfg: EcapaConfig = DEFAULT_CONFIG) -> Dict[str, np.ndarray]:
+    """Load an .npz written by save_weights (numpy's non-executing loader: allow_pickle=False)."""
+    with np.load(path, allow_pickle=False) as z:
+        w = {k: np.ascontiguousarray(z[k], dtype=np.float32) for k in z.files}
+    check_weights(w, cfg)
+    return w
+
+
+def check_weights(weights: Dict[str, np.ndarray], cfg: EcapaConfig = DEFAULT_CONFIG) -> None:
+    shapes = param_shapes(cfg)
+    missing = [k for k in shapes if k not in weights]
+    if missing:
+        raise ValueError(f"weights missing {len(missing)} tensors, e.g. {missing[:3]}")
+    for k, s in shapes.items():
+        if tuple(weights[k].shape) != s:
+            raise ValueError(f"weight {k}: shape {tuple(weights[k].shape)} != expected {s}")
+
+
+def bn_affine(weights: Dict[str, np.ndarray], name: str) -> Tuple[np.ndarray, np.ndarray]:
+    """Eval-mode BatchNorm as y = x*scale + shift (fp32; computed in fp64 then rounded once)."""
+    g = weights[f"{name}.gamma"].astype(np.float64)
+    b = weights[f"{name}.beta"].astype(np.float64)
+    m = weights[f"{name}.mean"].astype(np.float64)
+    v = weights[f"{name}.var"].astype(np.float64)
+    scale = g / np.sqrt(v + BN_EPS)
+    shift = b - m * scale
+    return scale.astype(np.float32), shift.astype(np.float32)
+
+
+def weights_digest(weights: Dict[str, np.ndarray]) -> str:
+    """Short content hash used in Backend.model_version."""
+    import hashlib
+    h = hashlib.sha256()
+    for k in sorted(weights):
+        h.update(k.encode()); h.update(np.ascontiguousarray(weights[k]).tobytes())
+    return h.hexdigest()[:12]

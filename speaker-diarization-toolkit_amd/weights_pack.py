@@ -1,0 +1,120 @@
+"""Pack an ECAPA-TDNN weight dict (weights.py naming) into the single device blob + offset table
+that sdk_ecapa_forward consumes.  Slot numbering mirrors csrc/ecapa_layout.h.
+
+Layout rules:
+  * operands of MFMA GEMMs are bf16, stored [C_out][taps * C_in_padded] (tap-major, K contiguous);
+    the mel input is zero-padded 80 -> 128 channels so every K-step is a full 64-channel tile;
+  * eval-mode BatchNorm is folded to a per-channel fp32 (scale, shift) applied in the epilogue;
+  * everything evaluated on the VALU (SE gates, global-context bias, final FC) stays fp32 and is
+    stored transposed ([C_in][C_out]) so consecutive lanes read consecutive addresses.
+"""
+from __future__ import annotations
+
+from typing import Dict, List, Tuple
+
+import numpy as np
+
+from .weights import DEFAULT_CONFIG, EcapaConfig, bn_affine, check_weights
+
+N_MELS_PADDED = 128
+ALIGN = 256
+
+EL_W, EL_B, EL_SCALE, EL_SHIFT = 0, 1, 2, 3
+EL_BLK0 = 0
+EL_TDNN1, EL_TDNN2 = 0, 32
+EL_SE_W1T, EL_SE_B1, EL_SE_W2T, EL_SE_B2 = 36, 37, 38, 39
+EL_MFA, EL_ASP_WH, EL_ASP_WMS_T, EL_ASP_B, EL_ASP_SCALE, EL_ASP_SHIFT = 0, 4, 5, 6, 7, 8
+EL_ASP_W2, EL_ASP_B2, EL_ASPBN_SCALE, EL_ASPBN_SHIFT, EL_FC_WT, EL_FC_B = 9, 10, 11, 12, 13, 14
+
+
+def block_base(i: int) -> int:
+    return 4 + (i - 1) * 40
+
+
+def res2net_slot(j: int) -> int:
+    return 4 + 4 * j
+
+
+def tail_base(n_blocks: int) -> int:
+    return 4 + n_blocks * 40
+
+
+def f32_to_bf16_bits(x: np.ndarray) -> np.ndarray:
+    """fp32 -> bf16 bit pattern, round-to-nearest-even (finite inputs)."""
+    u = np.ascontiguousarray(x, dtype=np.float32).view(np.uint32).astype(np.uint64)
+    return ((u + 0x7FFF + ((u >> 16) & 1)) >> 16).astype(np.uint16)
+
+
+def bf16_bits_to_f32(b: np.ndarray) -> np.ndarray:
+    return (np.ascontiguousarray(b, dtype=np.uint16).astype(np.uint32) << 16).view(np.float32)
+
+
+def conv_weight_kmajor(w: np.ndarray, cin_pad: int | None = None) -> np.ndarray:
+    """[C_out, C_in, k] -> bf16 bits [C_out, k * C_in_pad] (tap-major, zero-padded channels)."""
+    co, ci, k = w.shape
+    cp = cin_pad or ci
+    out = np.zeros((co, k, cp), dtype=np.float32)
+    out[:, :, :ci] = np.transpose(w, (0, 2, 1))
+    return f32_to_bf16_bits(out.reshape(co, k * cp))
+
+
+def pack_weights(weights: Dict[str, np.ndarray], cfg: EcapaConfig = DEFAULT_CONFIG):
+    """Return (blob: np.uint8 [bytes], desc_fields: dict) - host side only, no device access."""
+    check_weights(weights, cfg)
+    chunks: List[Tuple[int, np.ndarray]] = []
+    off = [-1] * 256
+    cur = 0
+
+    def put(slot: int, arr: np.ndarray):
+        nonlocal cur
+        a = np.ascontiguousarray(arr)
+        assert a.dtype in (np.uint16, np.float32), a.dtype
+        off[slot] = cur
+        chunks.append((cur, a.view(np.uint8).reshape(-1)))
+        cur += (a.nbytes + ALIGN - 1) // ALIGN * ALIGN
+
+    def tdnn(slot: int, name: str, cin_pad=None):
+        put(slot + EL_W, conv_weight_kmajor(weights[f"{name}.conv.w"], cin_pad))
+        put(slot + EL_B, weights[f"{name}.conv.b"].astype(np.float32))
+        s, sh = bn_affine(weights, f"{name}.bn")
+        put(slot + EL_SCALE, s)
+        put(slot + EL_SHIFT, sh)
+
+    nb = len(cfg.dilations)
+    tdnn(EL_BLK0, "blk0", N_MELS_PADDED)
+    for i in range(1, nb + 1):
+        b = block_base(i)
+        tdnn(b + EL_TDNN1, f"blk{i}.tdnn1")
+        for j in range(cfg.res2net_scale - 1):
+            tdnn(b + res2net_slot(j), f"blk{i}.res2net.{j}")
+        tdnn(b + EL_TDNN2, f"blk{i}.tdnn2")
+        put(b + EL_SE_W1T, weights[f"blk{i}.se.conv1.w"][:, :, 0].T.astype(np.float32))
+        put(b + EL_SE_B1, weights[f"blk{i}.se.conv1.b"])
+        put(b + EL_SE_W2T, weights[f"blk{i}.se.conv2.w"][:, :, 0].T.astype(np.float32))
+        put(b + EL_SE_B2, weights[f"blk{i}.se.conv2.b"])
+    t = tail_base(nb)
+    tdnn(t + EL_MFA, "mfa")
+    m = cfg.mfa_channels
+    wt = weights["asp.tdnn.conv.w"][:, :, 0]
+    put(t + EL_ASP_WH, f32_to_bf16_bits(wt[:, :m]))
+    put(t + EL_ASP_WMS_T, wt[:, m:].T.astype(np.float32))
+    put(t + EL_ASP_B, weights["asp.tdnn.conv.b"])
+    s, sh = bn_affine(weights, "asp.tdnn.bn")
+    put(t + EL_ASP_SCALE, s)
+    put(t + EL_ASP_SHIFT, sh)
+    put(t + EL_ASP_W2, f32_to_bf16_bits(weights["asp.conv.w"][:, :, 0]))
+    put(t + EL_ASP_B2, weights["asp.conv.b"])
+    s, sh = bn_affine(weights, "asp_bn")
+    put(t + EL_ASPBN_SCALE, s)
+    put(t + EL_ASPBN_SHIFT, sh)
+    put(t + EL_FC_WT, weights["fc.w"][:, :, 0].T.astype(np.float32))
+    put(t + EL_FC_B, weights["fc.b"])
+
+    blob = np.zeros(cur, dtype=np.uint8)
+    for o, a in chunks:
+        blob[o:o + a.size] = a
+    fields = dict(n_mels_padded=N_MELS_PADDED, channels=cfg.channels, sub_channels=cfg.sub_channels,
+                  scale=cfg.res2net_scale, se_channels=cfg.se_channels, attn_channels=cfg.attn_channels,
+                  mfa_channels=cfg.mfa_channels, embed_dim=cfg.embed_dim, n_blocks=nb, kernel0=cfg.kernel0,
+                  dilation=list(cfg.dilations) + [0] * (4 - nb), off=off)
+    return blob, fields
