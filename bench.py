@@ -1,0 +1,224 @@
+#!/usr/bin/env python3
+"""bench.py - BASELINE.json's metric on BASELINE.json's config, on N MI355X of one node.
+
+Workload (N = 1): config #2 of BASELINE.json - "1k synthetic 2-s segments -> ECAPA-TDNN
+embeddings on 1 MI355X, cosine assign vs 100 profiles".  One step = one pass of the hot path
+(fbank -> ECAPA-TDNN C=1024 forward -> L2-normalise -> cosine affinity + argmax) over the
+1000 resident segments.  N > 1: every rank owns its own 1000 segments (weak scaling, segments
+are independent), profiles are replicated, and the step ends with the RCCL all-gather of the
+[1000, 192] embeddings that the global clustering stage consumes (torch.distributed, backend
+"nccl" = RCCL).  Inputs are generated on the device before the timed region.
+
+Prints ONE JSON line on rank 0 (see README / DESIGN.md §6 for the field definitions).
+"""
+from __future__ import annotations
+
+import argparse
+import importlib
+import json
+import os
+import sys
+import time
+from pathlib import Path
+
+import numpy as np
+import torch
+
+ROOT = Path(__file__).resolve().parent
+sys.path.insert(0, str(ROOT))
+PKG = "speaker-diarization-toolkit_amd"
+
+# SURVEY.md §8(d) algorithmic figures
+SEG_SAMPLES = 32000
+T_FRAMES = 201
+MAC_PER_FRAME = 18_743_296
+MAC_PER_UTT = 1_966_080
+FLOP_PER_SEGMENT = 2 * (MAC_PER_FRAME * T_FRAMES + MAC_PER_UTT)          # 7.539 GFLOP
+BYTES_PER_SEGMENT_BF16 = 47_440 * T_FRAMES * 2 + 128_000 + 768             # layer-boundary model, 19.07 MB
+PEAK_BF16_MFMA = 2.5e15        # dense, MI355X_MICROARCH.md
+PEAK_HBM = 8.0e12
+
+
+def synth_pcm(B: int, seed: int) -> np.ndarray:
+    """SURVEY.md §8(d) cfg 2: N(0, 0.1) clipped + two sinusoids so the spectrum is not flat."""
+    rng = np.random.default_rng(seed)
+    t = np.arange(SEG_SAMPLES, dtype=np.float32) / 16000.0
+    x = rng.normal(0.0, 0.1, (B, SEG_SAMPLES)).astype(np.float32)
+    f1 = rng.uniform(100, 400, (B, 1)).astype(np.float32)
+    f2 = rng.uniform(1000, 3000, (B, 1)).astype(np.float32)
+    x += 0.2 * np.sin(2 * np.pi * f1 * t) + 0.1 * np.sin(2 * np.pi * f2 * t)
+    return np.clip(np.round(x * 32768.0), -32768, 32767).astype(np.int16)
+
+
+def unit_rows(n: int, d: int, seed: int) -> np.ndarray:
+    x = np.random.default_rng(seed).standard_normal((n, d)).astype(np.float32)
+    return x / np.linalg.norm(x, axis=1, keepdims=True)
+
+
+def cpu_baseline(pcm: np.ndarray, P: np.ndarray, budget_s: float = 15.0):
+    """The oracle (port of the path to torch-CPU fp32, all host cores) on a bounded sample."""
+    from oracle import ecapa as oecapa, fbank as ofbank, scoring as oscoring
+    weights = importlib.import_module(f"{PKG}.weights").synthetic_weights(0)
+    cores = os.cpu_count() or 1
+    torch.set_num_threads(cores)
+    model = oecapa.EcapaOracle(weights, "fp32", torch.float32)
+
+    def run(n):
+        t0 = time.perf_counter()
+        feats = torch.from_numpy(ofbank.fbank(pcm[:n]))
+        e = oecapa.l2_normalise(model.embed(feats).numpy())
+        oscoring.affinity_topk_fp32(e, P, 1)
+        return time.perf_counter() - t0
+
+    run(1)                                     # warm-up (thread pool, allocator)
+    t2 = run(2)
+    n = int(max(2, min(len(pcm), budget_s / max(t2 / 2, 1e-3))))
+    dt = run(n)
+    return {"value": n / dt, "unit": "segment-embeddings/sec", "cores": cores, "kind": "port",
+            "sample": f"{n} of the {len(pcm)} segments, oracle fbank+ECAPA(fp32)+L2+cosine argmax on torch-CPU, {dt:.1f} s"}
+
+
+def main() -> int:
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=10)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--segments", type=int, default=1000, help="segments per GPU (config #2: 1000)")
+    ap.add_argument("--profiles", type=int, default=100)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-affinity-config3", action="store_true")
+    args = ap.parse_args()
+
+    rank = int(os.environ.get("RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    local = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus:
+        if rank == 0:
+            print(f"bench.py: --gpus {args.gpus} but WORLD_SIZE={world}; launch with torch.distributed.run", file=sys.stderr)
+        return 2
+    torch.cuda.set_device(local)
+    dist = None
+    if world > 1:
+        import torch.distributed as dist
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group(backend="nccl", device_id=torch.device("cuda", local))
+
+    ops = importlib.import_module(f"{PKG}.ops")
+    _lib = importlib.import_module(f"{PKG}._lib")
+    eng = ops.get_engine(local)
+    info = _lib.device_info(local)
+    dev = eng.device
+
+    B = args.segments
+    pcm_host = synth_pcm(B, seed=rank)
+    pcm = torch.from_numpy(pcm_host).to(dev)
+    P_host = unit_rows(args.profiles, 192, seed=1)
+    Pn, Pb, rp = eng.l2norm(torch.from_numpy(P_host).to(dev))
+    rpm = rp.max().reshape(1)
+    gathered = torch.empty((world * B, 192), dtype=torch.float32, device=dev) if world > 1 else None
+    eng.desc                                   # upload weights before timing
+
+    def step():
+        E, Eb, re = eng.embed_pcm(pcm)
+        idx, sc = eng.affinity_topk(E, Eb, re, Pn, Pb, rpm, k=1)
+        if world > 1:
+            dist.all_gather_into_tensor(gathered, E)
+        return idx, sc
+
+    for _ in range(args.warmup):
+        step()
+
+    def fence():
+        torch.cuda.synchronize()
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    fence()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        step()
+    fence()
+    elapsed = time.perf_counter() - t0
+    if world > 1:
+        tt = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+        elapsed = float(tt.item())
+
+    out = None
+    if rank == 0:
+        ms_step = elapsed / args.steps * 1e3
+        value = world * B * args.steps / elapsed
+
+        # ---- roofline pass: per-launch HIP events on the launch stream, one extra step
+        eng.profile_begin()
+        step()
+        prof = eng.profile_end()
+        conv = prof["conv_gemm"]
+        conv_alg_flops = 2.0 * MAC_PER_FRAME * T_FRAMES * B          # SURVEY §8(d) per-frame MACs x frames x segments
+        achieved = conv_alg_flops / (conv["ms"] * 1e-3)
+        kernels = {k: {"launches": v["launches"], "ms": round(v["ms"], 4),
+                       "tflops": round(v["flops"] / (v["ms"] * 1e-3) / 1e12, 2) if v["flops"] else None,
+                       "gbps": round(v["bytes"] / (v["ms"] * 1e-3) / 1e9, 1) if v["bytes"] else None}
+                   for k, v in prof.items()}
+        step_dev_ms = sum(v["ms"] for v in prof.values())
+        roofline = {"kernel": "conv_gemm_kernel", "bound": "mfma", "achieved": round(achieved / 1e12, 2), "peak": PEAK_BF16_MFMA / 1e12,
+                    "unit": "TFLOP/s", "frac": round(achieved / PEAK_BF16_MFMA, 4), "traffic": None,
+                    "launches_per_step": conv["launches"], "avg_launch_ms": round(conv["ms"] / conv["launches"], 4),
+                    "algorithmic_flops_per_step": conv_alg_flops, "executed_tflops": round(conv["flops"] / (conv["ms"] * 1e-3) / 1e12, 2)}
+        # north_star's second view of the forward: layer-boundary HBM model (19.07 MB / segment, bf16)
+        fwd_ms = sum(prof[k]["ms"] for k in ("conv_gemm", "se_gate", "asp_stats", "rows_fc", "asp_pool", "copy") if k in prof)
+        fwd_hbm = {"bound": "hbm", "achieved": round(BYTES_PER_SEGMENT_BF16 * B / (fwd_ms * 1e-3) / 1e9, 1), "peak": PEAK_HBM / 1e9,
+                   "unit": "GB/s", "frac": round(BYTES_PER_SEGMENT_BF16 * B / (fwd_ms * 1e-3) / PEAK_HBM, 4),
+                   "model": "SURVEY.md 8(d) layer-boundary bytes (19.07 MB/segment) / forward device time"}
+
+        # ---- affinity pairs/sec at config #3 (100k segments x 1k profiles), HIP events
+        aff = None
+        if not args.no_affinity_config3:
+            N3, P3 = 100_000, 1000
+            E3, E3b, r3 = eng.l2norm(torch.randn(N3, 192, device=dev, generator=torch.Generator(device=dev).manual_seed(3)))
+            Q3, Q3b, q3 = eng.l2norm(torch.randn(P3, 192, device=dev, generator=torch.Generator(device=dev).manual_seed(4)))
+            q3m = q3.max().reshape(1)
+            for _ in range(3):
+                eng.affinity_topk(E3, E3b, r3, Q3, Q3b, q3m, k=1)
+            reps = 10
+            eng.profile_begin()
+            for _ in range(reps):
+                _, _, cnt = eng.affinity_topk(E3, E3b, r3, Q3, Q3b, q3m, k=1, want_count=True)
+            p3 = eng.profile_end()
+            coarse_ms = p3["affinity_coarse"]["ms"] / reps
+            total_ms = sum(v["ms"] for v in p3.values()) / reps
+            fl = 2.0 * N3 * P3 * 192
+            aff = {"workload": "config #3: 100k segments x 1k profiles, fused top-k + exact fp32 re-score",
+                   "pairs_per_sec": round(N3 * P3 / (total_ms * 1e-3), 1), "ms_total": round(total_ms, 4),
+                   "ms_coarse_mfma": round(coarse_ms, 4), "rows_rescanned": int(cnt.item()),
+                   "roofline": {"kernel": "affinity_coarse_kernel", "bound": "mfma", "achieved": round(fl / (coarse_ms * 1e-3) / 1e12, 2),
+                                "peak": PEAK_BF16_MFMA / 1e12, "unit": "TFLOP/s", "frac": round(fl / (coarse_ms * 1e-3) / PEAK_BF16_MFMA, 4),
+                                "traffic": None}}
+
+        out = {
+            "metric": "segment-embeddings/sec", "value": round(value, 2), "unit": "segment-embeddings/sec",
+            "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(ms_step, 3),
+            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "bf16", "data": "synthetic",
+            "config": {"workload": "config #2: 1k synthetic 2-s segments/GPU -> fbank -> ECAPA-TDNN C=1024 -> L2 -> cosine argmax vs 100 profiles",
+                       "segments_per_gpu": B, "profiles": args.profiles, "embed_dim": 192, "frames_per_segment": T_FRAMES,
+                       "weights": "random-init seed 0 (20.77 M params)", "parallelism": f"segments sharded x{world}, profiles replicated"
+                       + (", RCCL all-gather of embeddings per step" if world > 1 else "")},
+            "affinity_pairs_per_sec": aff["pairs_per_sec"] if aff else None,
+            "roofline": roofline, "roofline_forward_hbm_model": fwd_hbm, "affinity": aff,
+            "kernels": kernels, "step_device_ms": round(step_dev_ms, 3),
+            "device": {"name": info["name"], "arch": info["arch"], "cus": info["compute_units"], "clock_mhz": info["clock_khz"] / 1000.0},
+            "peaks_used": {"bf16_mfma_tflops": PEAK_BF16_MFMA / 1e12, "hbm_gbps": PEAK_HBM / 1e9},
+        }
+        if world == 1 and not args.no_cpu_baseline:
+            out["cpu_baseline"] = cpu_baseline(pcm_host, P_host)
+        print(json.dumps(out), flush=True)
+
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+    return 0
+
+
+if __name__ == "__main__":
+    sys.exit(main())

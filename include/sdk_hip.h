@@ -50,6 +50,21 @@ int sdk_shutdown(sdk_ctx* ctx);
 const char* sdk_last_error(void);
 int sdk_get_device_info(sdk_ctx* ctx, sdk_device_info* out);
 
+/* ---- measurement: per-kernel-family HIP-event timing on the launch stream (bench.py roofline) -- */
+enum {
+  SDK_K_CONV_GEMM = 0, SDK_K_SE_GATE, SDK_K_ASP_STATS, SDK_K_ROWS_FC, SDK_K_ASP_POOL, SDK_K_FBANK_TILE,
+  SDK_K_FBANK_NORM, SDK_K_L2NORM, SDK_K_AFF_COARSE, SDK_K_AFF_RESCORE, SDK_K_AFF_RESCAN, SDK_K_COPY,
+  SDK_K_AFF_MATVEC, SDK_K_COUNT
+};
+typedef struct sdk_profile_report {
+  int32_t launches[16];
+  double ms[16];          /* summed device time of the family's launches */
+  double flops[16];       /* executed flops as launched (2*M*N*K for GEMMs) */
+  double bytes[16];       /* compulsory bytes as launched (inputs once + outputs once) */
+} sdk_profile_report;
+int sdk_profile_begin(sdk_ctx* ctx);
+int sdk_profile_end(sdk_ctx* ctx, sdk_profile_report* out);   /* synchronises the device */
+
 /* ---- k1: fbank.  Input contract = audio_profiles.py:25-29 (16 kHz mono s16le). --------
  * pcm   [B, S] int16 (device)          T = 1 + S/160 frames per segment
  * tabs  packed DFT/mel tables from sdk_fbank_tables_bytes()/sdk_fbank_tables_fill(), copied to

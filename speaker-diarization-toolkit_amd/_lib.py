@@ -44,6 +44,13 @@ class EcapaDesc(C.Structure):
                 ("kernel0", C.c_int32), ("dilation", C.c_int32 * 4), ("off", C.c_int64 * 256)]
 
 
+class ProfileReport(C.Structure):
+    _fields_ = [("launches", C.c_int32 * 16), ("ms", C.c_double * 16), ("flops", C.c_double * 16), ("bytes", C.c_double * 16)]
+
+
+KERNEL_FAMILIES = ["conv_gemm", "se_gate", "asp_stats", "rows_fc", "asp_pool", "fbank_tile", "fbank_norm", "l2norm",
+                   "affinity_coarse", "affinity_rescore", "affinity_rescan", "copy", "affinity_matvec"]
+
 GEMM_RELU = 1
 GEMM_TANH = 2
 
@@ -56,6 +63,8 @@ SIGNATURES = {
     "sdk_shutdown": (_i, [_vp]),
     "sdk_last_error": (C.c_char_p, []),
     "sdk_get_device_info": (_i, [_vp, C.POINTER(DeviceInfo)]),
+    "sdk_profile_begin": (_i, [_vp]),
+    "sdk_profile_end": (_i, [_vp, C.POINTER(ProfileReport)]),
     "sdk_fbank_tables_bytes": (_sz, []),
     "sdk_fbank_tables_fill": (_i, [_vp, _sz]),
     "sdk_fbank_workspace_bytes": (_sz, [_i, _i]),

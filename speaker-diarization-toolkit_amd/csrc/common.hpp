@@ -3,6 +3,7 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 #include <stdio.h>
+#include <vector>
 
 #include "../../include/sdk_hip.h"
 
@@ -15,10 +16,32 @@ typedef float f32x16 __attribute__((ext_vector_type(16)));
 typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
 typedef uint32_t u32x2 __attribute__((ext_vector_type(2)));
 
+// Per-launch HIP-event timing, recorded ON THE STREAM THE KERNEL IS LAUNCHED ON, grouped by kernel
+// family.  Off by default (no events are created); bench.py switches it on for its roofline pass.
+struct sdk_prof_rec {
+  int family;
+  hipEvent_t a, b;
+  double flops, bytes;
+};
 struct sdk_ctx {
   int device;
   int num_cu;
   hipDeviceProp_t prop;
+  bool prof_on = false;
+  std::vector<sdk_prof_rec> prof;
+};
+
+struct ProfScope {   // brackets one kernel launch with two events when profiling is enabled
+  sdk_ctx* c; hipStream_t s; size_t slot; bool on;
+  ProfScope(sdk_ctx* ctx, void* stream, int family, double flops, double bytes) : c(ctx), s((hipStream_t)stream), slot(0), on(ctx && ctx->prof_on) {
+    if (!on) return;
+    sdk_prof_rec r{family, nullptr, nullptr, flops, bytes};
+    (void)hipEventCreate(&r.a); (void)hipEventCreate(&r.b);
+    (void)hipEventRecord(r.a, s);
+    slot = c->prof.size();
+    c->prof.push_back(r);
+  }
+  ~ProfScope() { if (on) (void)hipEventRecord(c->prof[slot].b, s); }
 };
 
 void sdk_set_error(const char* fmt, ...) __attribute__((format(printf, 1, 2)));

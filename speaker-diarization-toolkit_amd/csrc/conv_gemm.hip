@@ -224,6 +224,10 @@ extern "C" int sdk_conv_gemm(sdk_ctx* ctx, const sdk_conv_gemm_args* a, void* st
   p.M = a->M; p.N = a->N; p.Cin = a->Cin; p.taps = a->taps; p.dil = a->dil; p.T = a->T; p.flags = a->flags;
 
   const int nwg = (a->N / BN) * ceil_div(a->M, BM);
+  const double kk = (double)a->taps * a->Cin;
+  ProfScope ps(ctx, stream, SDK_K_CONV_GEMM, 2.0 * a->M * a->N * kk,
+               2.0 * a->M * a->Cin + 2.0 * a->N * kk + (a->C ? 2.0 : 0.0) * a->M * a->N + (a->C32 ? 4.0 : 0.0) * a->M * a->N +
+                   (a->S ? 4.0 : 0.0) * a->M * a->N);
   hipLaunchKernelGGL(conv_gemm_kernel, dim3(nwg), dim3(NT), LDS_BYTES, (hipStream_t)stream, p);
   SDK_LAUNCH_CHECK();
   return 0;

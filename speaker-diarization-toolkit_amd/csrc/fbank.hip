@@ -211,9 +211,13 @@ extern "C" int sdk_fbank(sdk_ctx* ctx, const int16_t* pcm, int B, int S, const v
   const int T = 1 + S / HOP;
   const int tps = ceil_div(T, FT);
   SDK_REQUIRE((int64_t)B * tps < (1ll << 31), "sdk_fbank: batch too large for one launch");
+  {
+  ProfScope ps(ctx, stream, SDK_K_FBANK_TILE, 2.0 * B * T * (double)NFFT * 2 * NBIN + 2.0 * B * T * NBIN * NMEL, 2.0 * B * S + 4.0 * B * T * NMEL);
   hipLaunchKernelGGL(fbank_tile_kernel, dim3(B * tps), dim3(NW * 64), 0, (hipStream_t)stream, pcm, S, T, tps,
                      (const FbankTables*)tabs, (float*)ws);
+  }
   SDK_LAUNCH_CHECK();
+  ProfScope ps2(ctx, stream, SDK_K_FBANK_NORM, 3.0 * B * T * NMEL, 4.0 * B * T * NMEL + 2.0 * B * T * ldf);
   hipLaunchKernelGGL(fbank_norm_kernel, dim3(B), dim3(256), 0, (hipStream_t)stream, (const float*)ws, T,
                      (bf16_t*)feats, ldf);
   SDK_LAUNCH_CHECK();

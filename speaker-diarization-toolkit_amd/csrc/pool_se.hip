@@ -276,6 +276,7 @@ extern "C" int sdk_se_gate_residual(sdk_ctx* ctx, const uint16_t* z, int64_t ldz
   const int ngrp = NT / (C / 8);
   const size_t lds = (size_t)(ngrp * C + C + Cse) * sizeof(float);
   SDK_REQUIRE((size_t)(NT / Cse) * Cse <= (size_t)ngrp * C, "sdk_se_gate_residual: scratch too small");
+  ProfScope ps(ctx, stream, SDK_K_SE_GATE, 3.0 * B * T * C, 6.0 * B * T * C);   // z, x read + out written (z re-read from L2)
   hipLaunchKernelGGL(se_gate_residual_kernel, dim3(B), dim3(NT), lds, (hipStream_t)stream, (const bf16_t*)z, ldz,
                      (const bf16_t*)x, ldx, w1t, b1, w2t, b2, (bf16_t*)out, ldo, T, C, Cse);
   SDK_LAUNCH_CHECK();
@@ -286,6 +287,7 @@ extern "C" int sdk_asp_stats(sdk_ctx* ctx, const uint16_t* h, int64_t ldh, int B
                              void* stream) {
   SDK_REQUIRE(ctx && h && out_ctx, "sdk_asp_stats: null argument");
   SDK_REQUIRE(B > 0 && T > 0 && C % 8 == 0 && ldh % 8 == 0, "sdk_asp_stats: bad shape (C=%d ldh=%lld)", C, (long long)ldh);
+  ProfScope ps(ctx, stream, SDK_K_ASP_STATS, 3.0 * B * T * C, 2.0 * B * T * C);
   hipLaunchKernelGGL(asp_stats_kernel, dim3(B, ceil_div(C, 1024)), dim3(NT), 0, (hipStream_t)stream, (const bf16_t*)h,
                      ldh, T, C, out_ctx);
   SDK_LAUNCH_CHECK();
@@ -299,6 +301,7 @@ extern "C" int sdk_rows_fc(sdk_ctx* ctx, const float* in, int64_t ldin, const fl
   SDK_REQUIRE(B > 0 && Cin > 0 && Nout > 0, "sdk_rows_fc: empty problem");
   SDK_REQUIRE((in_scale == nullptr) == (in_shift == nullptr), "sdk_rows_fc: in_scale and in_shift go together");
   SDK_REQUIRE(act >= 0 && act <= 2, "sdk_rows_fc: act=%d", act);
+  ProfScope ps(ctx, stream, SDK_K_ROWS_FC, 2.0 * B * Cin * Nout, 4.0 * ((double)B * Cin + (double)Cin * Nout + (double)B * Nout));
   hipLaunchKernelGGL(rows_fc_kernel, dim3(ceil_div(B, FC_ROWS), ceil_div(Nout, 128)), dim3(NT), 0, (hipStream_t)stream,
                      in, ldin, in_scale, in_shift, wt, bias, out, ldout, B, Cin, Nout, act);
   SDK_LAUNCH_CHECK();
@@ -309,6 +312,7 @@ extern "C" int sdk_asp_pool(sdk_ctx* ctx, const float* logits, int64_t ldl, cons
                             int T, int C, float* pooled, void* stream) {
   SDK_REQUIRE(ctx && logits && h && pooled, "sdk_asp_pool: null argument");
   SDK_REQUIRE(B > 0 && T > 0 && C % 64 == 0, "sdk_asp_pool: C=%d must be a multiple of 64", C);
+  ProfScope ps(ctx, stream, SDK_K_ASP_POOL, 8.0 * B * T * C, 6.0 * B * T * C);
   hipLaunchKernelGGL(asp_pool_kernel, dim3(B, C / 64), dim3(NT), 0, (hipStream_t)stream, logits, ldl,
                      (const bf16_t*)h, ldh, T, C, pooled);
   SDK_LAUNCH_CHECK();
@@ -319,6 +323,7 @@ extern "C" int sdk_l2norm(sdk_ctx* ctx, const float* X, int N, int d, float* E, 
                           void* stream) {
   SDK_REQUIRE(ctx && X, "sdk_l2norm: null argument");
   SDK_REQUIRE(N > 0 && d > 0, "sdk_l2norm: empty problem");
+  ProfScope ps(ctx, stream, SDK_K_L2NORM, 4.0 * N * d, 10.0 * N * d);
   hipLaunchKernelGGL(l2norm_kernel, dim3(ceil_div(N, NT / 64)), dim3(NT), 0, (hipStream_t)stream, X, N, d, E,
                      (bf16_t*)Eb, resid);
   SDK_LAUNCH_CHECK();

@@ -237,6 +237,7 @@ __global__ __launch_bounds__(256) void affinity_rescore_kernel(const float* __re
   for (int c = 0; c < NCAND; ++c) {
     cv[c] = cand_val[(int64_t)rc * NCAND + c];
     ci[c] = cand_idx[(int64_t)rc * NCAND + c];
+    if (ci[c] >= P) ci[c] = -1;   // never trust an index produced from non-finite scores
     if (ci[c] >= 0) best_coarse = fmaxf(best_coarse, cv[c]);
   }
   // the k best coarse values: anything below (k-th best coarse - 2 eps) cannot be in the exact top-k
@@ -266,7 +267,7 @@ __global__ __launch_bounds__(256) void affinity_rescore_kernel(const float* __re
 #pragma unroll
   for (int c = 0; c < NCAND; ++c) {
     // the 8 lanes of a group take the same branch (same row): no divergence inside the shuffles
-    if (ci[c] >= 0 && cv[c] >= cut) {
+    if (ci[c] >= 0 && ci[c] < P && cv[c] >= cut) {
       const float s = dot192_group8(e24, Pm + (int64_t)ci[c] * D, j);
       insert_exact<4>(s, ci[c], bs, bi);
     }
@@ -351,14 +352,23 @@ extern "C" int sdk_affinity_topk(sdk_ctx* ctx, const float* E, const uint16_t* E
   Workspace w;
   ws_layout(N, (char*)ws, &w);
   SDK_HIP_OK(hipMemsetAsync(w.flag_count, 0, sizeof(int32_t), s));
+  {
+  ProfScope ps(ctx, stream, SDK_K_AFF_COARSE, 2.0 * N * (double)Pn * D, 2.0 * ((double)N + Pn) * D + 68.0 * N);
   hipLaunchKernelGGL(affinity_coarse_kernel, dim3(ceil_div(N, SEG_PER_WG)), dim3(WAVES * 64), 0, s, (const bf16_t*)Eb,
                      (const bf16_t*)Pb, N, Pn, w.cand_val, w.cand_idx, w.ubound);
+  }
   SDK_LAUNCH_CHECK();
+  {
+  ProfScope ps(ctx, stream, SDK_K_AFF_RESCORE, 0.0, 4.0 * N * D + 68.0 * N + 8.0 * N * k);
   hipLaunchKernelGGL(affinity_rescore_kernel, dim3(ceil_div(N, 32)), dim3(256), 0, s, E, P, resid_e, resid_p, N, Pn, k,
                      w.cand_val, w.cand_idx, w.ubound, idx, score, w.flag_count, w.flag_rows);
+  }
   SDK_LAUNCH_CHECK();
+  {
+  ProfScope ps(ctx, stream, SDK_K_AFF_RESCAN, 0.0, 0.0);
   hipLaunchKernelGGL(affinity_rescan_kernel, dim3(1024), dim3(256), 0, s, E, P, Pn, k, w.flag_count, w.flag_rows, idx,
                      score);
+  }
   SDK_LAUNCH_CHECK();
   if (n_rescanned) {
     hipLaunchKernelGGL(copy_count_kernel, dim3(1), dim3(1), 0, s, w.flag_count, n_rescanned);

@@ -67,6 +67,35 @@ extern "C" int sdk_get_device_info(sdk_ctx* ctx, sdk_device_info* out) {
   return 0;
 }
 
+extern "C" int sdk_profile_begin(sdk_ctx* ctx) {
+  SDK_REQUIRE(ctx, "sdk_profile_begin: null ctx");
+  for (auto& r : ctx->prof) { (void)hipEventDestroy(r.a); (void)hipEventDestroy(r.b); }
+  ctx->prof.clear();
+  ctx->prof_on = true;
+  return 0;
+}
+
+extern "C" int sdk_profile_end(sdk_ctx* ctx, sdk_profile_report* out) {
+  SDK_REQUIRE(ctx && out, "sdk_profile_end: null argument");
+  ctx->prof_on = false;
+  memset(out, 0, sizeof(*out));
+  SDK_HIP_OK(hipDeviceSynchronize());
+  for (auto& r : ctx->prof) {
+    float ms = 0.f;
+    SDK_HIP_OK(hipEventElapsedTime(&ms, r.a, r.b));
+    if (r.family >= 0 && r.family < 16) {
+      out->launches[r.family] += 1;
+      out->ms[r.family] += ms;
+      out->flops[r.family] += r.flops;
+      out->bytes[r.family] += r.bytes;
+    }
+    (void)hipEventDestroy(r.a);
+    (void)hipEventDestroy(r.b);
+  }
+  ctx->prof.clear();
+  return 0;
+}
+
 // ------------------------------------------------------------------------------ ECAPA forward
 namespace {
 
@@ -133,6 +162,13 @@ extern "C" int sdk_ecapa_forward(sdk_ctx* ctx, const void* wblob, const sdk_ecap
               sdk_ecapa_workspace_bytes(d, B, T));
   SDK_REQUIRE(((uintptr_t)ws % 256) == 0 && ((uintptr_t)wblob % 256) == 0, "sdk_ecapa_forward: ws/wblob must be 256-byte aligned");
 
+  {  // every slot the schedule dereferences must be present in the blob
+    const int tbs = EL_TAIL_BASE(d->n_blocks);
+    for (int i = 1; i <= d->n_blocks; ++i)
+      for (int s = EL_SE_W1T; s <= EL_SE_B2; ++s)
+        SDK_REQUIRE(d->off[EL_BLOCK_BASE(i) + s] >= 0, "sdk_ecapa_forward: SE weight slot %d of block %d missing", s, i);
+    for (int s = EL_ASP_WH; s <= EL_FC_B; ++s) SDK_REQUIRE(d->off[tbs + s] >= 0, "sdk_ecapa_forward: tail weight slot %d missing", s);
+  }
   FwdWs w;
   fwd_layout(d, B, T, (char*)ws, &w);
   const char* wb = (const char*)wblob;
@@ -163,7 +199,10 @@ extern "C" int sdk_ecapa_forward(sdk_ctx* ctx, const void* wblob, const sdk_ecap
     if (int rc = tdnn(xin, ldx, C, 1, 1, base + EL_TDNN1, C, w.U, C, nullptr, 0, nullptr, 0)) return rc;
     // Res2Net: chunk 0 passes through, chunk c>=1 = TDNN(chunk c + y_{c-1}); the running sum is
     // produced by the previous conv's epilogue (S output), ping-ponging between two [M, S] buffers.
-    SDK_HIP_OK(hipMemcpy2DAsync(w.R, (size_t)C * 2, w.U, (size_t)C * 2, (size_t)S * 2, (size_t)M, hipMemcpyDeviceToDevice, st));
+    {
+      ProfScope ps(ctx, stream, SDK_K_COPY, 0.0, 2.0 * M * S * 2);
+      SDK_HIP_OK(hipMemcpy2DAsync(w.R, (size_t)C * 2, w.U, (size_t)C * 2, (size_t)S * 2, (size_t)M, hipMemcpyDeviceToDevice, st));
+    }
     for (int j = 0; j < d->scale - 1; ++j) {
       const uint16_t* Ain = j == 0 ? w.U + S : ((j & 1) ? w.Sa : w.Sb);
       const int64_t lda = j == 0 ? C : S;

@@ -95,6 +95,17 @@ class Engine:
             self.load_weights()
         return self._desc
 
+    # ------------------------------------------------------------------ measurement
+    def profile_begin(self) -> None:
+        check(self.lib.sdk_profile_begin(self.ctx), "sdk_profile_begin")
+
+    def profile_end(self) -> Dict[str, Dict[str, float]]:
+        """Per kernel family: launches, summed device ms (HIP events on the launch stream), flops, bytes."""
+        rep = _lib.ProfileReport()
+        check(self.lib.sdk_profile_end(self.ctx, C.byref(rep)), "sdk_profile_end")
+        return {name: {"launches": rep.launches[i], "ms": rep.ms[i], "flops": rep.flops[i], "bytes": rep.bytes[i]}
+                for i, name in enumerate(_lib.KERNEL_FAMILIES) if rep.launches[i]}
+
     # ------------------------------------------------------------------ k1
     def fbank(self, pcm: torch.Tensor, ldf: int = N_MELS_PADDED) -> torch.Tensor:
         """pcm [B, S] int16 (device) -> feats [B*T, ldf] bf16 (channels >= 80 are zero)."""

@@ -1,0 +1,334 @@
+"""GPU parity tests: every HIP kernel, called through the C ABI, against the CPU oracle on the same
+seeded inputs.  Integer / index results must be identical; floating point within the tolerance
+written next to each assert (bf16 layer-boundary model: DESIGN.md §3)."""
+import numpy as np
+import pytest
+import torch
+
+from conftest import sub
+from oracle import ecapa as oecapa
+from oracle import fbank as ofbank
+from oracle import scoring as oscoring
+
+pytestmark = pytest.mark.gpu
+
+W = sub("weights")
+WP = sub("weights_pack")
+OPS = sub("ops")
+
+BF16_ULP = 2.0 ** -8          # relative spacing of bf16 (8 significand bits)
+
+
+def dev(x, dtype=None):
+    t = torch.as_tensor(x)
+    if dtype is not None:
+        t = t.to(dtype)
+    return t.cuda()
+
+
+def bf16_round(x: torch.Tensor) -> torch.Tensor:
+    return x.to(torch.bfloat16).to(torch.float32)
+
+
+def assert_bf16_close(got: torch.Tensor, want_f32: torch.Tensor, what: str, max_ulps: float = 2.0, frac_exact: float = 0.98):
+    """got: bf16 result of the GPU; want_f32: the oracle's pre-rounding fp32 value.
+    Tolerance: every element within `max_ulps` bf16 ulps of the oracle value (fp32-vs-fp64
+    accumulation can flip the last bf16 bit), and >= frac_exact of the elements bit-identical to
+    the rounded oracle."""
+    g = got.float().cpu()
+    w = bf16_round(want_f32.float().cpu())
+    tol = max_ulps * BF16_ULP * w.abs().clamp_min(1e-30) + 1e-30
+    bad = (g - w).abs() > tol
+    assert not bad.any(), f"{what}: {int(bad.sum())} / {bad.numel()} elements off by more than {max_ulps} bf16 ulps; worst {float((g - w).abs().max())}"
+    same = float((g == w).float().mean())
+    assert same >= frac_exact, f"{what}: only {same:.4f} of elements bit-identical to the rounded oracle"
+
+
+# ------------------------------------------------------------------------------------------------
+# conv_gemm
+def _conv_ref(A, Wt, Cin, taps, dil, T, bias=None, scale=None, shift=None, ubias=None, relu=False, tanh=False):
+    """float64 oracle of sdk_conv_gemm on bf16-valued inputs.  A [M, lda>=Cin], Wt [N, taps*Cin]."""
+    A = A.double()[:, :Cin]
+    M = A.shape[0]
+    B = M // T
+    t = torch.arange(T)
+    out = torch.zeros(M, Wt.shape[0], dtype=torch.float64)
+    Ab = A.reshape(B, T, Cin)
+    for j in range(taps):
+        src = oecapa.reflect_index(t + (j - taps // 2) * dil, T)
+        out += (Ab[:, src, :].reshape(M, Cin)) @ Wt.double()[:, j * Cin:(j + 1) * Cin].T
+    out = out.float()
+    if bias is not None:
+        out = out + bias
+    if ubias is not None:
+        out = out + ubias.repeat_interleave(T, dim=0)
+    if relu:
+        out = torch.relu(out)
+    if scale is not None:
+        out = out * scale + shift
+    if tanh:
+        out = torch.tanh(out)
+    return out
+
+
+def test_conv_gemm_identity_layout(engine):
+    """A = I (exact), asymmetric integer W: catches any row/col swap or k-permutation exactly."""
+    K = N = 128
+    A = torch.eye(K, dtype=torch.float32)
+    Wt = (torch.arange(N * K, dtype=torch.float32).reshape(N, K) % 251) - 125      # W[n][k], asymmetric
+    C, _, _ = engine.conv_gemm(dev(A, torch.bfloat16), dev(Wt, torch.bfloat16), N, K)
+    torch.cuda.synchronize()
+    assert torch.equal(C.float().cpu(), Wt.T.contiguous()), "C[m][n] must equal W[n][m] for A = I"
+
+
+@pytest.mark.parametrize("M,T,N,Cin,taps,dil", [
+    (384, 384, 128, 64, 1, 1), (300, 100, 256, 128, 1, 1), (603, 201, 128, 128, 3, 2), (402, 201, 128, 128, 3, 4),
+    (250, 50, 256, 128, 5, 1), (1005, 201, 384, 192, 3, 3), (130, 130, 128, 3072, 1, 1), (64, 8, 128, 64, 3, 3)])
+def test_conv_gemm_integer_exact(engine, M, T, N, Cin, taps, dil):
+    """Small-integer operands: every product and partial sum is exact in fp32, so the GPU result must
+    equal the oracle bit for bit (tests the reflect row gather, tails and the K loop)."""
+    g = torch.Generator().manual_seed(M * 7 + N)
+    lda = Cin + 64                                         # strided input (slab of a wider tensor)
+    A = torch.randint(-3, 4, (M, lda), generator=g).float()
+    Wt = torch.randint(-2, 3, (N, taps * Cin), generator=g).float()
+    _, C32, _ = engine.conv_gemm(dev(A, torch.bfloat16)[:, :], dev(Wt, torch.bfloat16), N, Cin, taps=taps, dil=dil, T=T,
+                                 out_bf16=False, out_f32=True)
+    want = _conv_ref(A, Wt, Cin, taps, dil, T)
+    torch.cuda.synchronize()
+    assert torch.equal(C32.cpu(), want), f"max diff {float((C32.cpu() - want).abs().max())}"
+
+
+def test_conv_gemm_epilogue(engine):
+    M, T, N, Cin = 402, 201, 256, 128
+    g = torch.Generator().manual_seed(5)
+    A = bf16_round(torch.randn(M, Cin, generator=g))
+    Wt = bf16_round(torch.randn(N, 3 * Cin, generator=g) * 0.05)
+    bias, shift = torch.randn(N, generator=g), torch.randn(N, generator=g) * 0.1
+    scale = torch.rand(N, generator=g) + 0.5
+    ubias = torch.randn(M // T, N, generator=g)
+    X2 = bf16_round(torch.randn(M, N, generator=g))
+    for relu, tanh in [(True, False), (True, True), (False, False)]:
+        C, C32, S = engine.conv_gemm(dev(A, torch.bfloat16), dev(Wt, torch.bfloat16), N, Cin, taps=3, dil=2, T=T, bias=dev(bias),
+                                     scale=dev(scale), shift=dev(shift), ubias=dev(ubias), relu=relu, tanh=tanh, out_f32=True,
+                                     X2=dev(X2, torch.bfloat16))
+        want = _conv_ref(A, Wt, Cin, 3, 2, T, bias, scale, shift, ubias, relu, tanh)
+        torch.cuda.synchronize()
+        # fp32 epilogue vs float64-accumulated oracle: |diff| <= 2e-5 * (1 + |want|)  (K = 384 fp32 accumulation)
+        assert torch.allclose(C32.cpu(), want, rtol=2e-5, atol=2e-5), float((C32.cpu() - want).abs().max())
+        assert_bf16_close(C, want, f"C relu={relu} tanh={tanh}")
+        # S is defined on the ROUNDED C: S = bf16(float(bf16(v)) + X2)
+        assert torch.equal(S.float().cpu(), bf16_round(C.float().cpu() + X2)), "S = bf16(C + X2)"
+
+
+# ------------------------------------------------------------------------------------------------
+# per-utterance kernels
+def test_se_gate_residual(engine):
+    B, T, C, Cse = 5, 201, 1024, 128
+    g = torch.Generator().manual_seed(1)
+    z = bf16_round(torch.randn(B * T, C, generator=g))
+    x = bf16_round(torch.randn(B * T, C, generator=g))
+    w1 = torch.randn(Cse, C, generator=g) / 32
+    w2 = torch.randn(C, Cse, generator=g) / 11
+    b1, b2 = torch.randn(Cse, generator=g) * 0.1, torch.randn(C, generator=g) * 0.1
+    out = engine.se_gate_residual(dev(z, torch.bfloat16), dev(x, torch.bfloat16), dev(w1.T.contiguous()), dev(b1),
+                                  dev(w2.T.contiguous()), dev(b2), B, T)
+    mean = z.double().reshape(B, T, C).mean(1)
+    h = torch.relu(mean @ w1.double().T + b1)
+    gate = torch.sigmoid(h @ w2.double().T + b2).float()
+    want = gate[:, None, :] * z.reshape(B, T, C) + x.reshape(B, T, C)
+    torch.cuda.synchronize()
+    assert_bf16_close(out, want.reshape(B * T, C), "se_gate_residual", frac_exact=0.995)
+
+
+def test_asp_stats_and_pool(engine):
+    B, T, C = 3, 201, 3072
+    g = torch.Generator().manual_seed(2)
+    h = bf16_round(torch.randn(B * T, C, generator=g) * 20 + 5)
+    logits = torch.randn(B * T, C, generator=g) * 3
+    ctx = engine.asp_stats(dev(h, torch.bfloat16), B, T)
+    pooled = engine.asp_pool(dev(logits), dev(h, torch.bfloat16), B, T)
+    hd = h.double().reshape(B, T, C)
+    mu = hd.mean(1)
+    sd = ((hd - mu[:, None]) ** 2).mean(1).clamp_min(1e-12).sqrt()
+    w = torch.softmax(logits.double().reshape(B, T, C), dim=1)
+    wmu = (w * hd).sum(1)
+    wsd = (w * (hd - wmu[:, None]) ** 2).sum(1).clamp_min(1e-12).sqrt()
+    torch.cuda.synchronize()
+    # fp32 single-sweep statistics vs float64: rtol 2e-5 on values of magnitude ~20
+    assert torch.allclose(ctx.cpu().double(), torch.cat([mu, sd], 1), rtol=2e-5, atol=2e-5)
+    assert torch.allclose(pooled.cpu().double(), torch.cat([wmu, wsd], 1), rtol=5e-5, atol=5e-5)
+
+
+def test_rows_fc(engine):
+    g = torch.Generator().manual_seed(3)
+    for B, Cin, Nout, act in [(7, 6144, 192, 0), (5, 6144, 128, 0), (9, 1000, 70, 1), (1, 33, 200, 2)]:
+        x = torch.randn(B, Cin, generator=g)
+        wt = torch.randn(Cin, Nout, generator=g) / Cin ** 0.5
+        bias, isc, ish = torch.randn(Nout, generator=g), torch.rand(Cin, generator=g) + 0.5, torch.randn(Cin, generator=g)
+        out = engine.rows_fc(dev(x), dev(wt), dev(bias), dev(isc), dev(ish), act)
+        want = (x.double() * isc + ish) @ wt.double() + bias
+        want = torch.relu(want) if act == 1 else torch.sigmoid(want) if act == 2 else want
+        torch.cuda.synchronize()
+        assert torch.allclose(out.cpu().double(), want, rtol=1e-5, atol=2e-5), (B, Cin, Nout, float((out.cpu().double() - want).abs().max()))
+
+
+def test_l2norm(engine):
+    g = torch.Generator().manual_seed(4)
+    X = torch.randn(1001, 192, generator=g) * 7
+    X[5] = 0                                                 # zero row: must not produce NaN
+    E, Eb, r = engine.l2norm(dev(X))
+    want = torch.from_numpy(oecapa.l2_normalise(X.numpy()))
+    torch.cuda.synchronize()
+    assert torch.allclose(E.cpu(), want, rtol=0, atol=2e-7)                       # fp32 rounding only
+    assert torch.equal(Eb.float().cpu(), bf16_round(E.cpu()))                       # bf16 copy is RNE of E
+    rr = (E.cpu().double() - Eb.double().cpu()).norm(dim=1)
+    assert torch.allclose(r.cpu().double(), rr, rtol=1e-4, atol=1e-9)
+    assert torch.isfinite(E).all()
+
+
+# ------------------------------------------------------------------------------------------------
+# k1 fbank
+def _pcm(B, S, seed):
+    rng = np.random.default_rng(seed)
+    t = np.arange(S) / 16000.0
+    x = rng.normal(0, 0.1, (B, S))
+    for b in range(B):                                        # two sinusoids per segment so the spectrum is not flat
+        x[b] += 0.2 * np.sin(2 * np.pi * (200 + 37 * b) * t) + 0.1 * np.sin(2 * np.pi * (1800 + 91 * b) * t)
+    return np.clip(np.round(x * 32768), -32768, 32767).astype(np.int16)
+
+
+@pytest.mark.parametrize("B,S", [(3, 32000), (2, 16000), (1, 4805), (2, 800)])
+def test_fbank(engine, B, S):
+    pcm = _pcm(B, S, 11)
+    feats = engine.fbank(torch.from_numpy(pcm).cuda())
+    want = ofbank.fbank(pcm)                                   # [B, T, 80] float32 (float64 internally)
+    T = want.shape[1]
+    torch.cuda.synchronize()
+    got = feats.float().cpu().reshape(B, T, -1)
+    assert torch.count_nonzero(got[:, :, 80:]) == 0, "padding channels must be zero"
+    # fp32 DFT + log vs float64, then bf16 storage: within 2 bf16 ulps (+1e-3 dB absolute for values near 0)
+    w = torch.from_numpy(want)
+    err = (got[:, :, :80] - bf16_round(w)).abs()
+    tol = 2 * BF16_ULP * w.abs() + 2e-3
+    assert (err <= tol).all(), f"fbank: worst {float(err.max())} dB at |x|={float(w.abs().flatten()[err.argmax()])}"
+    assert float((got[:, :, :80] == bf16_round(w)).float().mean()) > 0.97
+
+
+# ------------------------------------------------------------------------------------------------
+# k2 ECAPA-TDNN forward
+SMALL = W.EcapaConfig(channels=256, mfa_channels=768, res2net_scale=2, se_channels=64, attn_channels=128)
+
+
+def _feats(B, T, seed):
+    g = torch.Generator().manual_seed(seed)
+    return (torch.randn(B, T, 80, generator=g) * 3.0)
+
+
+def _run_forward(cfg, weights, feats):
+    eng = OPS.Engine(0, weights=weights, cfg=cfg)
+    B, T, _ = feats.shape
+    f = torch.zeros(B * T, WP.N_MELS_PADDED, dtype=torch.bfloat16)
+    f[:, :80] = feats.reshape(B * T, 80).to(torch.bfloat16)
+    emb = eng.ecapa_forward(f.cuda(), B, T)
+    torch.cuda.synchronize()
+    return emb.cpu()
+
+
+def _cos(a, b):
+    a, b = a.double(), b.double()
+    return (a * b).sum(1) / (a.norm(dim=1) * b.norm(dim=1))
+
+
+@pytest.mark.parametrize("B,T", [(3, 50), (2, 9), (1, 201)])
+def test_ecapa_forward_small_config(B, T):
+    weights = W.synthetic_weights(3, SMALL)
+    feats = _feats(B, T, 21)
+    emb = _run_forward(SMALL, weights, feats)
+    o = oecapa.EcapaOracle(weights, "bf16", torch.float64, n_dilations=SMALL.dilations, scale=SMALL.res2net_scale)
+    want = o.embed(feats)
+    # bf16 layer-boundary model on both sides; the only differences are fp32-vs-fp64 accumulation and the
+    # resulting rare last-bit bf16 flips: cosine >= 1 - 2e-5 and elementwise 2e-3 of the embedding scale.
+    c = _cos(emb, want)
+    assert (c > 1 - 2e-5).all(), c
+    assert torch.allclose(emb, want, rtol=0, atol=2e-3 * float(want.abs().max())), float((emb - want).abs().max())
+
+
+def test_ecapa_forward_full_config(engine):
+    """C = 1024 (the BASELINE.json architecture), 4 two-second segments (T = 201)."""
+    weights = W.synthetic_weights(0)
+    feats = _feats(4, 201, 22)
+    f = torch.zeros(4 * 201, WP.N_MELS_PADDED, dtype=torch.bfloat16)
+    f[:, :80] = feats.reshape(-1, 80).to(torch.bfloat16)
+    emb = engine.ecapa_forward(f.cuda(), 4, 201).cpu()
+    want = oecapa.EcapaOracle(weights, "bf16", torch.float64).embed(feats)
+    c = _cos(emb, want)
+    assert (c > 1 - 2e-5).all(), c
+    assert torch.allclose(emb, want, rtol=0, atol=2e-3 * float(want.abs().max())), float((emb - want).abs().max())
+    # and the bf16 model itself stays close to the unrounded fp32 model (reported, loose bound)
+    ref32 = oecapa.EcapaOracle(weights, "fp32", torch.float64).embed(feats)
+    assert (_cos(emb, ref32) > 0.999).all()
+
+
+# ------------------------------------------------------------------------------------------------
+# k4 affinity + top-k
+def _unit(n, d, seed):
+    x = np.random.default_rng(seed).standard_normal((n, d)).astype(np.float32)
+    return oecapa.l2_normalise(x)
+
+
+def _score_gpu(engine, E, P, k):
+    En, Eb, re = engine.l2norm(dev(E))
+    Pn, Pb, rp = engine.l2norm(dev(P))
+    idx, sc, cnt = engine.affinity_topk(En, Eb, re, Pn, Pb, rp.max().reshape(1), k=k, want_count=True)
+    torch.cuda.synchronize()
+    return idx.cpu().numpy(), sc.cpu().numpy(), int(cnt.item()), En.cpu().numpy(), Pn.cpu().numpy()
+
+
+@pytest.mark.parametrize("N,P,k", [(1000, 100, 1), (5000, 1000, 1), (777, 45, 3), (129, 3, 3), (300, 2500, 4), (1, 1, 1), (4096, 1024, 2)])
+def test_affinity_topk_matches_oracle(engine, N, P, k):
+    E, Pm = _unit(N, 192, N + P), _unit(P, 192, 7 * P + 1)
+    idx, sc, cnt, En, Pn = _score_gpu(engine, E, Pm, k)
+    oidx, osc = oscoring.affinity_topk(En, Pn, k)          # oracle on the SAME normalised rows
+    # scores: fp32 fma chain vs float64 -> 1e-5 absolute (north_star tolerance); typically ~1e-7
+    assert np.abs(sc - osc).max() <= 1e-5, np.abs(sc - osc).max()
+    # integer IDs identical, except where the oracle itself has a near-tie below fp32 resolution
+    full = oscoring.affinity(En, Pn)
+    mism = np.argwhere(idx != oidx)
+    for n, j in mism:
+        assert abs(full[n, idx[n, j]] - full[n, oidx[n, j]]) <= 2e-7, (n, j, idx[n], oidx[n])
+    assert len(mism) <= max(1, N // 1000), f"{len(mism)} index mismatches"
+    assert cnt <= max(4, N // 20), f"{cnt} of {N} rows needed the exact rescan"
+
+
+def test_affinity_exact_ties_and_clusters(engine):
+    """Duplicate profiles (exact ties -> lowest index) and profiles that differ by less than the bf16
+    rounding of the coarse pass (forces the certification / rescan path)."""
+    base = _unit(40, 192, 99)
+    near = base + 1e-4 * _unit(40, 192, 100)               # indistinguishable in bf16
+    Pm = np.concatenate([base, base[:10], near], 0)        # rows 40..49 duplicate rows 0..9
+    E = _unit(500, 192, 101)
+    E[:40] = base + 0.05 * _unit(40, 192, 102)             # segments sitting next to a profile
+    idx, sc, cnt, En, Pn = _score_gpu(engine, E, Pm, 2)
+    full = (En.astype(np.float64) @ Pn.astype(np.float64).T)
+    oidx, osc = oscoring.affinity_topk(En, Pn, 2)
+    assert np.abs(sc - osc).max() <= 1e-5
+    for n in range(E.shape[0]):
+        for j in range(2):
+            if idx[n, j] != oidx[n, j]:
+                assert abs(full[n, idx[n, j]] - full[n, oidx[n, j]]) <= 2e-7, (n, j)
+    # exact duplicates: bitwise equal fp32 scores, so the lower index must come first
+    for n in range(10):
+        assert idx[n, 0] == n and idx[n, 1] in (n + 40, n + 50), (n, idx[n])
+    assert cnt > 0, "the near-duplicate construction must exercise the exact rescan path"
+
+
+def test_affinity_threshold_assignment(engine):
+    """Config #2 shape: 1000 segments x 100 profiles, threshold 0.354 (the ABC default)."""
+    E, Pm = _unit(1000, 192, 0), _unit(100, 192, 1)
+    E[::3] = oecapa.l2_normalise(Pm[np.arange(0, 1000, 3) % 100] + 0.6 * _unit(334, 192, 2))
+    idx, sc, _, En, Pn = _score_gpu(engine, E, Pm, 1)
+    best, osc = oscoring.assign(En, Pn, 0.354)
+    mine = np.where(sc[:, 0] >= np.float32(0.354), idx[:, 0], -1)
+    edge = np.abs(osc - 0.354) < 1e-6                        # a score within fp32 rounding of the threshold may land either side
+    assert np.array_equal(mine[~edge], best[~edge])
+    assert (best >= 0).sum() > 300
