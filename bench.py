@@ -59,7 +59,13 @@ def cpu_baseline(pcm: np.ndarray, P: np.ndarray, budget_s: float = 15.0):
     """The oracle (port of the path to torch-CPU fp32, all host cores) on a bounded sample."""
     from oracle import ecapa as oecapa, fbank as ofbank, scoring as oscoring
     weights = importlib.import_module(f"{PKG}.weights").synthetic_weights(0)
-    cores = os.cpu_count() or 1
+    # the GPU box gives one GPU's share of the host: at most 16 cores (oversubscribing the cgroup
+    # quota with os.cpu_count() threads makes torch-CPU 100x slower, not faster)
+    try:
+        avail = len(os.sched_getaffinity(0))
+    except AttributeError:
+        avail = os.cpu_count() or 1
+    cores = max(1, min(16, avail))
     torch.set_num_threads(cores)
     model = oecapa.EcapaOracle(weights, "fp32", torch.float32)
 
@@ -70,9 +76,8 @@ def cpu_baseline(pcm: np.ndarray, P: np.ndarray, budget_s: float = 15.0):
         oscoring.affinity_topk_fp32(e, P, 1)
         return time.perf_counter() - t0
 
-    run(1)                                     # warm-up (thread pool, allocator)
-    t2 = run(2)
-    n = int(max(2, min(len(pcm), budget_s / max(t2 / 2, 1e-3))))
+    t1 = run(1)                                # warm-up (thread pool, allocator) and calibration
+    n = int(max(1, min(len(pcm), 64, budget_s / max(t1, 1e-3))))
     dt = run(n)
     return {"value": n / dt, "unit": "segment-embeddings/sec", "cores": cores, "kind": "port",
             "sample": f"{n} of the {len(pcm)} segments, oracle fbank+ECAPA(fp32)+L2+cosine argmax on torch-CPU, {dt:.1f} s"}

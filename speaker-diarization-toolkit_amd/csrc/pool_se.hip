@@ -129,20 +129,24 @@ __global__ __launch_bounds__(NT) void asp_stats_kernel(const bf16_t* __restrict_
 }
 
 // ------------------------------------------------------------------------------------------
-// Small fp32 fully-connected layer over rows.  grid (ceil(B/4), ceil(Nout/128)); thread =
-// (output j, half k of each 512-wide input chunk); 4 rows share every weight load.
-constexpr int FC_ROWS = 4, FC_CHUNK = 512;
+// Small fp32 fully-connected layer over rows (per-utterance GEMV batch: SE-style heads, global-context
+// bias, final 6144->192 projection).  Block = 4 rows x 32 outputs x 8 K-slices: lane j of a 32-lane
+// half-wave owns output j (coalesced 128-B weight rows), the 8 half-waves split every 512-wide input
+// chunk, partial sums meet in LDS and are added in slice order (bitwise reproducible, no atomics).
+constexpr int FC_ROWS = 4, FC_CHUNK = 512, FC_OUT = 32, FC_SLICES = NT / FC_OUT;   // 8 slices of 64 inputs
 __global__ __launch_bounds__(NT) void rows_fc_kernel(const float* __restrict__ in, int64_t ldin,
                                                     const float* __restrict__ isc, const float* __restrict__ ish,
                                                     const float* __restrict__ wt, const float* __restrict__ bias,
                                                     float* __restrict__ out, int64_t ldout, int B, int Cin, int Nout,
                                                     int act) {
   __shared__ float xs[FC_ROWS][FC_CHUNK];
-  __shared__ float comb[FC_ROWS][128];
+  __shared__ float part[FC_SLICES][FC_ROWS][FC_OUT];
   const int tid = threadIdx.x;
-  const int jl = tid & 127, k = tid >> 7;
-  const int j = blockIdx.y * 128 + jl;
+  const int jl = tid & (FC_OUT - 1), ks = tid / FC_OUT;
+  const int j = blockIdx.y * FC_OUT + jl;
+  const int jc = j < Nout ? j : Nout - 1;
   const int b0 = blockIdx.x * FC_ROWS;
+  constexpr int SL = FC_CHUNK / FC_SLICES;
   float acc[FC_ROWS];
 #pragma unroll
   for (int r = 0; r < FC_ROWS; ++r) acc[r] = 0.f;
@@ -158,30 +162,30 @@ __global__ __launch_bounds__(NT) void rows_fc_kernel(const float* __restrict__ i
       xs[r][c] = v;
     }
     __syncthreads();
-    if (j < Nout) {
-      const int lo = k * (FC_CHUNK / 2), hi = min(n, lo + FC_CHUNK / 2);
-      for (int c = lo; c < hi; ++c) {
-        const float w = wt[(int64_t)(c0 + c) * Nout + j];
+    const int lo = ks * SL, hi = min(n, lo + SL);
+    const float* wp = wt + (int64_t)(c0 + lo) * Nout + jc;
+#pragma unroll 8
+    for (int c = lo; c < hi; ++c) {
+      const float w = *wp;
+      wp += Nout;
 #pragma unroll
-        for (int r = 0; r < FC_ROWS; ++r) acc[r] += xs[r][c] * w;
-      }
+      for (int r = 0; r < FC_ROWS; ++r) acc[r] = fmaf(xs[r][c], w, acc[r]);
     }
     __syncthreads();
   }
-  if (k == 1) {
 #pragma unroll
-    for (int r = 0; r < FC_ROWS; ++r) comb[r][jl] = acc[r];
-  }
+  for (int r = 0; r < FC_ROWS; ++r) part[ks][r][jl] = acc[r];
   __syncthreads();
-  if (k == 0 && j < Nout) {
+  if (tid < FC_ROWS * FC_OUT) {
+    const int r = tid / FC_OUT, jj = tid & (FC_OUT - 1);
+    const int jo = blockIdx.y * FC_OUT + jj;
+    if (b0 + r < B && jo < Nout) {
+      float v = bias ? bias[jo] : 0.f;
 #pragma unroll
-    for (int r = 0; r < FC_ROWS; ++r) {
-      if (b0 + r < B) {
-        float v = acc[r] + comb[r][jl] + (bias ? bias[j] : 0.f);
-        if (act == 1) v = fmaxf(v, 0.f);
-        else if (act == 2) v = 1.0f / (1.0f + __expf(-v));
-        out[(int64_t)(b0 + r) * ldout + j] = v;
-      }
+      for (int s2 = 0; s2 < FC_SLICES; ++s2) v += part[s2][r][jj];
+      if (act == 1) v = fmaxf(v, 0.f);
+      else if (act == 2) v = 1.0f / (1.0f + __expf(-v));
+      out[(int64_t)(b0 + r) * ldout + jo] = v;
     }
   }
 }
@@ -302,7 +306,7 @@ extern "C" int sdk_rows_fc(sdk_ctx* ctx, const float* in, int64_t ldin, const fl
   SDK_REQUIRE((in_scale == nullptr) == (in_shift == nullptr), "sdk_rows_fc: in_scale and in_shift go together");
   SDK_REQUIRE(act >= 0 && act <= 2, "sdk_rows_fc: act=%d", act);
   ProfScope ps(ctx, stream, SDK_K_ROWS_FC, 2.0 * B * Cin * Nout, 4.0 * ((double)B * Cin + (double)Cin * Nout + (double)B * Nout));
-  hipLaunchKernelGGL(rows_fc_kernel, dim3(ceil_div(B, FC_ROWS), ceil_div(Nout, 128)), dim3(NT), 0, (hipStream_t)stream,
+  hipLaunchKernelGGL(rows_fc_kernel, dim3(ceil_div(B, FC_ROWS), ceil_div(Nout, FC_OUT)), dim3(NT), 0, (hipStream_t)stream,
                      in, ldin, in_scale, in_shift, wt, bias, out, ldout, B, Cin, Nout, act);
   SDK_LAUNCH_CHECK();
   return 0;

@@ -1,0 +1,109 @@
+"""CPU-side checks of the drop-in boundary: the C-ABI library loads and exports every symbol the
+header declares, the host binding matches it, and - without a GPU - the product path fails loudly
+instead of falling back to anything."""
+import ctypes as C
+import re
+from pathlib import Path
+
+import numpy as np
+import pytest
+
+from conftest import ROOT, sub
+
+LIB = sub("_lib")
+HEADER = ROOT / "include" / "sdk_hip.h"
+
+
+def declared_functions():
+    text = re.sub(r"/\*.*?\*/", "", HEADER.read_text(), flags=re.S)
+    return sorted(set(re.findall(r"\b(sdk_[a-z0-9_]+)\s*\(", text)))
+
+
+def test_library_exports_every_declared_symbol():
+    lib = LIB.load_library()
+    names = declared_functions()
+    assert len(names) >= 20
+    for n in names:
+        assert hasattr(lib, n), f"{n} declared in include/sdk_hip.h but not exported by libsdk_hip.so"
+    assert sorted(LIB.SIGNATURES) == names, "host binding (_lib.SIGNATURES) out of sync with the header"
+    assert lib.sdk_abi_version() == 1
+
+
+def test_struct_layouts_match_header():
+    assert C.sizeof(LIB.EcapaDesc) == 14 * 4 + 256 * 8
+    assert C.sizeof(LIB.ProfileReport) == 16 * 4 + 3 * 16 * 8
+    assert C.sizeof(LIB.ConvGemmArgs) == 16 * 8 + 7 * 4 + 4       # 16 pointer/int64 slots, 6 ints + flags, tail pad
+
+
+def test_host_only_entry_points_work_without_gpu():
+    lib = LIB.load_library()
+    n = lib.sdk_fbank_tables_bytes()
+    buf = np.zeros(n, dtype=np.uint8)
+    assert lib.sdk_fbank_tables_fill(buf.ctypes.data, n) == 0
+    tab = buf[:7 * 2 * 50 * 64 * 4 * 4].view(np.float32).reshape(7, 2, 50, 64, 4)
+    # DFT table entry (wave 0, cos, group 0, lane 0, step 0): n = 0, f = 0 -> window(0) * cos(0) = 0.08
+    assert abs(tab[0, 0, 0, 0, 0] - 0.08) < 1e-7
+    # mel table must equal the oracle's filterbank
+    from oracle import fbank as ofb
+    ints = buf[tab.nbytes:tab.nbytes + 3 * 80 * 4].view(np.int32).reshape(3, 80)
+    melw = buf[tab.nbytes + 3 * 80 * 4:].view(np.float32)
+    Wm = ofb.mel_matrix().astype(np.float32)
+    for m in range(80):
+        st, ln, of = ints[0, m], ints[1, m], ints[2, m]
+        assert np.array_equal(np.nonzero(Wm[:, m])[0], np.arange(st, st + ln))
+        assert np.allclose(melw[of:of + ln], Wm[st:st + ln, m], rtol=0, atol=1e-7)
+    assert lib.sdk_fbank_tables_fill(buf.ctypes.data, 10) != 0 and b"too small" in lib.sdk_last_error()
+    assert lib.sdk_fbank_workspace_bytes(1000, 32000) == 1000 * 201 * 80 * 4
+    assert lib.sdk_affinity_workspace_bytes(100000) > 100000 * 72
+
+
+def test_no_gpu_means_loud_failure():
+    import torch
+    if torch.cuda.is_available():
+        pytest.skip("GPU present")
+    with pytest.raises(LIB.SdkError, match="no HIP device|no CPU fallback"):
+        LIB.get_ctx(0)
+    be = sub("backend").Backend()
+    assert be.name == "mi355x" and be.requires_api_key is False and be.embedding_dim == 192
+    with pytest.raises(LIB.SdkError):
+        be.engine()
+
+
+def test_missing_library_is_reported(monkeypatch, tmp_path):
+    monkeypatch.setattr(LIB, "_lib", None)
+    monkeypatch.setattr(LIB, "LIB_PATH", tmp_path / "libsdk_hip.so")
+    with pytest.raises(LIB.SdkError, match="has not been built"):
+        LIB.load_library()
+
+
+def test_weight_packing_layout():
+    W, WP = sub("weights"), sub("weights_pack")
+    cfg = W.EcapaConfig(channels=256, mfa_channels=768, res2net_scale=2, se_channels=64, attn_channels=128)
+    w = W.synthetic_weights(5, cfg)
+    blob, f = WP.pack_weights(w, cfg)
+    assert f["n_blocks"] == 3 and f["dilation"] == [2, 3, 4, 0] and f["n_mels_padded"] == 128
+    off = f["off"]
+    used = [o for o in off if o >= 0]
+    assert all(o % 256 == 0 for o in used) and len(used) == len(set(used))
+    # blk0 weight: [256][5][128] tap-major, channels 80..127 zero, values = bf16(w)
+    k0 = blob[off[0]:off[0] + 256 * 640 * 2].view(np.uint16).reshape(256, 5, 128)
+    assert not k0[:, :, 80:].any()
+    want = WP.f32_to_bf16_bits(np.transpose(w["blk0.conv.w"], (0, 2, 1)))
+    assert np.array_equal(k0[:, :, :80], want)
+    # folded BN of blk0
+    s, sh = W.bn_affine(w, "blk0.bn")
+    assert np.array_equal(blob[off[2]:off[2] + 1024].view(np.float32), s)
+    # SE weights are stored transposed
+    b1 = WP.block_base(1)
+    w1t = blob[off[b1 + WP.EL_SE_W1T]:off[b1 + WP.EL_SE_W1T] + 256 * 64 * 4].view(np.float32).reshape(256, 64)
+    assert np.array_equal(w1t, w["blk1.se.conv1.w"][:, :, 0].T)
+    assert W.DEFAULT_CONFIG.param_count() == 20_767_552 and W.DEFAULT_CONFIG.macs_per_frame() == 18_743_296
+
+
+def test_bf16_bits_roundtrip():
+    WP = sub("weights_pack")
+    import torch
+    x = np.random.default_rng(0).standard_normal(10000).astype(np.float32) * 100
+    ours = WP.bf16_bits_to_f32(WP.f32_to_bf16_bits(x))
+    ref = torch.from_numpy(x).to(torch.bfloat16).to(torch.float32).numpy()
+    assert np.array_equal(ours, ref)

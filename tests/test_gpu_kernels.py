@@ -30,14 +30,17 @@ def bf16_round(x: torch.Tensor) -> torch.Tensor:
     return x.to(torch.bfloat16).to(torch.float32)
 
 
-def assert_bf16_close(got: torch.Tensor, want_f32: torch.Tensor, what: str, max_ulps: float = 2.0, frac_exact: float = 0.98):
+def assert_bf16_close(got: torch.Tensor, want_f32: torch.Tensor, what: str, max_ulps: float = 2.0, frac_exact: float = 0.98,
+                      magnitude: torch.Tensor = None):
     """got: bf16 result of the GPU; want_f32: the oracle's pre-rounding fp32 value.
     Tolerance: every element within `max_ulps` bf16 ulps of the oracle value (fp32-vs-fp64
     accumulation can flip the last bf16 bit), and >= frac_exact of the elements bit-identical to
-    the rounded oracle."""
+    the rounded oracle.  `magnitude` (optional) replaces |oracle| as the ulp scale where the value is a
+    difference of larger terms (the fp32 rounding error follows the terms, not the cancelled result)."""
     g = got.float().cpu()
     w = bf16_round(want_f32.float().cpu())
-    tol = max_ulps * BF16_ULP * w.abs().clamp_min(1e-30) + 1e-30
+    mag = w.abs() if magnitude is None else torch.maximum(w.abs(), magnitude.float().cpu())
+    tol = max_ulps * BF16_ULP * 1.01 * mag.clamp_min(1e-30) + 1e-30      # 1.01: a last-bit flip across a binade edge
     bad = (g - w).abs() > tol
     assert not bad.any(), f"{what}: {int(bad.sum())} / {bad.numel()} elements off by more than {max_ulps} bf16 ulps; worst {float((g - w).abs().max())}"
     same = float((g == w).float().mean())
@@ -115,7 +118,7 @@ def test_conv_gemm_epilogue(engine):
         torch.cuda.synchronize()
         # fp32 epilogue vs float64-accumulated oracle: |diff| <= 2e-5 * (1 + |want|)  (K = 384 fp32 accumulation)
         assert torch.allclose(C32.cpu(), want, rtol=2e-5, atol=2e-5), float((C32.cpu() - want).abs().max())
-        assert_bf16_close(C, want, f"C relu={relu} tanh={tanh}")
+        assert_bf16_close(C, want, f"C relu={relu} tanh={tanh}", magnitude=torch.full_like(want, 2e-2))   # |pre| ~ 1: fp32 error 2e-5 abs
         # S is defined on the ROUNDED C: S = bf16(float(bf16(v)) + X2)
         assert torch.equal(S.float().cpu(), bf16_round(C.float().cpu() + X2)), "S = bf16(C + X2)"
 
@@ -137,7 +140,8 @@ def test_se_gate_residual(engine):
     gate = torch.sigmoid(h @ w2.double().T + b2).float()
     want = gate[:, None, :] * z.reshape(B, T, C) + x.reshape(B, T, C)
     torch.cuda.synchronize()
-    assert_bf16_close(out, want.reshape(B * T, C), "se_gate_residual", frac_exact=0.995)
+    mag = (gate[:, None, :] * z.reshape(B, T, C)).abs() + x.reshape(B, T, C).abs()
+    assert_bf16_close(out, want.reshape(B * T, C), "se_gate_residual", frac_exact=0.995, magnitude=mag.reshape(B * T, C) * 2 ** -9)
 
 
 def test_asp_stats_and_pool(engine):
@@ -297,29 +301,42 @@ def test_affinity_topk_matches_oracle(engine, N, P, k):
     for n, j in mism:
         assert abs(full[n, idx[n, j]] - full[n, oidx[n, j]]) <= 2e-7, (n, j, idx[n], oidx[n])
     assert len(mism) <= max(1, N // 1000), f"{len(mism)} index mismatches"
-    assert cnt <= max(4, N // 20), f"{cnt} of {N} rows needed the exact rescan"
+    # k <= 2: the 4-deep per-half candidate lists certify almost every row; k = 3, 4 sit next to the list
+    # depth, so a large share of rows is (correctly) certified by the exact rescan instead.
+    if k <= 2:
+        assert cnt <= max(4, N // 20), f"{cnt} of {N} rows needed the exact rescan"
 
 
-def test_affinity_exact_ties_and_clusters(engine):
-    """Duplicate profiles (exact ties -> lowest index) and profiles that differ by less than the bf16
-    rounding of the coarse pass (forces the certification / rescan path)."""
+def test_affinity_exact_ties(engine):
+    """Duplicate profiles give bitwise-equal fp32 scores: the lower profile index must rank first."""
     base = _unit(40, 192, 99)
-    near = base + 1e-4 * _unit(40, 192, 100)               # indistinguishable in bf16
-    Pm = np.concatenate([base, base[:10], near], 0)        # rows 40..49 duplicate rows 0..9
+    Pm = np.concatenate([base, base[:10]], 0)              # rows 40..49 duplicate rows 0..9
     E = _unit(500, 192, 101)
-    E[:40] = base + 0.05 * _unit(40, 192, 102)             # segments sitting next to a profile
+    E[:10] = base[:10] + 0.05 * _unit(10, 192, 102)        # segments sitting next to a duplicated profile
     idx, sc, cnt, En, Pn = _score_gpu(engine, E, Pm, 2)
-    full = (En.astype(np.float64) @ Pn.astype(np.float64).T)
     oidx, osc = oscoring.affinity_topk(En, Pn, 2)
     assert np.abs(sc - osc).max() <= 1e-5
-    for n in range(E.shape[0]):
-        for j in range(2):
-            if idx[n, j] != oidx[n, j]:
-                assert abs(full[n, idx[n, j]] - full[n, oidx[n, j]]) <= 2e-7, (n, j)
-    # exact duplicates: bitwise equal fp32 scores, so the lower index must come first
     for n in range(10):
-        assert idx[n, 0] == n and idx[n, 1] in (n + 40, n + 50), (n, idx[n])
-    assert cnt > 0, "the near-duplicate construction must exercise the exact rescan path"
+        assert idx[n, 0] == n and idx[n, 1] == n + 40 and sc[n, 0] == sc[n, 1], (n, idx[n], sc[n])
+    assert np.array_equal(idx, oidx)
+
+
+def test_affinity_near_duplicates_force_rescan(engine):
+    """Profiles that differ by less than the bf16 rounding of the coarse pass: the certification must
+    notice it cannot separate them and take the exact fp32 rescan - results still equal the oracle."""
+    base = _unit(40, 192, 99)
+    near = base + 1e-4 * _unit(40, 192, 100)               # indistinguishable in bf16
+    Pm = np.concatenate([base, near, near + 1e-4 * _unit(40, 192, 103), base + 2e-4 * _unit(40, 192, 104),
+                         base + 3e-4 * _unit(40, 192, 105)], 0)
+    E = _unit(500, 192, 101)
+    E[:40] = base + 0.05 * _unit(40, 192, 102)
+    idx, sc, cnt, En, Pn = _score_gpu(engine, E, Pm, 1)
+    full = (En.astype(np.float64) @ Pn.astype(np.float64).T)
+    oidx, osc = oscoring.affinity_topk(En, Pn, 1)
+    assert np.abs(sc - osc).max() <= 1e-5
+    for n in np.argwhere(idx[:, 0] != oidx[:, 0]).flatten():
+        assert abs(full[n, idx[n, 0]] - full[n, oidx[n, 0]]) <= 2e-7, n      # below fp32 resolution of the score itself
+    assert cnt >= 30, f"only {cnt} rows took the exact rescan; the construction should force ~40"
 
 
 def test_affinity_threshold_assignment(engine):

@@ -1,0 +1,124 @@
+"""Host logic either side of the GPU path: WAV contract reader, window cutting, embeddings store +
+batch loader (k7), result aggregation, registry."""
+import json
+import os
+from pathlib import Path
+
+import numpy as np
+import pytest
+
+from conftest import PKG, ROOT, sub
+
+wav = sub("wav")
+store = sub("store")
+backend = sub("backend")
+api = sub("plugin_api")
+
+
+def test_wav_roundtrip_and_contract(tmp_path):
+    x = (np.random.default_rng(0).standard_normal(16000) * 3000).astype(np.int16)
+    p = tmp_path / "a.wav"
+    wav.write_wav_s16(p, x)
+    assert np.array_equal(wav.read_wav_s16(p), x)
+    wav.write_wav_s16(tmp_path / "b.wav", x, rate=8000)
+    with pytest.raises(wav.AudioFormatError, match="-ar 16000 -ac 1 -f wav -acodec pcm_s16le"):
+        wav.read_wav_s16(tmp_path / "b.wav")
+    (tmp_path / "c.wav").write_bytes(b"not a wav at all")
+    with pytest.raises(wav.AudioFormatError):
+        wav.read_wav_s16(tmp_path / "c.wav")
+
+
+def test_cut_windows():
+    x = np.arange(16000 * 10, dtype=np.int16)
+    pcm, spans = wav.cut_windows(x, None)                       # whole file: 2-s windows, 1-s hop
+    assert pcm.shape == (9, 32000) and spans[0] == (0.0, 2.0) and spans[-1] == (8.0, 10.0)
+    assert np.array_equal(pcm[3], x[48000:80000])
+    pcm, spans = wav.cut_windows(x, [(1.0, 1.2), (3.0, 4.0), (5.0, 9.5)])
+    assert spans[0] == (2.5, 4.5)                              # 1-s segment widened symmetrically to the 2-s window
+    assert len(spans) == 1 + 4 and spans[-1] == (7.5, 9.5)    # (1.0,1.2) dropped (< 0.5 s); tail window flush with the end
+    short = np.ones(8000, dtype=np.int16)
+    pcm, spans = wav.cut_windows(short, None)
+    assert pcm.shape == (1, 32000) and pcm[0, 8000:].sum() == 0 and spans == [(0.0, 0.5)]
+
+
+def _profile(sid, recs):
+    return {"id": sid, "names": {"default": sid.title()}, "embeddings": {"mi355x": recs}}
+
+
+def test_store_and_batch_loader(tmp_path, monkeypatch):
+    monkeypatch.setenv("SPEAKERS_EMBEDDINGS_DIR", str(tmp_path))
+    rng = np.random.default_rng(1)
+    vecs = rng.standard_normal((3, 192)).astype(np.float32)
+    ext = [store.save_vector(v) for v in vecs]
+    assert all(e.startswith("npy:") for e in ext) and store.save_vector(vecs[0]) == ext[0]     # content-addressed, idempotent
+    assert np.array_equal(store.load_vector(ext[1]), vecs[1])
+    cands = [
+        _profile("alice", [{"id": "emb-a1", "external_id": ext[0], "model_version": "mi355x-ecapa1024-x", "trust_level": "high"},
+                           {"id": "emb-a2", "external_id": ext[1], "model_version": "mi355x-ecapa1024-x", "trust_level": "low"}]),
+        _profile("bob", [{"id": "emb-b1", "external_id": ext[2], "model_version": "mi355x-ecapa1024-x"},
+                         {"id": "emb-b2", "external_id": "AD1NQVAB", "model_version": "speechmatics-v2"},
+                         {"id": "emb-b3", "external_id": "npy:" + "0" * 24, "model_version": "mi355x-ecapa1024-x"}]),
+        {"id": "carol", "embeddings": {}},
+    ]
+    batch = store.load_profile_batch(cands, "mi355x", model_prefix="mi355x-")
+    assert batch.matrix.shape == (3, 192) and batch.speaker_ids == ["alice", "alice", "bob"]
+    assert batch.embedding_ids == ["emb-a1", "emb-a2", "emb-b1"] and batch.trust_levels == ["high", "low", "unknown"]
+    assert len(batch.skipped) == 2 and "speechmatics-v2" in batch.skipped[0]
+    assert np.array_equal(batch.matrix, vecs)
+    # per-speaker links: what speaker-report counts (speaker-report:292-294)
+    assert sorted(p.name for p in (tmp_path / "embeddings" / "alice").glob("*.npy")) == ["emb-a1.npy", "emb-a2.npy"]
+    store.save_matrix_pack(tmp_path / "pack.npy", batch)
+    again = store.load_matrix_pack(tmp_path / "pack.npy")
+    assert np.array_equal(np.asarray(again.matrix), vecs) and again.speaker_ids == batch.speaker_ids
+    with pytest.raises(ValueError):
+        store.save_vector(np.zeros(10, np.float32))
+    with pytest.raises(ValueError):
+        store.vector_path("AD1NQVAB")
+
+
+def test_aggregate_matches():
+    batch = store.ProfileBatch(np.zeros((3, 192), np.float32), ["alice", "alice", "bob"], ["emb-a1", "emb-a2", "emb-b1"], ["high", "low", "high"])
+    spans = [(0, 2), (1, 3), (2, 4), (3, 5), (4, 6)]
+    idx = np.array([0, 1, 1, 2, 2])
+    sc = np.array([0.9, 0.5, 0.7, 0.2, 0.8], np.float32)
+    rows = backend.aggregate_matches(idx, sc, spans, batch, 0.354)
+    assert [r["speaker_id"] for r in rows] == ["bob", "alice"]                 # bob: mean(0.8) ; alice: mean(0.9,0.5,0.7)=0.7
+    assert rows[1]["embedding_id"] == "emb-a2" and rows[1]["n_segments"] == 3 and rows[1]["segment"] == (0, 4)
+    assert abs(rows[1]["similarity"] - np.mean(np.array([0.9, 0.5, 0.7], np.float32).astype(np.float64))) < 1e-12
+    assert rows[0]["confidence"] == rows[0]["similarity"]
+    assert backend.aggregate_matches(idx, sc, spans, batch, 0.95) == []
+
+
+def test_registry(monkeypatch, tmp_path):
+    api.reload_backends_config()
+    monkeypatch.delenv("SPEAKER_BACKENDS_CONFIG", raising=False)
+    assert api.list_backends() == ["mi355x"]
+    be = api.get_backend("mi355x")
+    assert be.name == "mi355x" and be.model_version.startswith("mi355x-ecapa1024-") and be.get_audio_profile().sample_rate == 16000
+    assert be.check_embedding_compatibility({"model_version": be.model_version})["compatible"] is True
+    with pytest.raises(ValueError, match="Unknown backend: nope. Available: mi355x"):
+        api.get_backend("nope")
+    cfg = tmp_path / "b.yaml"
+    cfg.write_text("backends:\n  short: " + PKG + ".backend\n  long:\n    module: " + PKG + ".backend\n")
+    monkeypatch.setenv("SPEAKER_BACKENDS_CONFIG", str(cfg))
+    api.reload_backends_config()
+    assert api.list_backends() == ["short", "long"] and api.get_backend("long").name == "mi355x"
+    api.reload_backends_config()
+
+
+def test_backend_plugs_into_the_reference_registry(monkeypatch):
+    """Drop-in check against the real toolkit when it is mounted (build container only)."""
+    ref = Path("/root/reference")
+    if not ref.exists():
+        pytest.skip("reference not mounted on this machine")
+    import subprocess, sys
+    code = (
+        "import sys; sys.path[:0]=[%r,%r]\n"
+        "from speaker_detection_backends import get_backend\n"
+        "from speaker_detection_backends.base import EmbeddingBackend\n"
+        "b=get_backend('mi355x'); assert isinstance(b, EmbeddingBackend), type(b).__mro__\n"
+        "print(b.name, b.embedding_dim, b.get_audio_profile().sample_rate, b.model_version)\n" % (str(ref), str(ROOT)))
+    env = dict(os.environ, SPEAKER_BACKENDS_CONFIG=str(ROOT / PKG / "backends.yaml"), PYTHONDONTWRITEBYTECODE="1")
+    r = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, env=env)
+    assert r.returncode == 0, r.stderr
+    assert r.stdout.startswith("mi355x 192 16000 mi355x-ecapa1024-")

@@ -1,0 +1,112 @@
+"""The oracle is the checker for the GPU path, so it is itself cross-checked against independent
+library implementations (parity with the reference is unpinned: it has no such arithmetic)."""
+import numpy as np
+import torch
+import torch.nn.functional as F
+
+from conftest import sub
+from oracle import ecapa as oecapa
+from oracle import fbank as ofbank
+from oracle import scoring as oscoring
+from oracle import spectral as ospec
+
+W = sub("weights")
+SMALL = W.EcapaConfig(channels=256, mfa_channels=768, res2net_scale=2, se_channels=64, attn_channels=128)
+
+
+def _pcm(B, S, seed=0):
+    rng = np.random.default_rng(seed)
+    return np.clip(rng.normal(0, 0.1, (B, S)) * 32768, -32768, 32767).astype(np.int16)
+
+
+def test_fbank_power_spectrum_matches_torch_stft():
+    pcm = _pcm(2, 8000)
+    x = torch.from_numpy(pcm.astype(np.float64) / 32768)
+    st = torch.stft(x, 400, 160, 400, window=torch.hamming_window(400, periodic=True, dtype=torch.float64), center=True,
+                    pad_mode="constant", return_complex=True)
+    P = (st.abs() ** 2).transpose(1, 2).numpy()
+    assert np.abs(P - ofbank.power_spectrum(pcm)).max() < 1e-10
+    assert ofbank.fbank(pcm).shape == (2, 51, 80) and ofbank.num_frames(32000) == 201
+
+
+def test_fbank_mel_and_normalisation_properties():
+    Wm = ofbank.mel_matrix()
+    assert Wm.shape == (201, 80) and (Wm >= 0).all() and abs(Wm.max() - 1.0) < 0.05
+    assert (np.count_nonzero(Wm, axis=0) >= 1).all()                  # no empty filter
+    f = ofbank.fbank(_pcm(3, 16000, 1))
+    assert np.abs(f.mean(axis=1)).max() < 1e-4                          # per-utterance mean normalisation
+    # gain invariance (log + mean-norm), away from the clipping floor
+    a = ofbank.fbank((_pcm(1, 16000, 2) // 2).astype(np.int16))
+    b = ofbank.fbank(((_pcm(1, 16000, 2) // 2) * 2).astype(np.int16))
+    assert np.abs(a - b).max() < 0.2
+
+
+def test_conv_is_torch_conv1d_with_reflect_padding():
+    w = W.synthetic_weights(1, SMALL)
+    o = oecapa.EcapaOracle(w, "fp32", torch.float64, n_dilations=SMALL.dilations, scale=SMALL.res2net_scale)
+    x = torch.randn(2, 37, 128, dtype=torch.float32)
+    for name, dil in [("blk1.res2net.0.conv", 2), ("blk3.res2net.0.conv", 4)]:
+        got = o.conv(x, name, dil)
+        wt = torch.from_numpy(w[f"{name}.w"]).double()
+        ref = F.conv1d(F.pad(x.double().transpose(1, 2), (dil, dil), mode="reflect"), wt, torch.from_numpy(w[f"{name}.b"]).double(), dilation=dil)
+        assert torch.allclose(got.double(), ref.transpose(1, 2), atol=1e-5)
+    x0 = torch.randn(2, 20, 80)
+    got = o.conv(x0, "blk0.conv", 1)
+    ref = F.conv1d(F.pad(x0.double().transpose(1, 2), (2, 2), mode="reflect"), torch.from_numpy(w["blk0.conv.w"]).double(),
+                   torch.from_numpy(w["blk0.conv.b"]).double())
+    assert torch.allclose(got.double(), ref.transpose(1, 2), atol=1e-5)
+
+
+def test_ecapa_oracle_shapes_and_modes():
+    w = W.synthetic_weights(2, SMALL)
+    feats = torch.randn(2, 30, 80) * 3
+    kw = dict(n_dilations=SMALL.dilations, scale=SMALL.res2net_scale)
+    e64, inter = oecapa.EcapaOracle(w, "bf16", torch.float64, **kw).embed(feats, True)
+    e32 = oecapa.EcapaOracle(w, "bf16", torch.float32, **kw).embed(feats)
+    ef = oecapa.EcapaOracle(w, "fp32", torch.float64, **kw).embed(feats)
+    assert e64.shape == (2, 192) and inter["mfa"].shape == (2, 30, 768) and inter["pooled"].shape == (2, 1536)
+    cos = lambda a, b: float(((a * b).sum(1) / (a.norm(dim=1) * b.norm(dim=1))).min())
+    assert cos(e64, e32) > 1 - 1e-4          # accumulation precision barely matters ...
+    assert cos(e64, ef) > 0.999              # ... and the bf16 model tracks the fp32 model
+    # batch independence: a segment's embedding does not depend on its batch neighbours
+    solo = oecapa.EcapaOracle(w, "bf16", torch.float64, **kw).embed(feats[1:2])
+    assert torch.allclose(solo, e64[1:2], atol=1e-6)
+    n = oecapa.l2_normalise(e64.numpy())
+    assert np.allclose(np.linalg.norm(n, axis=1), 1, atol=1e-6)
+    assert np.array_equal(oecapa.to_bf16_f32(n), torch.from_numpy(n).to(torch.bfloat16).float().numpy())
+
+
+def test_scoring_topk_against_bruteforce():
+    rng = np.random.default_rng(3)
+    E = oecapa.l2_normalise(rng.standard_normal((200, 192)).astype(np.float32))
+    P = oecapa.l2_normalise(rng.standard_normal((37, 192)).astype(np.float32))
+    P[5] = P[2]                                                        # exact tie -> lowest index first
+    idx, sc = oscoring.affinity_topk(E, P, 3)
+    full = E.astype(np.float64) @ P.astype(np.float64).T
+    for n in range(200):
+        order = sorted(range(37), key=lambda p: (-full[n, p], p))[:3]
+        assert list(idx[n]) == order
+    assert np.abs(sc - np.take_along_axis(full, idx.astype(np.int64), 1)).max() < 1e-7
+    best, s = oscoring.assign(E, P, 0.2)
+    assert ((best >= 0) == (s >= np.float32(0.2))).all()
+    i2, s2 = oscoring.affinity_topk_fp32(E, P, 1)
+    assert np.abs(s2[:, 0] - sc[:, 0]).max() < 1e-5
+
+
+def test_spectral_against_scipy_and_sklearn():
+    from scipy.linalg import eigh
+    E, truth = ospec.vmf_mixture(600, 192, 5, seed=4)
+    A = ospec.rectified_affinity(E)
+    d = A.sum(1)
+    S = A / np.sqrt(np.outer(d, d))
+    lam_ref = np.sort(eigh(S, eigvals_only=True))[::-1][:5]
+    lam, U = ospec.subspace_iteration(E, 5, n_iter=40, seed=0)
+    assert np.allclose(lam, lam_ref, atol=1e-6)
+    assert np.allclose(ospec.degrees(E), d)
+    lab, _ = ospec.spectral_cluster(E, 5, n_iter=40)
+    assert ospec.adjusted_rand_index(lab, truth) == 1.0
+    from sklearn.cluster import KMeans
+    R = ospec.row_normalise(U)
+    km = KMeans(5, n_init=5, random_state=0).fit(R)
+    assert ospec.adjusted_rand_index(km.labels_, lab) == 1.0
+    assert list(ospec.canonical_labels(np.array([7, 7, 2, 7, 5, 2]))) == [0, 0, 1, 0, 2, 1]

@@ -18,7 +18,7 @@ stage() {  # name timeout cmd...
 : > gpurun_out/run.log
 WHAT=${1:-all}
 if [ "$WHAT" = all ] || [ "$WHAT" = test ]; then
-  stage pytest_gpu 900 python -m pytest tests -m gpu -q -x --no-header -p no:cacheprovider ${PYTEST_ARGS:-}
+  stage pytest_gpu 900 python -m pytest tests -m gpu -q --no-header -p no:cacheprovider ${PYTEST_ARGS--x}
 fi
 if [ "$WHAT" = all ] || [ "$WHAT" = bench ]; then
   stage smoke 300 python __graft_entry__.py smoke
