@@ -104,6 +104,9 @@ typedef struct sdk_conv_gemm_args {
   uint32_t flags;
 } sdk_conv_gemm_args;
 int sdk_conv_gemm(sdk_ctx* ctx, const sdk_conv_gemm_args* a, void* stream);
+/* Tuning knob (A/B measurements): 1 = 128x128 register-staged tile, 2 = 256x256 LDS-DMA tile where
+ * the shape allows it (default; also settable once via $SDK_GEMM_VARIANT). */
+int sdk_set_gemm_variant(int variant);
 
 /* Squeeze-excitation gate + residual, one workgroup per segment:
  *   mean[c] = (1/T) sum_t z[b,t,c];  h = relu(W1 mean + b1);  g = sigmoid(W2 h + b2)

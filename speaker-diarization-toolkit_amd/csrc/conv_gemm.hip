@@ -12,6 +12,8 @@
 // Software pipeline: global loads of K-step s+1 are in flight (registers) while step s is computed.
 // Epilogue (fp32): +bias +per-segment bias, ReLU, BN affine, tanh; result staged through LDS and
 // written as whole 16-B chunks; optional second output S = bf16(C + X2) (Res2Net chain).
+#include <stdlib.h>
+
 #include "common.hpp"
 
 namespace {
@@ -200,6 +202,234 @@ __global__ __launch_bounds__(NT, 2) void conv_gemm_kernel(Params p) {
 
 }  // namespace
 
+// ================================================================================================
+// v2: 256x256x64 tile, 8 waves (2 M x 4 N, 128x64 per wave), operands staged by LDS-DMA
+// (global_load_lds_dwordx4: no VGPR round trip), two 64-KiB LDS stages, counted vmcnt so the next
+// K-tile stays in flight across the barriers, raw s_barrier (a __syncthreads() would drain the DMA).
+//
+//   LDS image per stage: A [256 rows][64 k] then B [256 rows][64 k], 128-B rows; the DMA writes each
+//   wave-instruction's 1 KiB linearly (8 rows x 128 B), so the XOR swizzle lives on the SOURCE side:
+//   the lane that fills chunk position p of row r fetches global chunk p ^ (r & 7); fragment reads
+//   use position c ^ (r & 7) (same involution both sides).
+//   The conv row gather (segment-local reflect of the tap offset) is just the per-lane global
+//   address of the DMA - the shifted frame tile lands in LDS without ever existing in HBM.
+namespace {
+
+constexpr int BM2 = 256, BN2 = 256, NT2 = 512;
+constexpr int STAGE2 = (BM2 + BN2) * BK * 2;         // 65536
+constexpr int LDS2 = 2 * STAGE2;                     // 131072
+constexpr int CT2_F32 = BN2 + 4;                     // fp32 words per staged accumulator row (260: 2-way = free on ds_write_b32)
+static_assert(64 * CT2_F32 * 4 <= LDS2, "epilogue quarter-tile must fit in the stage memory");
+
+typedef const void __attribute__((address_space(1)))* gptr_t;
+typedef void __attribute__((address_space(3)))* lptr_t;
+
+__global__ __launch_bounds__(NT2, 2) void conv_gemm256_kernel(Params p) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
+  const int wm = wid >> 2, wn = wid & 3;
+
+  const int nbn = p.N / BN2;
+  const int nbm = (p.M + BM2 - 1) / BM2;
+  const int tile = xcd_remap(blockIdx.x, nbn * nbm);
+  const int bn = tile % nbn, bm = tile / nbn;
+  const int m0 = bm * BM2, n0 = bn * BN2;
+
+  // ---- DMA assignment: wave wid fills rows [32 wid, 32 wid + 32) of A and of B, 8 rows per instruction
+  const int rin = lane >> 3, pos = lane & 7;
+  const int gch = (pos ^ rin) * 8;                   // source chunk (elements) for this lane's LDS position
+  int segbase[4], tloc[4];
+  const bf16_t* wrow[4];
+  const int Ktot = p.taps * p.Cin;
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    const int row = 32 * wid + 8 * i + rin;
+    int m = m0 + row;
+    m = m < p.M ? m : p.M - 1;
+    if (p.taps > 1) {
+      const int b = m / p.T;
+      segbase[i] = b * p.T;
+      tloc[i] = m - b * p.T;
+    } else {
+      segbase[i] = m;
+      tloc[i] = 0;
+    }
+    wrow[i] = p.W + (int64_t)(n0 + row) * Ktot + gch;
+  }
+  const int ksteps_per_tap = p.Cin / BK;
+  const int nk = p.taps * ksteps_per_tap;
+  const int half = p.taps >> 1;
+
+  auto issue = [&](int t, int stage) {
+    const int j = t / ksteps_per_tap;
+    const int kc = (t - j * ksteps_per_tap) * BK;
+    const int off = (j - half) * p.dil;
+    char* sA = smem + stage * STAGE2 + (32 * wid) * 128;
+    char* sB = sA + BM2 * BK * 2;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      const int src = p.taps > 1 ? segbase[i] + reflect_idx(tloc[i] + off, p.T) : segbase[i];
+      const bf16_t* ga = p.A + (int64_t)src * p.lda + kc + gch;
+      __builtin_amdgcn_global_load_lds((gptr_t)ga, (lptr_t)(sA + i * 1024), 16, 0, 0);
+    }
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      const bf16_t* gb = wrow[i] + j * p.Cin + kc;
+      __builtin_amdgcn_global_load_lds((gptr_t)gb, (lptr_t)(sB + i * 1024), 16, 0, 0);
+    }
+  };
+
+  f32x4 acc[8][4];
+#pragma unroll
+  for (int mi = 0; mi < 8; ++mi)
+#pragma unroll
+    for (int ni = 0; ni < 4; ++ni) acc[mi][ni] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+  const int fr = lane & 15, fq = lane >> 4, sw = lane & 7;
+  const uint32_t a_base = (wm * 128 + fr) * 128;
+  const uint32_t b_base = BM2 * BK * 2 + (wn * 64 + fr) * 128;
+  const uint32_t c0 = ((0 * 4 + fq) ^ sw) << 4, c1 = ((1 * 4 + fq) ^ sw) << 4;
+
+  // One barrier per K-tile: [own DMA of tile t landed] -> barrier (everyone's landed, and everyone has
+  // finished computing tile t-1, so the other stage is free) -> issue the DMA of tile t+1 -> compute t.
+  // The DMA issue and its flight overlap the ds_read/MFMA stream of the same iteration.
+  const bool dma_early = __builtin_amdgcn_readfirstlane(wid) < 4;
+  issue(0, 0);
+  for (int t = 0; t < nk; ++t) {
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+    // the two waves that share a SIMD issue their DMA at different points of the iteration, so one
+    // of them always has MFMAs to feed the matrix pipe while the other spends issue slots on the DMA
+    if (dma_early && t + 1 < nk) issue(t + 1, (t + 1) & 1);
+    const char* st = smem + (t & 1) * STAGE2;
+    // four sub-phases (ks, mh) of 16 MFMAs; the fragments of sub-phase q+1 are fetched while q computes.
+    // sched_barrier keeps the compiler from hoisting every ds_read to the top (register pressure).
+    bf16x8 b0[4], b1[4], a0[4], a1[4];
+    auto ldB = [&](bf16x8* dst, uint32_t coff) {
+#pragma unroll
+      for (int ni = 0; ni < 4; ++ni) dst[ni] = *reinterpret_cast<const bf16x8*>(st + b_base + ni * 2048 + coff);
+    };
+    auto ldA = [&](bf16x8* dst, int mh, uint32_t coff) {
+#pragma unroll
+      for (int mi = 0; mi < 4; ++mi) dst[mi] = *reinterpret_cast<const bf16x8*>(st + a_base + (mh * 4 + mi) * 2048 + coff);
+    };
+    auto mma = [&](const bf16x8* af, const bf16x8* bf, int mh) {
+      __builtin_amdgcn_s_setprio(1);
+#pragma unroll
+      for (int mi = 0; mi < 4; ++mi)
+#pragma unroll
+        for (int ni = 0; ni < 4; ++ni)
+          acc[mh * 4 + mi][ni] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[mi], bf[ni], acc[mh * 4 + mi][ni], 0, 0, 0);
+      __builtin_amdgcn_s_setprio(0);
+    };
+    ldB(b0, c0);
+    ldA(a0, 0, c0);
+    __builtin_amdgcn_sched_barrier(0);
+    ldA(a1, 1, c0);
+    mma(a0, b0, 0);
+    __builtin_amdgcn_sched_barrier(0);
+    ldB(b1, c1);
+    ldA(a0, 0, c1);
+    mma(a1, b0, 1);
+    __builtin_amdgcn_sched_barrier(0);
+    if (!dma_early && t + 1 < nk) issue(t + 1, (t + 1) & 1);
+    __builtin_amdgcn_sched_barrier(0);
+    ldA(a1, 1, c1);
+    mma(a0, b1, 0);
+    __builtin_amdgcn_sched_barrier(0);
+    mma(a1, b1, 1);
+  }
+  asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+  __builtin_amdgcn_s_barrier();                      // every wave is done reading the last stage
+
+  // ------------------------------------------------------------------ epilogue
+  // Raw fp32 accumulators go to LDS a 64-row quarter at a time (the accumulator registers die at
+  // once: no spills), then all 512 threads sweep the quarter row-major: 8 columns per thread,
+  // epilogue math in fp32, one 16-byte bf16 store (and two 16-byte fp32 stores for C32).
+  float* ct32 = reinterpret_cast<float*>(smem);
+  const bool relu = p.flags & SDK_GEMM_RELU, tnh = p.flags & SDK_GEMM_TANH;
+#pragma unroll
+  for (int q = 0; q < 4; ++q) {
+    if (wm == (q >> 1)) {
+#pragma unroll
+      for (int mq = 0; mq < 4; ++mq) {
+        const int mi = (q & 1) * 4 + mq;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          const int lrow = mq * 16 + fq * 4 + r;
+#pragma unroll
+          for (int ni = 0; ni < 4; ++ni) ct32[lrow * CT2_F32 + wn * 64 + ni * 16 + fr] = acc[mi][ni][r];
+        }
+      }
+    }
+    __syncthreads();
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      const int id = tid + NT2 * i;                          // 64 rows x 32 column chunks of 8
+      const int lrow = id >> 5, cc = id & 31;
+      const int m = m0 + q * 64 + lrow;
+      if (m < p.M) {
+        const int col = n0 + cc * 8;
+        const f32x4 v0 = *reinterpret_cast<const f32x4*>(ct32 + lrow * CT2_F32 + cc * 8);
+        const f32x4 v1 = *reinterpret_cast<const f32x4*>(ct32 + lrow * CT2_F32 + cc * 8 + 4);
+        float v[8] = {v0[0], v0[1], v0[2], v0[3], v1[0], v1[1], v1[2], v1[3]};
+        if (p.bias) {
+          const f32x4 b0 = *reinterpret_cast<const f32x4*>(p.bias + col), b1 = *reinterpret_cast<const f32x4*>(p.bias + col + 4);
+#pragma unroll
+          for (int e = 0; e < 4; ++e) { v[e] += b0[e]; v[4 + e] += b1[e]; }
+        }
+        if (p.ubias) {
+          const float* ub = p.ubias + (int64_t)(m / p.T) * p.ldub + col;
+#pragma unroll
+          for (int e = 0; e < 8; ++e) v[e] += ub[e];
+        }
+        if (relu) {
+#pragma unroll
+          for (int e = 0; e < 8; ++e) v[e] = fmaxf(v[e], 0.f);
+        }
+        if (p.scale) {
+          const f32x4 s0 = *reinterpret_cast<const f32x4*>(p.scale + col), s1 = *reinterpret_cast<const f32x4*>(p.scale + col + 4);
+          const f32x4 t0 = *reinterpret_cast<const f32x4*>(p.shift + col), t1 = *reinterpret_cast<const f32x4*>(p.shift + col + 4);
+#pragma unroll
+          for (int e = 0; e < 4; ++e) { v[e] = v[e] * s0[e] + t0[e]; v[4 + e] = v[4 + e] * s1[e] + t1[e]; }
+        }
+        if (tnh) {
+#pragma unroll
+          for (int e = 0; e < 8; ++e) v[e] = tanhf(v[e]);
+        }
+        if (p.C32) {
+          float* o = p.C32 + (int64_t)m * p.ldc32 + col;
+          *reinterpret_cast<f32x4*>(o) = f32x4{v[0], v[1], v[2], v[3]};
+          *reinterpret_cast<f32x4*>(o + 4) = f32x4{v[4], v[5], v[6], v[7]};
+        }
+        const u32x4 packed = pack8(v);
+        if (p.C) *reinterpret_cast<u32x4*>(p.C + (int64_t)m * p.ldc + col) = packed;
+        if (p.S) {
+          const u32x4 x = *reinterpret_cast<const u32x4*>(p.X2 + (int64_t)m * p.ldx2 + col);
+          float fv[8], fx[8];
+          unpack8(packed, fv);
+          unpack8(x, fx);
+#pragma unroll
+          for (int e = 0; e < 8; ++e) fv[e] += fx[e];
+          *reinterpret_cast<u32x4*>(p.S + (int64_t)m * p.lds + col) = pack8(fv);
+        }
+      }
+    }
+    __syncthreads();
+  }
+}
+
+int g_gemm_variant = -1;   // -1: read SDK_GEMM_VARIANT once; 1 = force the 128^2 kernel, 2 = prefer 256^2
+
+}  // namespace
+
+extern "C" int sdk_set_gemm_variant(int v) {   // tuning knob: 1 = 128^2 register-staged, 2 = 256^2 LDS-DMA (default)
+  if (g_gemm_variant < 0)
+    SDK_HIP_OK(hipFuncSetAttribute((const void*)conv_gemm256_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, LDS2));
+  g_gemm_variant = v;
+  return 0;
+}
+
 extern "C" int sdk_conv_gemm(sdk_ctx* ctx, const sdk_conv_gemm_args* a, void* stream) {
   SDK_REQUIRE(ctx && a, "sdk_conv_gemm: null ctx/args");
   SDK_REQUIRE(a->A && a->W, "sdk_conv_gemm: A and W are required");
@@ -228,7 +458,17 @@ extern "C" int sdk_conv_gemm(sdk_ctx* ctx, const sdk_conv_gemm_args* a, void* st
   ProfScope ps(ctx, stream, SDK_K_CONV_GEMM, 2.0 * a->M * a->N * kk,
                2.0 * a->M * a->Cin + 2.0 * a->N * kk + (a->C ? 2.0 : 0.0) * a->M * a->N + (a->C32 ? 4.0 : 0.0) * a->M * a->N +
                    (a->S ? 4.0 : 0.0) * a->M * a->N);
-  hipLaunchKernelGGL(conv_gemm_kernel, dim3(nwg), dim3(NT), LDS_BYTES, (hipStream_t)stream, p);
+  if (g_gemm_variant < 0) {
+    const char* e = getenv("SDK_GEMM_VARIANT");
+    g_gemm_variant = e ? atoi(e) : 2;
+    SDK_HIP_OK(hipFuncSetAttribute((const void*)conv_gemm256_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, LDS2));
+  }
+  if (g_gemm_variant != 1 && a->N % BN2 == 0 && a->M >= BM2) {
+    const int nwg2 = (a->N / BN2) * ceil_div(a->M, BM2);
+    hipLaunchKernelGGL(conv_gemm256_kernel, dim3(nwg2), dim3(NT2), LDS2, (hipStream_t)stream, p);
+  } else {
+    hipLaunchKernelGGL(conv_gemm_kernel, dim3(nwg), dim3(NT), LDS_BYTES, (hipStream_t)stream, p);
+  }
   SDK_LAUNCH_CHECK();
   return 0;
 }

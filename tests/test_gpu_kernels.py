@@ -86,7 +86,8 @@ def test_conv_gemm_identity_layout(engine):
 
 @pytest.mark.parametrize("M,T,N,Cin,taps,dil", [
     (384, 384, 128, 64, 1, 1), (300, 100, 256, 128, 1, 1), (603, 201, 128, 128, 3, 2), (402, 201, 128, 128, 3, 4),
-    (250, 50, 256, 128, 5, 1), (1005, 201, 384, 192, 3, 3), (130, 130, 128, 3072, 1, 1), (64, 8, 128, 64, 3, 3)])
+    (250, 50, 256, 128, 5, 1), (1005, 201, 384, 192, 3, 3), (130, 130, 128, 3072, 1, 1), (64, 8, 128, 64, 3, 3),
+    (1005, 201, 512, 192, 3, 3), (520, 130, 256, 64, 5, 1), (256, 256, 256, 3072, 1, 1), (2010, 201, 1024, 128, 3, 4), (257, 257, 256, 64, 1, 1)])
 def test_conv_gemm_integer_exact(engine, M, T, N, Cin, taps, dil):
     """Small-integer operands: every product and partial sum is exact in fp32, so the GPU result must
     equal the oracle bit for bit (tests the reflect row gather, tails and the K loop)."""
