@@ -54,7 +54,7 @@ int sdk_get_device_info(sdk_ctx* ctx, sdk_device_info* out);
 enum {
   SDK_K_CONV_GEMM = 0, SDK_K_SE_GATE, SDK_K_ASP_STATS, SDK_K_ROWS_FC, SDK_K_ASP_POOL, SDK_K_FBANK_TILE,
   SDK_K_FBANK_NORM, SDK_K_L2NORM, SDK_K_AFF_COARSE, SDK_K_AFF_RESCORE, SDK_K_AFF_RESCAN, SDK_K_COPY,
-  SDK_K_AFF_MATVEC, SDK_K_COUNT
+  SDK_K_AFF_MATVEC, SDK_K_CONV_GEMM256, SDK_K_ASP_FUSED, SDK_K_COUNT
 };
 typedef struct sdk_profile_report {
   int32_t launches[16];
@@ -128,6 +128,11 @@ int sdk_rows_fc(sdk_ctx* ctx, const float* in, int64_t ldin, const float* in_sca
                 int B, int Cin, int Nout, int act, void* stream);
 int sdk_asp_pool(sdk_ctx* ctx, const float* logits, int64_t ldl, const uint16_t* h, int64_t ldh,
                  int B, int T, int C, float* pooled, void* stream);
+/* Fused form of (attention-logit GEMM + sdk_asp_pool) for T <= sdk_asp_fused_max_frames(): the fp32
+ * logits stay in accumulator registers.  ah [B*T, A=128] bf16 attention hidden, w2 [C, A] bf16, b2 [C]. */
+int sdk_asp_fused_max_frames(void);
+int sdk_asp_fused(sdk_ctx* ctx, const uint16_t* ah, int64_t ldah, const uint16_t* w2, const float* b2,
+                  const uint16_t* h, int64_t ldh, int B, int T, int C, int A, float* pooled, void* stream);
 
 /* Whole forward: feats [B*T, ldf] bf16 -> raw embeddings emb [B, 192] fp32.
  * `wblob` is the packed device weight blob and `wdesc` (HOST) its offset table, both produced by

@@ -35,6 +35,7 @@ struct Params {
   bf16_t* S; int64_t lds;
   int M, N, Cin, taps, dil, T;
   uint32_t flags;
+  int tune;
 };
 
 __global__ __launch_bounds__(NT, 2) void conv_gemm_kernel(Params p) {
@@ -290,54 +291,69 @@ __global__ __launch_bounds__(NT2, 2) void conv_gemm256_kernel(Params p) {
   const uint32_t b_base = BM2 * BK * 2 + (wn * 64 + fr) * 128;
   const uint32_t c0 = ((0 * 4 + fq) ^ sw) << 4, c1 = ((1 * 4 + fq) ^ sw) << 4;
 
-  // One barrier per K-tile: [own DMA of tile t landed] -> barrier (everyone's landed, and everyone has
-  // finished computing tile t-1, so the other stage is free) -> issue the DMA of tile t+1 -> compute t.
-  // The DMA issue and its flight overlap the ds_read/MFMA stream of the same iteration.
-  const bool dma_early = __builtin_amdgcn_readfirstlane(wid) < 4;
+  // Software pipeline, one barrier per K-tile, placed BEFORE the last MFMA sub-phase of the tile:
+  //   P0 P1 P2 | own reads of tile t done, own DMA of tile t+1 landed, barrier |
+  //   issue DMA of tile t+2 into the stage just freed, prefetch tile t+1's first fragments | P3
+  // so the LDS latency of the next tile's first reads and the DMA issue hide under P3's MFMAs, and a
+  // DMA always has a whole iteration to land.  The two waves that share a SIMD issue their DMA at
+  // different points (before / after P3) so one of them always has MFMAs for the matrix pipe.
+  const int pol = p.tune;   // 0: waves 0-3 early / 4-7 late (default), 1: all early, 2: all late, 3: odd/even
+  const int wu = __builtin_amdgcn_readfirstlane(wid);
+  const bool dma_early = pol == 1 ? true : pol == 2 ? false : pol == 3 ? (wu & 1) == 0 : wu < 4;
+  bf16x8 b0[4], b1[4], a0[4], a1[4];
+  auto ldB = [&](const char* st, bf16x8* dst, uint32_t coff) {
+#pragma unroll
+    for (int ni = 0; ni < 4; ++ni) dst[ni] = *reinterpret_cast<const bf16x8*>(st + b_base + ni * 2048 + coff);
+  };
+  auto ldA = [&](const char* st, bf16x8* dst, int mh, uint32_t coff) {
+#pragma unroll
+    for (int mi = 0; mi < 4; ++mi) dst[mi] = *reinterpret_cast<const bf16x8*>(st + a_base + (mh * 4 + mi) * 2048 + coff);
+  };
+  auto mma = [&](const bf16x8* af, const bf16x8* bf, int mh) {
+    __builtin_amdgcn_s_setprio(1);
+#pragma unroll
+    for (int mi = 0; mi < 4; ++mi)
+#pragma unroll
+      for (int ni = 0; ni < 4; ++ni)
+        acc[mh * 4 + mi][ni] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[mi], bf[ni], acc[mh * 4 + mi][ni], 0, 0, 0);
+    __builtin_amdgcn_s_setprio(0);
+  };
+
   issue(0, 0);
-  for (int t = 0; t < nk; ++t) {
+  if (nk > 1) {
+    issue(1, 1);
+    asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+  } else {
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    __builtin_amdgcn_s_barrier();
-    // the two waves that share a SIMD issue their DMA at different points of the iteration, so one
-    // of them always has MFMAs to feed the matrix pipe while the other spends issue slots on the DMA
-    if (dma_early && t + 1 < nk) issue(t + 1, (t + 1) & 1);
+  }
+  __builtin_amdgcn_s_barrier();
+  ldB(smem, b0, c0);
+  ldA(smem, a0, 0, c0);
+  for (int t = 0; t < nk; ++t) {
     const char* st = smem + (t & 1) * STAGE2;
-    // four sub-phases (ks, mh) of 16 MFMAs; the fragments of sub-phase q+1 are fetched while q computes.
-    // sched_barrier keeps the compiler from hoisting every ds_read to the top (register pressure).
-    bf16x8 b0[4], b1[4], a0[4], a1[4];
-    auto ldB = [&](bf16x8* dst, uint32_t coff) {
-#pragma unroll
-      for (int ni = 0; ni < 4; ++ni) dst[ni] = *reinterpret_cast<const bf16x8*>(st + b_base + ni * 2048 + coff);
-    };
-    auto ldA = [&](bf16x8* dst, int mh, uint32_t coff) {
-#pragma unroll
-      for (int mi = 0; mi < 4; ++mi) dst[mi] = *reinterpret_cast<const bf16x8*>(st + a_base + (mh * 4 + mi) * 2048 + coff);
-    };
-    auto mma = [&](const bf16x8* af, const bf16x8* bf, int mh) {
-      __builtin_amdgcn_s_setprio(1);
-#pragma unroll
-      for (int mi = 0; mi < 4; ++mi)
-#pragma unroll
-        for (int ni = 0; ni < 4; ++ni)
-          acc[mh * 4 + mi][ni] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[mi], bf[ni], acc[mh * 4 + mi][ni], 0, 0, 0);
-      __builtin_amdgcn_s_setprio(0);
-    };
-    ldB(b0, c0);
-    ldA(a0, 0, c0);
     __builtin_amdgcn_sched_barrier(0);
-    ldA(a1, 1, c0);
-    mma(a0, b0, 0);
+    ldA(st, a1, 1, c0);
+    mma(a0, b0, 0);                                   // P0
     __builtin_amdgcn_sched_barrier(0);
-    ldB(b1, c1);
-    ldA(a0, 0, c1);
-    mma(a1, b0, 1);
+    ldB(st, b1, c1);
+    ldA(st, a0, 0, c1);
+    mma(a1, b0, 1);                                   // P1
     __builtin_amdgcn_sched_barrier(0);
-    if (!dma_early && t + 1 < nk) issue(t + 1, (t + 1) & 1);
+    ldA(st, a1, 1, c1);
+    mma(a0, b1, 0);                                   // P2
     __builtin_amdgcn_sched_barrier(0);
-    ldA(a1, 1, c1);
-    mma(a0, b1, 0);
+    if (t + 1 < nk) {
+      asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+      __builtin_amdgcn_s_barrier();
+      if (dma_early && t + 2 < nk) issue(t + 2, t & 1);
+      const char* sn = smem + ((t + 1) & 1) * STAGE2;
+      ldB(sn, b0, c0);
+      ldA(sn, a0, 0, c0);
+    }
     __builtin_amdgcn_sched_barrier(0);
-    mma(a1, b1, 1);
+    mma(a1, b1, 1);                                   // P3
+    __builtin_amdgcn_sched_barrier(0);
+    if (!dma_early && t + 2 < nk) issue(t + 2, t & 1);
   }
   asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
   __builtin_amdgcn_s_barrier();                      // every wave is done reading the last stage
@@ -446,28 +462,28 @@ extern "C" int sdk_conv_gemm(sdk_ctx* ctx, const sdk_conv_gemm_args* a, void* st
   if (a->C32) SDK_REQUIRE(a->ldc32 >= a->N, "sdk_conv_gemm: bad ldc32");
   if (a->ubias) SDK_REQUIRE(a->ldub >= a->N, "sdk_conv_gemm: bad ldub");
 
+  if (g_gemm_variant < 0) {
+    const char* e = getenv("SDK_GEMM_VARIANT");
+    g_gemm_variant = e ? atoi(e) : 2;
+    SDK_HIP_OK(hipFuncSetAttribute((const void*)conv_gemm256_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, LDS2));
+  }
   Params p;
   p.A = (const bf16_t*)a->A; p.lda = a->lda; p.W = (const bf16_t*)a->W;
   p.C = (bf16_t*)a->C; p.ldc = a->ldc; p.C32 = a->C32; p.ldc32 = a->ldc32;
   p.bias = a->bias; p.scale = a->scale; p.shift = a->shift; p.ubias = a->ubias; p.ldub = a->ldub;
   p.X2 = (const bf16_t*)a->X2; p.ldx2 = a->ldx2; p.S = (bf16_t*)a->S; p.lds = a->lds;
   p.M = a->M; p.N = a->N; p.Cin = a->Cin; p.taps = a->taps; p.dil = a->dil; p.T = a->T; p.flags = a->flags;
+  p.tune = g_gemm_variant / 16;
 
-  const int nwg = (a->N / BN) * ceil_div(a->M, BM);
   const double kk = (double)a->taps * a->Cin;
-  ProfScope ps(ctx, stream, SDK_K_CONV_GEMM, 2.0 * a->M * a->N * kk,
+  const bool use256 = (g_gemm_variant & 15) != 1 && a->N % BN2 == 0 && a->M >= BM2;
+  ProfScope ps(ctx, stream, use256 ? SDK_K_CONV_GEMM256 : SDK_K_CONV_GEMM, 2.0 * a->M * a->N * kk,
                2.0 * a->M * a->Cin + 2.0 * a->N * kk + (a->C ? 2.0 : 0.0) * a->M * a->N + (a->C32 ? 4.0 : 0.0) * a->M * a->N +
                    (a->S ? 4.0 : 0.0) * a->M * a->N);
-  if (g_gemm_variant < 0) {
-    const char* e = getenv("SDK_GEMM_VARIANT");
-    g_gemm_variant = e ? atoi(e) : 2;
-    SDK_HIP_OK(hipFuncSetAttribute((const void*)conv_gemm256_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, LDS2));
-  }
-  if (g_gemm_variant != 1 && a->N % BN2 == 0 && a->M >= BM2) {
-    const int nwg2 = (a->N / BN2) * ceil_div(a->M, BM2);
-    hipLaunchKernelGGL(conv_gemm256_kernel, dim3(nwg2), dim3(NT2), LDS2, (hipStream_t)stream, p);
+  if (use256) {
+    hipLaunchKernelGGL(conv_gemm256_kernel, dim3((a->N / BN2) * ceil_div(a->M, BM2)), dim3(NT2), LDS2, (hipStream_t)stream, p);
   } else {
-    hipLaunchKernelGGL(conv_gemm_kernel, dim3(nwg), dim3(NT), LDS_BYTES, (hipStream_t)stream, p);
+    hipLaunchKernelGGL(conv_gemm_kernel, dim3((a->N / BN) * ceil_div(a->M, BM)), dim3(NT), LDS_BYTES, (hipStream_t)stream, p);
   }
   SDK_LAUNCH_CHECK();
   return 0;

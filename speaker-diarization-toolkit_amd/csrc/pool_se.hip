@@ -243,6 +243,98 @@ __global__ __launch_bounds__(NT) void asp_pool_kernel(const float* __restrict__ 
 }
 
 // ------------------------------------------------------------------------------------------
+// Fused attentive-statistics pooling: attention logits (MFMA) + softmax over frames + weighted
+// mean/std, one workgroup per (segment, 128-channel block).  The [T, 3072] fp32 logits never exist
+// in HBM.  The GEMM is oriented with FRAMES on the accumulator registers and the CHANNEL on the lane (A = attention hidden [T x 128], B = W2 rows of
+// the wave's 32 channels), so each lane owns one channel and the softmax over frames is a
+// register-local reduction plus one exchange with lane^32.
+//   LDS (57 KiB, one buffer used twice): the segment's attention-hidden tile, 256-B rows with the
+//   16-B chunk index XORed by (row & 15) (conflict-free ds_read_b128 A fragments), then - after the
+//   MFMA phase - the segment's [T x 128] slab of h, read back 2 bytes per lane (64 B per half-wave).
+template <int NTILES>
+__global__ __launch_bounds__(NT, 2) void asp_fused_kernel(const bf16_t* __restrict__ ah, int64_t ldah,
+                                                      const bf16_t* __restrict__ w2, const float* __restrict__ b2,
+                                                      const bf16_t* __restrict__ h, int64_t ldh, int T, int C,
+                                                      float* __restrict__ pooled) {
+  constexpr int ROWS = 32 * NTILES;
+  __shared__ __attribute__((aligned(16))) char lds[ROWS * 256];
+  const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
+  const int col = lane & 31, hh = lane >> 5;
+  const int seg = blockIdx.y;                        // channel block is the fast grid index: the workgroups of one
+  const int64_t base = (int64_t)seg * T;             // segment run back to back and share its hidden tile in L2
+  const int cblk = blockIdx.x * 128;
+  const int ch = cblk + wid * 32 + col;
+
+  // ---- phase A: attention-hidden tile -> LDS (rows >= T are zero)
+  for (int id = tid; id < ROWS * 16; id += NT) {
+    const int r = id >> 4, c = id & 15;
+    u32x4 v = {0u, 0u, 0u, 0u};
+    if (r < T) v = *reinterpret_cast<const u32x4*>(ah + (base + r) * ldah + c * 8);
+    *reinterpret_cast<u32x4*>(lds + r * 256 + ((c ^ (r & 15)) << 4)) = v;
+  }
+  // B operand: W2 rows of this lane's channel, resident for the whole tile
+  bf16x8 bfrag[8];
+#pragma unroll
+  for (int ks = 0; ks < 8; ++ks) bfrag[ks] = *reinterpret_cast<const bf16x8*>(w2 + (int64_t)ch * 128 + ks * 16 + hh * 8);
+  __syncthreads();
+
+  f32x16 acc[NTILES];
+#pragma unroll
+  for (int rt = 0; rt < NTILES; ++rt) {
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc[rt][r] = 0.f;
+    const int row = rt * 32 + col;
+#pragma unroll
+    for (int ks = 0; ks < 8; ++ks) {
+      const bf16x8 a = *reinterpret_cast<const bf16x8*>(lds + row * 256 + (((ks * 2 + hh) ^ (row & 15)) << 4));
+      acc[rt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, bfrag[ks], acc[rt], 0, 0, 0);
+    }
+  }
+  __syncthreads();
+  // ---- phase B: h slab [T x 128 channels] -> the same LDS
+  for (int id = tid; id < T * 16; id += NT) {
+    const int r = id >> 4, c = id & 15;
+    *reinterpret_cast<u32x4*>(lds + r * 256 + c * 16) = *reinterpret_cast<const u32x4*>(h + (base + r) * ldh + cblk + c * 8);
+  }
+  // softmax max while the loads are in flight (registers only; branch-free: rows >= T count as -inf)
+  float mx = -INFINITY;
+#pragma unroll
+  for (int rt = 0; rt < NTILES; ++rt)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      const int t = rt * 32 + (r & 3) + 8 * (r >> 2) + 4 * hh;
+      mx = fmaxf(mx, t < T ? acc[rt][r] : -INFINITY);
+    }
+  mx = fmaxf(mx, __shfl_xor(mx, 32, 64));          // bias is constant over frames: max(v + bias) = max(v) + bias
+  __syncthreads();
+  // ---- phase C: weighted moments about K = h[t = 0] (shifted single pass, fp32).  Rows >= T hold
+  // stale but finite bytes of the hidden tile and get weight 0, so every LDS read is unconditional.
+  const bf16_t* hl = reinterpret_cast<const bf16_t*>(lds) + wid * 32 + col;
+  const float K = bf16_to_f32(hl[0]);
+  float l = 0.f, s1 = 0.f, s2 = 0.f;
+#pragma unroll
+  for (int rt = 0; rt < NTILES; ++rt)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      const int t = rt * 32 + (r & 3) + 8 * (r >> 2) + 4 * hh;
+      const float e = t < T ? __expf(acc[rt][r] - mx) : 0.f;
+      const float d = bf16_to_f32(hl[t * 128]) - K;
+      l += e;
+      s1 = fmaf(e, d, s1);
+      s2 = fmaf(e * d, d, s2);
+      if (r == 15) __builtin_amdgcn_sched_barrier(0);   // one row tile at a time: keeps 16, not 112, reads in flight
+    }
+  l += __shfl_xor(l, 32, 64);
+  s1 += __shfl_xor(s1, 32, 64);
+  s2 += __shfl_xor(s2, 32, 64);
+  if (hh == 0) {
+    const float a = s1 / l;
+    pooled[(int64_t)seg * 2 * C + ch] = K + a;
+    pooled[(int64_t)seg * 2 * C + C + ch] = sqrtf(fmaxf(s2 / l - a * a, 1e-12f));
+  }
+}
+
+// ------------------------------------------------------------------------------------------
 // k3: L2-normalise rows; one wave per row.
 __global__ __launch_bounds__(NT) void l2norm_kernel(const float* __restrict__ X, int N, int d, float* __restrict__ E,
                                                    bf16_t* __restrict__ Eb, float* __restrict__ resid) {
@@ -319,6 +411,22 @@ extern "C" int sdk_asp_pool(sdk_ctx* ctx, const float* logits, int64_t ldl, cons
   ProfScope ps(ctx, stream, SDK_K_ASP_POOL, 8.0 * B * T * C, 6.0 * B * T * C);
   hipLaunchKernelGGL(asp_pool_kernel, dim3(B, C / 64), dim3(NT), 0, (hipStream_t)stream, logits, ldl,
                      (const bf16_t*)h, ldh, T, C, pooled);
+  SDK_LAUNCH_CHECK();
+  return 0;
+}
+
+extern "C" int sdk_asp_fused_max_frames(void) { return 224; }
+
+extern "C" int sdk_asp_fused(sdk_ctx* ctx, const uint16_t* ah, int64_t ldah, const uint16_t* w2, const float* b2,
+                             const uint16_t* h, int64_t ldh, int B, int T, int C, int A, float* pooled, void* stream) {
+  SDK_REQUIRE(ctx && ah && w2 && b2 && h && pooled, "sdk_asp_fused: null argument");
+  SDK_REQUIRE(A == 128, "sdk_asp_fused: attention width %d, this build is specialised for 128", A);
+  SDK_REQUIRE(B > 0 && T > 0 && T <= 224, "sdk_asp_fused: T=%d frames unsupported (1..224); use sdk_conv_gemm + sdk_asp_pool", T);
+  SDK_REQUIRE(C % 128 == 0 && ldah % 8 == 0 && ldh % 8 == 0, "sdk_asp_fused: C=%d must be a multiple of 128", C);
+  ProfScope ps(ctx, stream, SDK_K_ASP_FUSED, 2.0 * B * T * (double)A * C, 2.0 * B * T * ((double)C + A) + 8.0 * B * C);
+  const dim3 grid(C / 128, B);
+  if (T <= 96) hipLaunchKernelGGL(asp_fused_kernel<3>, grid, dim3(NT), 0, (hipStream_t)stream, (const bf16_t*)ah, ldah, (const bf16_t*)w2, b2, (const bf16_t*)h, ldh, T, C, pooled);
+  else hipLaunchKernelGGL(asp_fused_kernel<7>, grid, dim3(NT), 0, (hipStream_t)stream, (const bf16_t*)ah, ldah, (const bf16_t*)w2, b2, (const bf16_t*)h, ldh, T, C, pooled);
   SDK_LAUNCH_CHECK();
   return 0;
 }

@@ -232,12 +232,17 @@ extern "C" int sdk_ecapa_forward(sdk_ctx* ctx, const void* wblob, const sdk_ecap
     g.ubias = w.ubias; g.ldub = A; g.scale = P32(tb + EL_ASP_SCALE); g.shift = P32(tb + EL_ASP_SHIFT);
     g.M = M; g.N = A; g.Cin = Cm; g.taps = 1; g.dil = 1; g.T = T; g.flags = SDK_GEMM_RELU | SDK_GEMM_TANH;
     if (int rc = sdk_conv_gemm(ctx, &g, stream)) return rc;
-    memset(&g, 0, sizeof(g));
-    g.A = w.AH; g.lda = A; g.W = P16(tb + EL_ASP_W2); g.C32 = w.logits; g.ldc32 = Cm; g.bias = P32(tb + EL_ASP_B2);
-    g.M = M; g.N = Cm; g.Cin = A; g.taps = 1; g.dil = 1; g.T = T; g.flags = 0;
-    if (int rc = sdk_conv_gemm(ctx, &g, stream)) return rc;
+    if (A == 128 && T <= sdk_asp_fused_max_frames()) {
+      // logits GEMM + softmax pooling fused: no [M, Cm] fp32 logits round trip through HBM
+      if (int rc = sdk_asp_fused(ctx, w.AH, A, P16(tb + EL_ASP_W2), P32(tb + EL_ASP_B2), w.H, Cm, B, T, Cm, A, w.pooled, stream)) return rc;
+    } else {
+      memset(&g, 0, sizeof(g));
+      g.A = w.AH; g.lda = A; g.W = P16(tb + EL_ASP_W2); g.C32 = w.logits; g.ldc32 = Cm; g.bias = P32(tb + EL_ASP_B2);
+      g.M = M; g.N = Cm; g.Cin = A; g.taps = 1; g.dil = 1; g.T = T; g.flags = 0;
+      if (int rc = sdk_conv_gemm(ctx, &g, stream)) return rc;
+      if (int rc = sdk_asp_pool(ctx, w.logits, Cm, w.H, Cm, B, T, Cm, w.pooled, stream)) return rc;
+    }
   }
-  if (int rc = sdk_asp_pool(ctx, w.logits, Cm, w.H, Cm, B, T, Cm, w.pooled, stream)) return rc;
   return sdk_rows_fc(ctx, w.pooled, 2 * Cm, P32(tb + EL_ASPBN_SCALE), P32(tb + EL_ASPBN_SHIFT), P32(tb + EL_FC_WT),
                      P32(tb + EL_FC_B), emb, d->embed_dim, B, 2 * Cm, d->embed_dim, 0, stream);
 }

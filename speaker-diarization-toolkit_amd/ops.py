@@ -223,6 +223,14 @@ class Engine:
         return out
 
 
+    def asp_fused(self, ah, w2, b2, h, B, T):
+        Cm = h.shape[1]
+        out = torch.empty((B, 2 * Cm), dtype=torch.float32, device=self.device)
+        check(self.lib.sdk_asp_fused(self.ctx, ah.data_ptr(), ah.stride(0), w2.data_ptr(), b2.data_ptr(), h.data_ptr(), h.stride(0),
+                                     B, T, Cm, ah.shape[1], out.data_ptr(), _stream()), "sdk_asp_fused")
+        return out
+
+
 _engines: Dict[int, Engine] = {}
 
 

@@ -164,6 +164,26 @@ def test_asp_stats_and_pool(engine):
     assert torch.allclose(pooled.cpu().double(), torch.cat([wmu, wsd], 1), rtol=5e-5, atol=5e-5)
 
 
+@pytest.mark.parametrize("B,T", [(3, 201), (2, 224), (4, 50), (1, 9), (2, 97)])
+def test_asp_fused_matches_unfused_oracle(engine, B, T):
+    C, A = 3072, 128
+    g = torch.Generator().manual_seed(T)
+    h = bf16_round(torch.randn(B * T, C, generator=g) * 20 + 5)
+    ah = bf16_round(torch.tanh(torch.randn(B * T, A, generator=g)))
+    w2 = bf16_round(torch.randn(C, A, generator=g) * 0.3)
+    b2 = torch.randn(C, generator=g)
+    pooled = engine.asp_fused(dev(ah, torch.bfloat16), dev(w2, torch.bfloat16), dev(b2), dev(h, torch.bfloat16), B, T)
+    logits = (ah.double() @ w2.double().T + b2).reshape(B, T, C)
+    hd = h.double().reshape(B, T, C)
+    w = torch.softmax(logits, dim=1)
+    wmu = (w * hd).sum(1)
+    wsd = (w * (hd - wmu[:, None]) ** 2).sum(1).clamp_min(1e-12).sqrt()
+    torch.cuda.synchronize()
+    # fp32 MFMA accumulation (K = 128) + __expf + shifted fp32 moments vs float64: rtol 1e-4 on values ~ 5..25
+    assert torch.allclose(pooled.cpu().double(), torch.cat([wmu, wsd], 1), rtol=1e-4, atol=1e-4), \
+        float((pooled.cpu().double() - torch.cat([wmu, wsd], 1)).abs().max())
+
+
 def test_rows_fc(engine):
     g = torch.Generator().manual_seed(3)
     for B, Cin, Nout, act in [(7, 6144, 192, 0), (5, 6144, 128, 0), (9, 1000, 70, 1), (1, 33, 200, 2)]:

@@ -6,10 +6,11 @@ import torch
 sys.path.insert(0, str(Path(__file__).resolve().parent.parent))
 ops = importlib.import_module("speaker-diarization-toolkit_amd.ops")
 eng = ops.get_engine(0)
-shapes = [  # (name, M, N, Cin, taps, dil, T)
+shapes_all = [  # (name, M, N, Cin, taps, dil, T)
     ("blk0", 201000, 1024, 128, 5, 1, 201), ("tdnn", 201000, 1024, 1024, 1, 1, 201), ("mfa", 201000, 3072, 3072, 1, 1, 201),
     ("k128", 201000, 1024, 128, 1, 1, 201), ("k4096", 100500, 1024, 4096, 1, 1, 201), ("res2net", 201000, 128, 128, 3, 2, 201),
     ("asp_hidden", 201000, 128, 3072, 1, 1, 201), ("logits", 201000, 3072, 128, 1, 1, 201)]
+shapes = [x for x in shapes_all if x[0] in ("tdnn","mfa","k4096")] if len(sys.argv) > 2 else shapes_all
 variants = [int(v) for v in (sys.argv[1].split(",") if len(sys.argv) > 1 else ["1", "2"])]
 g = torch.Generator(device="cuda").manual_seed(0)
 for name, M, N, Cin, taps, dil, T in shapes:
