@@ -169,6 +169,30 @@ int sdk_affinity_topk(sdk_ctx* ctx, const float* E, const uint16_t* Eb, const fl
                       int N, int Pn, int d, int k, int32_t* idx, float* score,
                       int32_t* n_rescanned, void* ws, size_t ws_bytes, void* stream);
 
+/* ---- k6: spectral clustering pieces on the rectified cosine affinity A = max(E E^T, 0) (BASELINE.json
+ *      config #5).  A is never stored: its tiles are recomputed on the matrix cores per application.
+ *   sdk_affinity_matvec : Y[row0+i, :] = sum_j max(<e_i, e_j>, 0) * xscale[j] * X[j, :]   for i < rows
+ *                         Eb [N,192] bf16 (ALL rows, i.e. the all-gathered embeddings), X [N,kv] fp32,
+ *                         kv <= 32, xscale [N] or NULL, Y [N,kv] fp32 (only the owned rows are written).
+ *                         Degrees are the case X = ones.  ws: sdk_affinity_matvec_workspace_bytes(N).
+ *   sdk_rows_gram       : G [k,k] = X^T Y over n rows (order-fixed two-stage reduction)
+ *   sdk_rows_apply      : Y[i,:] = scale[i] * (X[i,:] @ R),  R [k,k] row-major, scale may be NULL
+ *   sdk_rows_unit       : rows scaled to unit length
+ *   sdk_kmeans_mindist  : d2[i] = (first ? : min(d2[i],)) |R[i] - centre|^2      (maximin initialisation)
+ *   sdk_kmeans_assign   : label[i] = nearest of kc centres (ties -> lowest), dist2, optional per-256-row-block
+ *                         partial sums [nblk, kc, k] and counts [nblk, kc]
+ */
+size_t sdk_affinity_matvec_workspace_bytes(int N);
+int sdk_affinity_matvec(sdk_ctx* ctx, const uint16_t* Eb, int N, int d, int row0, int rows, const float* X,
+                        const float* xscale, int kv, float* Y, void* ws, size_t ws_bytes, void* stream);
+size_t sdk_rows_gram_workspace_bytes(int n, int k);
+int sdk_rows_gram(sdk_ctx* ctx, const float* X, const float* Y, int n, int k, float* G, void* ws, size_t ws_bytes, void* stream);
+int sdk_rows_apply(sdk_ctx* ctx, const float* X, const float* R, const float* scale, int n, int k, float* Y, void* stream);
+int sdk_rows_unit(sdk_ctx* ctx, const float* X, int n, int k, float* Y, void* stream);
+int sdk_kmeans_mindist(sdk_ctx* ctx, const float* R, int n, int k, const float* centre, float* d2, int first, void* stream);
+int sdk_kmeans_assign(sdk_ctx* ctx, const float* R, int n, int k, const float* centres, int kc, int32_t* label,
+                      float* dist2, float* part_sum, int32_t* part_cnt, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -81,6 +81,14 @@ SIGNATURES = {
     "sdk_ecapa_forward": (_i, [_vp, _vp, C.POINTER(EcapaDesc), _vp, _i, _i, _i, _vp, _sz, _vp, _vp]),
     "sdk_l2norm": (_i, [_vp, _vp, _i, _i, _vp, _vp, _vp, _vp]),
     "sdk_affinity_workspace_bytes": (_sz, [_i]),
+    "sdk_affinity_matvec_workspace_bytes": (_sz, [_i]),
+    "sdk_affinity_matvec": (_i, [_vp, _vp, _i, _i, _i, _i, _vp, _vp, _i, _vp, _vp, _sz, _vp]),
+    "sdk_rows_gram_workspace_bytes": (_sz, [_i, _i]),
+    "sdk_rows_gram": (_i, [_vp, _vp, _vp, _i, _i, _vp, _vp, _sz, _vp]),
+    "sdk_rows_apply": (_i, [_vp, _vp, _vp, _vp, _i, _i, _vp, _vp]),
+    "sdk_rows_unit": (_i, [_vp, _vp, _i, _i, _vp, _vp]),
+    "sdk_kmeans_mindist": (_i, [_vp, _vp, _i, _i, _vp, _vp, _i, _vp]),
+    "sdk_kmeans_assign": (_i, [_vp, _vp, _i, _i, _vp, _i, _vp, _vp, _vp, _vp, _vp]),
     "sdk_affinity_topk": (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _vp, _vp, _vp, _vp, _sz, _vp]),
 }
 

@@ -1,0 +1,161 @@
+"""Global segment clustering (BASELINE.json config #5; SURVEY.md §8 k5 + k6): spectral clustering of
+N L2-normalised embeddings on the rectified cosine affinity, row-sharded over the ranks.
+
+    E_all   = all_gather(E_local)                                  the ONE big exchange (RCCL over xGMI)
+    deg     = A 1 ; S = D^-1/2 A D^-1/2                            A = max(E E^T, 0), recomputed per use
+    V       = orth(seeded gaussian [N, k])                         CholeskyQR (Gram all-reduce, k x k)
+    repeat  : V <- orth(S V)                                       subspace iteration; per step one
+                                                                   all-gather of V [N, k] (6.4 MB at 100k x 16)
+    Ritz    : H = V^T S V, eigh (k x k, host), U = V Q
+    k-means : rows of U normalised; maximin init; Lloyd with centroid all-reduce
+    labels  : canonical (order of first appearance over the global row order)
+
+Every O(N^2) and O(N k^2) operation runs in libsdk_hip.so (ops.Engine); the k x k algebra (Cholesky,
+eigh of a 16 x 16 matrix) is done on the host in float64.  The algorithm is restated for the CPU in
+oracle/spectral.py; free choices (rectification, init, iteration counts) are identical.
+
+`provider` is the object that executes the row-block primitives: an ops.Engine on a GPU.  The
+distributed control flow itself is device-agnostic, so tests/test_dist_gloo.py drives it on CPU
+ranks with an oracle-backed provider.
+"""
+from __future__ import annotations
+
+from dataclasses import dataclass
+from typing import Optional, Tuple
+
+import numpy as np
+import torch
+
+from . import dist as sdist
+
+
+@dataclass
+class SpectralResult:
+    labels: np.ndarray            # [N] int32 canonical, identical on every rank
+    eigenvalues: np.ndarray       # [k] descending (of S = D^-1/2 A D^-1/2)
+    n_iter: int
+
+
+class _Comm:
+    def __init__(self, group=None):
+        import torch.distributed as d
+        self.on = d.is_available() and d.is_initialized() and d.get_world_size(group) > 1
+        self.group = group
+        self.rank = d.get_rank(group) if self.on else 0
+        self.world = d.get_world_size(group) if self.on else 1
+
+    def gather_rows(self, local: torch.Tensor, n_total: int) -> torch.Tensor:
+        return sdist.all_gather_rows(local, n_total, self.group) if self.on else local
+
+    def sum_(self, x: torch.Tensor) -> torch.Tensor:
+        return sdist.all_reduce_sum(x, self.group) if self.on else x
+
+    def argmax_row(self, value: float, row: int, dev) -> int:
+        """Global row index of the largest value (ties -> lowest row)."""
+        if not self.on:
+            return row
+        import torch.distributed as d
+        t = torch.tensor([value, float(row)], dtype=torch.float64, device=dev)
+        out = torch.zeros((self.world * 2,), dtype=torch.float64, device=dev)
+        d.all_gather_into_tensor(out, t, group=self.group)
+        pairs = out.reshape(self.world, 2).cpu().tolist()
+        return int(max(pairs, key=lambda p: (p[0], -p[1]))[1])
+
+
+def canonical_labels(lab: np.ndarray) -> np.ndarray:
+    lab = np.asarray(lab)
+    _, first = np.unique(lab, return_index=True)
+    remap = np.full(int(lab.max()) + 1, -1, dtype=np.int32)
+    for new, old in enumerate(lab[np.sort(first)]):
+        remap[int(old)] = new
+    return remap[lab]
+
+
+def spectral_cluster(provider, E_local: torch.Tensor, Eb_local: torch.Tensor, n_total: int, k: int, n_iter: int = 30,
+                     n_kmeans: int = 20, seed: int = 0, group=None) -> SpectralResult:
+    """E_local / Eb_local: this rank's unit-norm embedding rows (fp32 / bf16) under
+    dist.shard_bounds(n_total, world).  Returns identical results on every rank."""
+    comm = _Comm(group)
+    lo, hi = sdist.shard_bounds(n_total, comm.world)[comm.rank]
+    n_loc = hi - lo
+    dev = Eb_local.device
+    assert Eb_local.shape[0] == n_loc, (Eb_local.shape, lo, hi)
+
+    Eb_all = comm.gather_rows(Eb_local.contiguous(), n_total)                      # k5: the embedding all-gather
+    ones = torch.ones((n_total, 1), dtype=torch.float32, device=dev)
+    deg = provider.affinity_matvec(Eb_all, ones, lo, n_loc)[lo:hi, 0].contiguous()
+    dinv_loc = torch.rsqrt(deg)
+    dinv_all = comm.gather_rows(dinv_loc.reshape(-1, 1), n_total).reshape(-1).contiguous()
+
+    # seeded start, same gaussian as the oracle (numpy PCG64), orthonormalised across ranks
+    G0 = np.random.default_rng(seed).standard_normal((n_total, k))
+    V = torch.from_numpy(G0[lo:hi].astype(np.float32)).to(dev)
+    V = _orth(provider, comm, V, k)
+
+    eye = torch.eye(k, dtype=torch.float32, device=dev)
+
+    def apply_S(Vloc: torch.Tensor) -> torch.Tensor:
+        Vall = comm.gather_rows(Vloc, n_total)
+        Y = provider.affinity_matvec(Eb_all, Vall, lo, n_loc, xscale=dinv_all)[lo:hi].contiguous()
+        return provider.rows_apply(Y, eye, scale=dinv_loc)
+
+    for _ in range(n_iter):
+        V = _orth(provider, comm, apply_S(V), k)
+    SV = apply_S(V)
+    H = comm.sum_(provider.rows_gram(V, SV)).double().cpu().numpy()
+    H = 0.5 * (H + H.T)
+    lam, Q = np.linalg.eigh(H)
+    order = np.argsort(-lam)
+    Qd = torch.from_numpy(np.ascontiguousarray(Q[:, order]).astype(np.float32)).to(dev)
+    U = provider.rows_apply(V, Qd)
+    R = provider.rows_unit(U)
+
+    labels_loc = _kmeans(provider, comm, R, lo, n_total, k, n_kmeans)
+    lab_all = comm.gather_rows(labels_loc.reshape(-1, 1), n_total).reshape(-1)
+    return SpectralResult(canonical_labels(lab_all.cpu().numpy()), lam[order], n_iter)
+
+
+def _orth(provider, comm: _Comm, Y: torch.Tensor, k: int) -> torch.Tensor:
+    """CholeskyQR2: Q = Y R^-1 with R^T R = sum_ranks Y^T Y; applied twice for fp32 stability."""
+    for _ in range(2):
+        G = comm.sum_(provider.rows_gram(Y, Y)).double().cpu().numpy()
+        G = 0.5 * (G + G.T)
+        L = np.linalg.cholesky(G + 1e-30 * np.eye(k))
+        Rinv = np.linalg.inv(L.T)                                                  # Y R^-1, R = L^T
+        Y = provider.rows_apply(Y, torch.from_numpy(np.ascontiguousarray(Rinv).astype(np.float32)).to(Y.device))
+    return Y
+
+
+def _kmeans(provider, comm: _Comm, R: torch.Tensor, lo: int, n_total: int, k: int, n_iter: int) -> torch.Tensor:
+    dev = R.device
+    n_loc = R.shape[0]
+
+    def fetch_row(global_row: int) -> torch.Tensor:
+        """The row with this global index, on every rank (owner contributes it, others zeros; summed)."""
+        v = torch.zeros((R.shape[1],), dtype=torch.float32, device=dev)
+        if lo <= global_row < lo + n_loc:
+            v = R[global_row - lo].clone()
+        return comm.sum_(v)
+
+    centres = [fetch_row(0)]
+    d2 = torch.empty((max(n_loc, 1),), dtype=torch.float32, device=dev)[:n_loc]
+    for j in range(1, k):
+        if n_loc:
+            provider.kmeans_mindist(R, centres[-1], d2, first=(j == 1))
+            val, arg = torch.max(d2, dim=0)
+            cand = (float(val.item()), lo + int(arg.item()))
+        else:
+            cand = (-1.0, n_total)
+        centres.append(fetch_row(comm.argmax_row(cand[0], cand[1], dev)))
+    C = torch.stack(centres).contiguous()
+    labels = torch.zeros((n_loc,), dtype=torch.int32, device=dev)
+    for _ in range(n_iter):
+        labels, _, ps, pc = provider.kmeans_assign(R, C, want_sums=True)
+        sums = comm.sum_(ps.double().sum(dim=0))
+        cnts = comm.sum_(pc.sum(dim=0).double())
+        newC = torch.where(cnts[:, None] > 0, sums / cnts.clamp_min(1.0)[:, None], C.double()).float()
+        if torch.equal(newC, C):
+            break
+        C = newC.contiguous()
+    labels, _, _, _ = provider.kmeans_assign(R, C, want_sums=False)
+    return labels

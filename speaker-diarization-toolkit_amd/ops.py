@@ -223,6 +223,55 @@ class Engine:
         return out
 
 
+    # ------------------------------------------------------------------ k6 (spectral clustering pieces)
+    def affinity_matvec(self, Eb, X, row0: int = 0, rows: Optional[int] = None, xscale=None, out=None):
+        """Y[row0:row0+rows] = max(E E^T, 0)[row0:row0+rows, :] @ (xscale[:, None] * X);  X [N, kv] fp32."""
+        _need(Eb, torch.bfloat16, "Eb"); _need(X, torch.float32, "X")
+        N, d = Eb.shape
+        kv = X.shape[1]
+        rows = N - row0 if rows is None else rows
+        Y = out if out is not None else torch.zeros((N, kv), dtype=torch.float32, device=self.device)
+        ws = self._scratch_bytes("matvec", self.lib.sdk_affinity_matvec_workspace_bytes(N))
+        check(self.lib.sdk_affinity_matvec(self.ctx, Eb.data_ptr(), N, d, row0, rows, X.contiguous().data_ptr(), _ptr(xscale), kv,
+                                           Y.data_ptr(), ws.data_ptr(), ws.numel(), _stream()), "sdk_affinity_matvec")
+        return Y
+
+    def rows_gram(self, X, Y):
+        n, k = X.shape
+        G = torch.empty((k, k), dtype=torch.float32, device=self.device)
+        ws = self._scratch_bytes("gram", self.lib.sdk_rows_gram_workspace_bytes(n, k))
+        check(self.lib.sdk_rows_gram(self.ctx, X.data_ptr(), Y.data_ptr(), n, k, G.data_ptr(), ws.data_ptr(), ws.numel(), _stream()), "sdk_rows_gram")
+        return G
+
+    def rows_apply(self, X, R, scale=None):
+        n, k = X.shape
+        Y = torch.empty_like(X)
+        check(self.lib.sdk_rows_apply(self.ctx, X.data_ptr(), R.contiguous().data_ptr(), _ptr(scale), n, k, Y.data_ptr(), _stream()), "sdk_rows_apply")
+        return Y
+
+    def rows_unit(self, X):
+        n, k = X.shape
+        Y = torch.empty_like(X)
+        check(self.lib.sdk_rows_unit(self.ctx, X.data_ptr(), n, k, Y.data_ptr(), _stream()), "sdk_rows_unit")
+        return Y
+
+    def kmeans_mindist(self, R, centre, d2, first: bool):
+        n, k = R.shape
+        check(self.lib.sdk_kmeans_mindist(self.ctx, R.data_ptr(), n, k, centre.contiguous().data_ptr(), d2.data_ptr(), int(first), _stream()), "sdk_kmeans_mindist")
+        return d2
+
+    def kmeans_assign(self, R, centres, want_sums: bool = True):
+        n, k = R.shape
+        kc = centres.shape[0]
+        lab = torch.empty((n,), dtype=torch.int32, device=self.device)
+        d2 = torch.empty((n,), dtype=torch.float32, device=self.device)
+        nb = (n + 255) // 256
+        ps = torch.empty((nb, kc, k), dtype=torch.float32, device=self.device) if want_sums else None
+        pc = torch.empty((nb, kc), dtype=torch.int32, device=self.device) if want_sums else None
+        check(self.lib.sdk_kmeans_assign(self.ctx, R.data_ptr(), n, k, centres.contiguous().data_ptr(), kc, lab.data_ptr(), d2.data_ptr(),
+                                         _ptr(ps), _ptr(pc), _stream()), "sdk_kmeans_assign")
+        return lab, d2, ps, pc
+
     def asp_fused(self, ah, w2, b2, h, B, T):
         Cm = h.shape[1]
         out = torch.empty((B, 2 * Cm), dtype=torch.float32, device=self.device)

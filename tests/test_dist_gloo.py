@@ -57,3 +57,47 @@ def test_all_gather_rows_world2_gloo(tmp_path):
         d.mkdir()
         mp.spawn(_worker, args=(world, _free_port(), n_total, str(d)), nprocs=world, join=True)
         assert sorted(os.listdir(d)) == ["rank0.ok", "rank1.ok"]
+
+
+def _cluster_worker(rank, world, port, out_dir):
+    import importlib
+    import sys
+    sys.path.insert(0, str(ROOT))
+    sys.path.insert(0, str(ROOT / "tests"))
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from cpu_provider import CpuProvider
+    from oracle import spectral as ospec
+    D = importlib.import_module(f"{PKG}.dist")
+    CL = importlib.import_module(f"{PKG}.cluster")
+    N, k = 601, 4                                         # odd N: ragged shards
+    E, truth = ospec.vmf_mixture(N, 192, k, seed=11, noise=0.5)
+    Eb = torch.from_numpy(E).to(torch.bfloat16)
+    lo, hi = D.shard_range(N)
+    res = CL.spectral_cluster(CpuProvider(), torch.from_numpy(E[lo:hi]), Eb[lo:hi].clone(), N, k, n_iter=20, n_kmeans=15, seed=0)
+    olab, olam = ospec.spectral_cluster(Eb.float().numpy(), k, n_iter=20, n_kmeans=15, seed=0)
+    ok = np.array_equal(res.labels, olab) and np.abs(res.eigenvalues - olam).max() < 1e-5 and ospec.adjusted_rand_index(res.labels, truth) == 1.0
+    open(os.path.join(out_dir, f"rank{rank}.ok" if ok else f"rank{rank}.bad"), "w").close()
+    dist.destroy_process_group()
+
+
+def test_spectral_cluster_world2_gloo(tmp_path):
+    """Row-sharded spectral clustering (embedding all-gather, per-iteration V all-gather, Gram and centroid
+    all-reduces) on two CPU ranks: every rank must reproduce the single-process oracle's integer labels."""
+    mp.spawn(_cluster_worker, args=(2, _free_port(), str(tmp_path)), nprocs=2, join=True)
+    assert sorted(os.listdir(tmp_path)) == ["rank0.ok", "rank1.ok"]
+
+
+def test_spectral_cluster_single_process_cpu_provider():
+    import importlib
+    import sys
+    sys.path.insert(0, str(ROOT / "tests"))
+    from cpu_provider import CpuProvider
+    from oracle import spectral as ospec
+    CL = importlib.import_module(f"{PKG}.cluster")
+    E, truth = ospec.vmf_mixture(500, 192, 5, seed=3, noise=0.5)
+    Eb = torch.from_numpy(E).to(torch.bfloat16)
+    res = CL.spectral_cluster(CpuProvider(), torch.from_numpy(E), Eb, 500, 5, n_iter=20, n_kmeans=15)
+    olab, olam = ospec.spectral_cluster(Eb.float().numpy(), 5, n_iter=20, n_kmeans=15)
+    assert np.array_equal(res.labels, olab) and np.abs(res.eigenvalues - olam).max() < 1e-5
+    assert ospec.adjusted_rand_index(res.labels, truth) == 1.0

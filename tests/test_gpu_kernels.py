@@ -370,3 +370,69 @@ def test_affinity_threshold_assignment(engine):
     edge = np.abs(osc - 0.354) < 1e-6                        # a score within fp32 rounding of the threshold may land either side
     assert np.array_equal(mine[~edge], best[~edge])
     assert (best >= 0).sum() > 300
+
+
+# ------------------------------------------------------------------------------------------------
+# k6 spectral clustering pieces
+from oracle import spectral as ospec  # noqa: E402
+
+CL = sub("cluster")
+
+
+@pytest.mark.parametrize("N,kv,row0,rows", [(1000, 16, 0, 1000), (777, 5, 100, 300), (4096, 32, 0, 4096), (130, 1, 0, 130)])
+def test_affinity_matvec(engine, N, kv, row0, rows):
+    E = _unit(N, 192, N)
+    _, Eb, _ = engine.l2norm(dev(E))
+    Ef = Eb.float().cpu().numpy().astype(np.float64)            # the kernel sees the bf16 rows
+    rng = np.random.default_rng(kv)
+    X = rng.standard_normal((N, kv)).astype(np.float32)
+    xs = rng.uniform(0.5, 1.5, N).astype(np.float32)
+    Y = engine.affinity_matvec(Eb, dev(X), row0, rows, xscale=dev(xs))
+    torch.cuda.synchronize()
+    A = np.maximum(Ef[row0:row0 + rows] @ Ef.T, 0.0)
+    want = A @ (X.astype(np.float64) * xs[:, None])
+    got = Y.cpu().numpy()[row0:row0 + rows]
+    # S is rounded to bf16 inside the kernel (2^-9 relative per term, random sign) and X is split hi+lo:
+    # error ~ 2^-9 * |A| |X| / sqrt(N_eff); tolerance 1.5e-3 of the row's absolute sum
+    scale = (A @ np.abs(X.astype(np.float64) * xs[:, None])) + 1e-6
+    assert (np.abs(got - want) <= 1.5e-3 * scale).all(), float((np.abs(got - want) / scale).max())
+    if rows < N:
+        assert not Y.cpu().numpy()[:row0].any() and not Y.cpu().numpy()[row0 + rows:].any(), "rows outside the block must stay untouched"
+
+
+def test_thin_helpers(engine):
+    rng = np.random.default_rng(0)
+    X = rng.standard_normal((1000, 16)).astype(np.float32)
+    Yv = rng.standard_normal((1000, 16)).astype(np.float32)
+    G = engine.rows_gram(dev(X), dev(Yv)).cpu().numpy()
+    assert np.allclose(G, X.astype(np.float64).T @ Yv.astype(np.float64), rtol=1e-5, atol=1e-4)
+    R = rng.standard_normal((16, 16)).astype(np.float32)
+    sc = rng.uniform(0.5, 2, 1000).astype(np.float32)
+    Z = engine.rows_apply(dev(X), dev(R), dev(sc)).cpu().numpy()
+    assert np.allclose(Z, (X.astype(np.float64) @ R) * sc[:, None], rtol=1e-5, atol=1e-5)
+    U = engine.rows_unit(dev(X)).cpu().numpy()
+    assert np.allclose(np.linalg.norm(U, axis=1), 1, atol=1e-6)
+    C = X[:5].copy()
+    lab, d2, ps, pc = engine.kmeans_assign(dev(X), dev(C))
+    dist = ((X[:, None, :].astype(np.float64) - C[None]) ** 2).sum(-1)
+    assert np.array_equal(lab.cpu().numpy(), dist.argmin(1))
+    assert np.allclose(d2.cpu().numpy(), dist.min(1), rtol=1e-5, atol=1e-6)
+    sums = ps.cpu().numpy().astype(np.float64).sum(0)
+    for q in range(5):
+        assert np.allclose(sums[q], X[dist.argmin(1) == q].astype(np.float64).sum(0), rtol=1e-5, atol=1e-4)
+    assert np.array_equal(pc.cpu().numpy().sum(0), np.bincount(dist.argmin(1), minlength=5))
+
+
+@pytest.mark.parametrize("N,k", [(2000, 6), (5000, 16)])
+def test_spectral_cluster_matches_oracle(engine, N, k):
+    """Config #5 scaled down: mixture-of-clusters embeddings, GPU pipeline vs the CPU oracle run on the
+    same bf16-rounded rows.  Integer labels must be identical (canonical order of first appearance)."""
+    E, truth = ospec.vmf_mixture(N, 192, k, seed=N + k, noise=0.6)
+    En, Eb, _ = engine.l2norm(dev(E))
+    res = CL.spectral_cluster(engine, En, Eb, N, k, n_iter=25, n_kmeans=20, seed=0)
+    Ef = Eb.float().cpu().numpy()
+    olab, olam = ospec.spectral_cluster(Ef, k, n_iter=25, n_kmeans=20, seed=0)
+    assert np.array_equal(res.labels, olab), f"ARI vs oracle {ospec.adjusted_rand_index(res.labels, olab)}"
+    assert ospec.adjusted_rand_index(res.labels, truth) == 1.0
+    # eigenvalues of S: bf16 tile rounding inside A V -> 2e-3 absolute (values in [0, 1])
+    assert np.abs(res.eigenvalues - olam).max() < 2e-3, (res.eigenvalues, olam)
