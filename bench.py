@@ -159,20 +159,27 @@ def main() -> int:
         eng.profile_begin()
         step()
         prof = eng.profile_end()
-        conv = prof["conv_gemm"]
-        conv_alg_flops = 2.0 * MAC_PER_FRAME * T_FRAMES * B          # SURVEY §8(d) per-frame MACs x frames x segments
-        achieved = conv_alg_flops / (conv["ms"] * 1e-3)
+        # dominant kernel: conv_gemm256_kernel (blk0, the six 1024x1024 TDNN layers, the 3072x3072 MFA layer)
+        big = prof["conv_gemm256"]
+        MAC_BIG = 80 * 5 * 1024 + 6 * 1024 * 1024 + 3072 * 3072        # SURVEY Appendix B rows served by this kernel
+        big_alg_flops = 2.0 * MAC_BIG * T_FRAMES * B
+        achieved = big_alg_flops / (big["ms"] * 1e-3)
         kernels = {k: {"launches": v["launches"], "ms": round(v["ms"], 4),
                        "tflops": round(v["flops"] / (v["ms"] * 1e-3) / 1e12, 2) if v["flops"] else None,
                        "gbps": round(v["bytes"] / (v["ms"] * 1e-3) / 1e9, 1) if v["bytes"] else None}
                    for k, v in prof.items()}
         step_dev_ms = sum(v["ms"] for v in prof.values())
-        roofline = {"kernel": "conv_gemm_kernel", "bound": "mfma", "achieved": round(achieved / 1e12, 2), "peak": PEAK_BF16_MFMA / 1e12,
+        roofline = {"kernel": "conv_gemm256_kernel", "bound": "mfma", "achieved": round(achieved / 1e12, 2), "peak": PEAK_BF16_MFMA / 1e12,
                     "unit": "TFLOP/s", "frac": round(achieved / PEAK_BF16_MFMA, 4), "traffic": None,
-                    "launches_per_step": conv["launches"], "avg_launch_ms": round(conv["ms"] / conv["launches"], 4),
-                    "algorithmic_flops_per_step": conv_alg_flops, "executed_tflops": round(conv["flops"] / (conv["ms"] * 1e-3) / 1e12, 2)}
+                    "launches_per_step": big["launches"], "avg_launch_ms": round(big["ms"] / big["launches"], 4),
+                    "algorithmic_flops_per_step": big_alg_flops, "share_of_step_device_time": round(big["ms"] / step_dev_ms, 3),
+                    "executed_tflops": round(big["flops"] / (big["ms"] * 1e-3) / 1e12, 2)}
+        fwd_keys = ("conv_gemm256", "conv_gemm", "se_gate", "asp_stats", "rows_fc", "asp_pool", "asp_fused", "copy")
+        fwd_ms = sum(prof[k]["ms"] for k in fwd_keys if k in prof)
+        fwd_mfma = {"bound": "mfma", "achieved": round(FLOP_PER_SEGMENT * B / (fwd_ms * 1e-3) / 1e12, 2), "peak": PEAK_BF16_MFMA / 1e12,
+                    "unit": "TFLOP/s", "frac": round(FLOP_PER_SEGMENT * B / (fwd_ms * 1e-3) / PEAK_BF16_MFMA, 4),
+                    "model": "SURVEY.md 8(d) 7.539 GFLOP/segment / whole ECAPA forward device time (all kernels)"}
         # north_star's second view of the forward: layer-boundary HBM model (19.07 MB / segment, bf16)
-        fwd_ms = sum(prof[k]["ms"] for k in ("conv_gemm", "se_gate", "asp_stats", "rows_fc", "asp_pool", "copy") if k in prof)
         fwd_hbm = {"bound": "hbm", "achieved": round(BYTES_PER_SEGMENT_BF16 * B / (fwd_ms * 1e-3) / 1e9, 1), "peak": PEAK_HBM / 1e9,
                    "unit": "GB/s", "frac": round(BYTES_PER_SEGMENT_BF16 * B / (fwd_ms * 1e-3) / PEAK_HBM, 4),
                    "model": "SURVEY.md 8(d) layer-boundary bytes (19.07 MB/segment) / forward device time"}
@@ -201,6 +208,23 @@ def main() -> int:
                                 "peak": PEAK_BF16_MFMA / 1e12, "unit": "TFLOP/s", "frac": round(fl / (coarse_ms * 1e-3) / PEAK_BF16_MFMA, 4),
                                 "traffic": None}}
 
+        # ---- config #5 kernel: rectified-affinity mat-vec A X (A = max(E E^T, 0) recomputed on MFMA), 100k x 100k
+        clus = None
+        if not args.no_affinity_config3:
+            N5, k5 = 100_000, 16
+            E5, E5b, _ = eng.l2norm(torch.randn(N5, 192, device=dev, generator=torch.Generator(device=dev).manual_seed(5)))
+            X5 = torch.randn(N5, k5, device=dev, generator=torch.Generator(device=dev).manual_seed(6))
+            eng.affinity_matvec(E5b, X5)
+            eng.profile_begin()
+            for _ in range(3):
+                eng.affinity_matvec(E5b, X5)
+            p5 = eng.profile_end()["affinity_matvec"]
+            ms5 = p5["ms"] / 3
+            clus = {"workload": "config #5 tile kernel: 100k x 100k segment-segment affinity recomputed + A.X (k=16), one GPU",
+                    "pairs_per_sec": round(N5 * N5 / (ms5 * 1e-3), 1), "ms": round(ms5, 3),
+                    "roofline": {"kernel": "affinity_matvec_kernel", "bound": "mfma", "achieved": round(2.0 * N5 * N5 * (192 + k5) / (ms5 * 1e-3) / 1e12, 2),
+                                 "peak": PEAK_BF16_MFMA / 1e12, "unit": "TFLOP/s", "frac": round(2.0 * N5 * N5 * (192 + k5) / (ms5 * 1e-3) / PEAK_BF16_MFMA, 4), "traffic": None}}
+
         out = {
             "metric": "segment-embeddings/sec", "value": round(value, 2), "unit": "segment-embeddings/sec",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(ms_step, 3),
@@ -210,7 +234,8 @@ def main() -> int:
                        "weights": "random-init seed 0 (20.77 M params)", "parallelism": f"segments sharded x{world}, profiles replicated"
                        + (", RCCL all-gather of embeddings per step" if world > 1 else "")},
             "affinity_pairs_per_sec": aff["pairs_per_sec"] if aff else None,
-            "roofline": roofline, "roofline_forward_hbm_model": fwd_hbm, "affinity": aff,
+            "roofline": roofline, "roofline_forward_mfma": fwd_mfma, "roofline_forward_hbm_model": fwd_hbm, "affinity": aff,
+            "affinity_cluster": clus,
             "kernels": kernels, "step_device_ms": round(step_dev_ms, 3),
             "device": {"name": info["name"], "arch": info["arch"], "cus": info["compute_units"], "clock_mhz": info["clock_khz"] / 1000.0},
             "peaks_used": {"bf16_mfma_tflops": PEAK_BF16_MFMA / 1e12, "hbm_gbps": PEAK_HBM / 1e9},

@@ -156,14 +156,15 @@ int sdk_l2norm(sdk_ctx* ctx, const float* X, int N, int d, float* E, uint16_t* E
 /* ---- k4: segments x profiles cosine affinity with fused top-k (replaces the scoring a local
  *      identify_speaker performs per candidate: base.py:130-151; rows consumed by
  *      speaker_detection:1085-1127).
- *   coarse pass : bf16 MFMA  Eb [N,d] x Pb [P,d]^T, fused per-row top-4 (no N x P matrix in HBM)
+ *   coarse pass : bf16 MFMA  Eb [N,d] x Pb [P,d]^T, fused per-row candidate lists (no N x P matrix in HBM)
  *   exact pass  : fp32 re-score of the candidates, sorted, ties -> lowest profile index
- *   guarantee   : rows whose 4th coarse candidate is within the rounding margin of the best are
- *                 re-scanned exactly in fp32 over all P, so idx/score equal an fp32 full scan.
+ *   guarantee   : rows whose last coarse candidate is within the rounding margin of the k-th exact score
+ *                 are re-scanned exactly in fp32 over all P, so idx/score equal an fp32 full scan
+ *                 (k = 1 is the fast path: ~1 % of rows rescanned; larger k rescans more).
  * d must be 192 (= 12 MFMA k-steps), k <= 4.  idx [N,k] int32, score [N,k] fp32.
  * n_rescanned (device int32, may be NULL) receives the number of rows that took the exact path.
- * ws: sdk_affinity_workspace_bytes(N). */
-size_t sdk_affinity_workspace_bytes(int N);
+ * ws: sdk_affinity_workspace_bytes(N, P). */
+size_t sdk_affinity_workspace_bytes(int N, int P);
 int sdk_affinity_topk(sdk_ctx* ctx, const float* E, const uint16_t* Eb, const float* resid_e,
                       const float* P, const uint16_t* Pb, const float* resid_p,
                       int N, int Pn, int d, int k, int32_t* idx, float* score,

@@ -80,7 +80,7 @@ SIGNATURES = {
     "sdk_ecapa_workspace_bytes": (_sz, [C.POINTER(EcapaDesc), _i, _i]),
     "sdk_ecapa_forward": (_i, [_vp, _vp, C.POINTER(EcapaDesc), _vp, _i, _i, _i, _vp, _sz, _vp, _vp]),
     "sdk_l2norm": (_i, [_vp, _vp, _i, _i, _vp, _vp, _vp, _vp]),
-    "sdk_affinity_workspace_bytes": (_sz, [_i]),
+    "sdk_affinity_workspace_bytes": (_sz, [_i, _i]),
     "sdk_affinity_matvec_workspace_bytes": (_sz, [_i]),
     "sdk_affinity_matvec": (_i, [_vp, _vp, _i, _i, _i, _i, _vp, _vp, _i, _vp, _vp, _sz, _vp]),
     "sdk_rows_gram_workspace_bytes": (_sz, [_i, _i]),

@@ -28,12 +28,28 @@ __global__ __launch_bounds__(NT) void se_gate_residual_kernel(
   float s[8];
 #pragma unroll
   for (int e = 0; e < 8; ++e) s[e] = 0.f;
-  for (int t = grp; t < T; t += ngrp) {
-    const u32x4 v = *reinterpret_cast<const u32x4*>(z + (base + t) * ldz + c8 * 8);
-    float f[8];
-    unpack8(v, f);
+  {
+    // 4 independent 16-byte loads in flight per lane (the sweep is latency-bound otherwise)
+    const bf16_t* zp = z + base * ldz + c8 * 8;
+    int t = grp;
+    for (; t + 3 * ngrp < T; t += 4 * ngrp) {
+      u32x4 v[4];
 #pragma unroll
-    for (int e = 0; e < 8; ++e) s[e] += f[e];
+      for (int u = 0; u < 4; ++u) v[u] = *reinterpret_cast<const u32x4*>(zp + (int64_t)(t + u * ngrp) * ldz);
+#pragma unroll
+      for (int u = 0; u < 4; ++u) {
+        float f[8];
+        unpack8(v[u], f);
+#pragma unroll
+        for (int e = 0; e < 8; ++e) s[e] += f[e];
+      }
+    }
+    for (; t < T; t += ngrp) {
+      float f[8];
+      unpack8(*reinterpret_cast<const u32x4*>(zp + (int64_t)t * ldz), f);
+#pragma unroll
+      for (int e = 0; e < 8; ++e) s[e] += f[e];
+    }
   }
 #pragma unroll
   for (int e = 0; e < 8; ++e) part[grp * C + c8 * 8 + e] = s[e];
@@ -71,15 +87,31 @@ __global__ __launch_bounds__(NT) void se_gate_residual_kernel(
   float g[8];
 #pragma unroll
   for (int e = 0; e < 8; ++e) g[e] = mean[c8 * 8 + e];
-  for (int t = grp; t < T; t += ngrp) {
-    const u32x4 zv = *reinterpret_cast<const u32x4*>(z + (base + t) * ldz + c8 * 8);
-    const u32x4 xv = *reinterpret_cast<const u32x4*>(x + (base + t) * ldx + c8 * 8);
-    float fz[8], fx[8];
-    unpack8(zv, fz);
-    unpack8(xv, fx);
+  {
+    const bf16_t* zp = z + base * ldz + c8 * 8;
+    const bf16_t* xp = x + base * ldx + c8 * 8;
+    bf16_t* op = out + base * ldo + c8 * 8;
+    auto one = [&](const u32x4& zv, const u32x4& xv, int t) {
+      float fz[8], fx[8];
+      unpack8(zv, fz);
+      unpack8(xv, fx);
 #pragma unroll
-    for (int e = 0; e < 8; ++e) fz[e] = g[e] * fz[e] + fx[e];
-    *reinterpret_cast<u32x4*>(out + (base + t) * ldo + c8 * 8) = pack8(fz);
+      for (int e = 0; e < 8; ++e) fz[e] = g[e] * fz[e] + fx[e];
+      *reinterpret_cast<u32x4*>(op + (int64_t)t * ldo) = pack8(fz);
+    };
+    int t = grp;
+    for (; t + 3 * ngrp < T; t += 4 * ngrp) {
+      u32x4 zv[4], xv[4];
+#pragma unroll
+      for (int u = 0; u < 4; ++u) {
+        zv[u] = *reinterpret_cast<const u32x4*>(zp + (int64_t)(t + u * ngrp) * ldz);
+        xv[u] = *reinterpret_cast<const u32x4*>(xp + (int64_t)(t + u * ngrp) * ldx);
+      }
+#pragma unroll
+      for (int u = 0; u < 4; ++u) one(zv[u], xv[u], t + u * ngrp);
+    }
+    for (; t < T; t += ngrp)
+      one(*reinterpret_cast<const u32x4*>(zp + (int64_t)t * ldz), *reinterpret_cast<const u32x4*>(xp + (int64_t)t * ldx), t);
   }
 }
 

@@ -5,16 +5,18 @@
 //
 //  coarse pass (affinity_coarse_kernel)   bf16 MFMA, S^T tile = P_tile[32 x 192] . E_tile[32 x 192]^T
 //      with the PROFILE index on the accumulator registers and the SEGMENT on the lane: every lane
-//      owns one segment and keeps a sorted top-4 of the profiles it has seen in registers
-//      (insert = 1 v_max + 3 v_med3 on values whose low 10 mantissa bits carry the profile index).
-//      Nothing but 8 candidates per segment is written to HBM.
+//      owns one segment and keeps a sorted top-3 of the profiles it has seen in registers
+//      (insert = 1 v_max + 2 v_med3 on values whose low 10 mantissa bits carry the profile index;
+//      5 VALU ops per score in all - the kernel is VALU-issue-bound, so every op counts).
+//      Profile tiles arrive by LDS-DMA into a 3-stage ring.  Only 6 candidates per segment reach HBM.
 //  exact pass (affinity_rescore_kernel)   fp32 re-score of the candidates that can still win, fixed
 //      summation order; certifies the result against the rigorous rounding bound
 //          |exact - coarse| <= r_e + (1 + r_e) r_p + 2^-13 + K 2^-23 =: eps
 //      (r_e, r_p = measured bf16 rounding residual norms from sdk_l2norm): any profile that is not a
-//      candidate scores at most u + eps, u = the larger of the two lane-halves' 4th-best coarse
-//      score.  Rows with x_k <= u + eps are queued for
-//  exact rescan (affinity_rescan_kernel)  fp32 scan over all P with the same dot-product routine.
+//      candidate scores at most u + eps, u = the larger of the two lane-halves' 3rd-best coarse
+//      score.  Rows with x_k <= u + eps (~1 % for k = 1) are queued for
+//  exact rescan (affinity_rescan_kernel)  fp32 scan over all P with the same dot-product routine,
+//      one work item per (row, 1024-profile slice), merged by affinity_rescan_merge_kernel.
 // The reported (idx, score) therefore equal an fp32 full scan: ties -> lowest profile index.
 #include "common.hpp"
 
@@ -26,10 +28,12 @@ constexpr int SEG_PER_WAVE = 32;
 constexpr int WAVES = 4;
 constexpr int SEG_PER_WG = SEG_PER_WAVE * WAVES;   // 128
 constexpr int PT = 32;                 // profiles per tile
-constexpr int PROW = 400;              // LDS bytes per profile row (384 + 16 pad: 25 slots, odd -> conflict-free)
+constexpr int PROWB = 384;             // LDS bytes per profile row (24 chunks of 16 B, XOR-swizzled)
+constexpr int NSTAGE = 3;              // LDS ring depth (2 tiles in flight); 36 KiB -> 4 workgroups per CU
 constexpr int CHUNK_TILES = 32;        // 1024 profiles share one 10-bit index space
 constexpr uint32_t IDX_MASK = 0x3ffu;
-constexpr int NCAND = 8;
+constexpr int DEPTH = 3;               // per-lane sorted candidate list (one lane = one half of the profiles)
+constexpr int NCAND = 2 * DEPTH;
 
 struct Workspace {        // layout inside the caller's scratch buffer
   float* cand_val;        // [N][8] coarse value (index bits stripped)
@@ -37,11 +41,13 @@ struct Workspace {        // layout inside the caller's scratch buffer
   float* ubound;          // [N]    u (see header comment)
   int32_t* flag_count;    // [1]
   int32_t* flag_rows;     // [N]
+  float* part_s;          // [N * nslices * 4] partial exact lists of the rescan (only when P > 1024)
+  int32_t* part_i;
 };
 
 __host__ __device__ inline size_t align256(size_t v) { return (v + 255) & ~(size_t)255; }
 
-inline size_t ws_layout(int N, char* base, Workspace* w) {
+inline size_t ws_layout(int N, int P, char* base, Workspace* w) {
   size_t off = 0;
   auto take = [&](size_t bytes) { char* p = base ? base + off : nullptr; off += align256(bytes); return p; };
   char* a = take((size_t)N * NCAND * 4);
@@ -49,17 +55,20 @@ inline size_t ws_layout(int N, char* base, Workspace* w) {
   char* c = take((size_t)N * 4);
   char* d = take(256);
   char* e = take((size_t)N * 4);
+  const size_t nsl = (size_t)((P + 1023) / 1024);
+  char* f1 = take(nsl > 1 ? (size_t)N * nsl * 16 : 16);
+  char* f2 = take(nsl > 1 ? (size_t)N * nsl * 16 : 16);
+  if (w) { w->part_s = (float*)f1; w->part_i = (int32_t*)f2; }
   if (w) { w->cand_val = (float*)a; w->cand_idx = (int32_t*)b; w->ubound = (float*)c; w->flag_count = (int32_t*)d; w->flag_rows = (int32_t*)e; }
   return off;
 }
 
-// sorted insert of x into (m0 >= m1 >= m2 >= m3); values are packed floats
-__device__ __forceinline__ void insert4(float x, float& m0, float& m1, float& m2, float& m3) {
-  const float n3 = __builtin_amdgcn_fmed3f(x, m2, m3);
+// sorted insert of x into (m0 >= m1 >= m2): 1 v_max + 2 v_med3; values are packed floats
+__device__ __forceinline__ void insert3(float x, float& m0, float& m1, float& m2) {
   const float n2 = __builtin_amdgcn_fmed3f(x, m1, m2);
   const float n1 = __builtin_amdgcn_fmed3f(x, m0, m1);
   m0 = fmaxf(x, m0);
-  m1 = n1; m2 = n2; m3 = n3;
+  m1 = n1; m2 = n2;
 }
 
 __global__ __launch_bounds__(WAVES * 64, 2) void affinity_coarse_kernel(const bf16_t* __restrict__ Eb,
@@ -67,7 +76,11 @@ __global__ __launch_bounds__(WAVES * 64, 2) void affinity_coarse_kernel(const bf
                                                                        float* __restrict__ cand_val,
                                                                        int32_t* __restrict__ cand_idx,
                                                                        float* __restrict__ ubound) {
-  __shared__ __attribute__((aligned(16))) char sP[2][PT * PROW];
+  // Profile tiles stream through a 3-stage LDS ring filled by LDS-DMA (global_load_lds_dwordx4), two
+  // tiles in flight behind a counted vmcnt and ONE raw barrier per tile.  Rows are 384 B (24 chunks of
+  // 16 B), unpadded because the DMA writes 1 KiB linearly; bank conflicts are removed by XORing the low
+  // 3 bits of the chunk index with (row >> 1) & 7 on the SOURCE address and again on the fragment read.
+  __shared__ __attribute__((aligned(16))) char sP[NSTAGE][PT * PROWB];
   const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
   const int col = lane & 31, h = lane >> 5;
   const int seg = blockIdx.x * SEG_PER_WG + wid * SEG_PER_WAVE + col;
@@ -79,107 +92,113 @@ __global__ __launch_bounds__(WAVES * 64, 2) void affinity_coarse_kernel(const bf
   for (int ks = 0; ks < KS; ++ks)
     bfrag[ks] = *reinterpret_cast<const bf16x8*>(Eb + (int64_t)seg_c * D + ks * 16 + h * 8);
 
-  // staging: 32 rows x 24 chunks of 16 B = 768 chunks, 3 per thread
   const int ntiles = (P + PT - 1) / PT;
-  u32x4 st[3];
-  auto gload = [&](int tile) {
+  // DMA assignment: a tile is 768 chunks = 12 wave-instructions; wave w issues instructions 3w .. 3w+2
+  int drow[3], dsrc[3];
+#pragma unroll
+  for (int i = 0; i < 3; ++i) {
+    const int id = (wid * 3 + i) * 64 + lane;
+    const int row = id / 24, pos = id - row * 24;
+    drow[i] = row;
+    dsrc[i] = ((pos & ~7) | ((pos & 7) ^ ((row >> 1) & 7))) * 8;    // source chunk (elements)
+  }
+  auto issue = [&](int tile) {
+    char* st = sP[tile % NSTAGE];
 #pragma unroll
     for (int i = 0; i < 3; ++i) {
-      const int id = tid + 256 * i;
-      const int row = id / 24, ch = id - row * 24;
-      int pr = tile * PT + row;
+      int pr = tile * PT + drow[i];
       pr = pr < P ? pr : P - 1;
-      st[i] = *reinterpret_cast<const u32x4*>(Pb + (int64_t)pr * D + ch * 8);
-    }
-  };
-  auto swrite = [&](int buf) {
-#pragma unroll
-    for (int i = 0; i < 3; ++i) {
-      const int id = tid + 256 * i;
-      const int row = id / 24, ch = id - row * 24;
-      *reinterpret_cast<u32x4*>(&sP[buf][row * PROW + ch * 16]) = st[i];
+      __builtin_amdgcn_global_load_lds((const void __attribute__((address_space(1)))*)(Pb + (int64_t)pr * D + dsrc[i]),
+                                       (void __attribute__((address_space(3)))*)(st + (wid * 3 + i) * 1024), 16, 0, 0);
     }
   };
 
   // global candidate list of this lane (its half of the profiles): value + full index
-  float gv[4] = {-INFINITY, -INFINITY, -INFINITY, -INFINITY};
-  int gi[4] = {-1, -1, -1, -1};
+  float gv[DEPTH] = {-INFINITY, -INFINITY, -INFINITY};
+  int gi[DEPTH] = {-1, -1, -1};
   // chunk-local packed list
-  float m0 = -INFINITY, m1 = -INFINITY, m2 = -INFINITY, m3 = -INFINITY;
+  float m0 = -INFINITY, m1 = -INFINITY, m2 = -INFINITY;
 
   auto merge_chunk = [&](int chunk) {
-    float mv[4] = {m0, m1, m2, m3};
+    const float mv[DEPTH] = {m0, m1, m2};
 #pragma unroll
-    for (int e = 0; e < 4; ++e) {
+    for (int e = 0; e < DEPTH; ++e) {
       const uint32_t bits = __float_as_uint(mv[e]);
-      if (mv[e] == -INFINITY) continue;
-      const float v = __uint_as_float(bits & ~IDX_MASK);
+      const bool live = mv[e] != -INFINITY;
+      const float v = live ? __uint_as_float(bits & ~IDX_MASK) : -INFINITY;
       const int idx = chunk * (CHUNK_TILES * PT) + (int)(bits & IDX_MASK);
-      // insert (v, idx) into the sorted global list
-      int pos = 4;
+      // insert (v, idx) into the sorted global list (a dead entry compares below everything: no-op)
+      int pos = DEPTH;
 #pragma unroll
-      for (int q = 3; q >= 0; --q)
+      for (int q = DEPTH - 1; q >= 0; --q)
         if (v > gv[q]) pos = q;
 #pragma unroll
-      for (int q = 3; q >= 1; --q)
+      for (int q = DEPTH - 1; q >= 1; --q)
         if (q > pos) { gv[q] = gv[q - 1]; gi[q] = gi[q - 1]; }
 #pragma unroll
-      for (int q = 0; q < 4; ++q)
+      for (int q = 0; q < DEPTH; ++q)
         if (q == pos) { gv[q] = v; gi[q] = idx; }
     }
-    m0 = m1 = m2 = m3 = -INFINITY;
+    m0 = m1 = m2 = -INFINITY;
   };
 
-  gload(0);
-  swrite(0);
-  __syncthreads();
-  const int arow = col * PROW + h * 16;
+  issue(0);
+  if (ntiles > 1) issue(1);
+  const int rsw = (col >> 1) & 7;
   for (int t = 0; t < ntiles; ++t) {
-    const int buf = t & 1;
-    if (t + 1 < ntiles) gload(t + 1);
+    if (t + 1 < ntiles) asm volatile("s_waitcnt vmcnt(3)" ::: "memory");   // tile t+1 (3 DMA instructions) may stay in flight
+    else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();                               // tile t landed for everyone; the stage of tile t-1 is free
+    if (t + 2 < ntiles) issue(t + 2);
+    const char* st = sP[t % NSTAGE] + col * PROWB;
     f32x16 acc;
 #pragma unroll
     for (int r = 0; r < 16; ++r) acc[r] = 0.f;
 #pragma unroll
     for (int ks = 0; ks < KS; ++ks) {
-      const bf16x8 a = *reinterpret_cast<const bf16x8*>(&sP[buf][arow + ks * 32]);
+      const int c = ks * 2 + h;
+      const bf16x8 a = *reinterpret_cast<const bf16x8*>(st + (((c & ~7) | ((c & 7) ^ rsw)) << 4));
       acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, bfrag[ks], acc, 0, 0, 0);
     }
     const int tl = t & (CHUNK_TILES - 1);
     const uint32_t tb = (uint32_t)(tl * PT + 4 * h);
-    const bool partial = (t + 1) * PT > P;
+    if ((t + 1) * PT <= P) {                                     // full tile: 5 VALU ops per score
 #pragma unroll
-    for (int r = 0; r < 16; ++r) {
-      const uint32_t rc = (uint32_t)((r & 3) + 8 * (r >> 2));
-      float x = __uint_as_float(((__float_as_uint(acc[r]) & ~IDX_MASK) | tb) | rc);
-      if (partial && (t * PT + (int)rc + 4 * h) >= P) x = -INFINITY;   // rows past the last profile
-      insert4(x, m0, m1, m2, m3);
+      for (int r = 0; r < 16; ++r) {
+        const uint32_t rc = (uint32_t)((r & 3) + 8 * (r >> 2));
+        insert3(__uint_as_float(((__float_as_uint(acc[r]) & ~IDX_MASK) | tb) | rc), m0, m1, m2);
+      }
+    } else {                                                     // last, partial tile: rows past the last profile never enter
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const uint32_t rc = (uint32_t)((r & 3) + 8 * (r >> 2));
+        float x = __uint_as_float(((__float_as_uint(acc[r]) & ~IDX_MASK) | tb) | rc);
+        if (t * PT + (int)rc + 4 * h >= P) x = -INFINITY;
+        insert3(x, m0, m1, m2);
+      }
     }
     if (tl == CHUNK_TILES - 1 || t + 1 == ntiles) merge_chunk(t / CHUNK_TILES);
-    if (t + 1 < ntiles) swrite(buf ^ 1);
-    __syncthreads();
   }
   if (seg < N) {
 #pragma unroll
-    for (int e = 0; e < 4; ++e) {
-      cand_val[(int64_t)seg * NCAND + h * 4 + e] = gv[e];
-      cand_idx[(int64_t)seg * NCAND + h * 4 + e] = gi[e];
+    for (int e = 0; e < DEPTH; ++e) {
+      cand_val[(int64_t)seg * NCAND + h * DEPTH + e] = gv[e];
+      cand_idx[(int64_t)seg * NCAND + h * DEPTH + e] = gi[e];
     }
-    // u = max over the two halves of their 4th best (a bound on every profile that is not a candidate)
-    const float other = __shfl_xor(gv[3], 32, 64);
-    if (h == 0) ubound[seg] = fmaxf(gv[3], other);
+    // u = max over the two halves of their last list entry (a bound on every profile that is not a candidate)
+    const float other = __shfl_xor(gv[DEPTH - 1], 32, 64);
+    if (h == 0) ubound[seg] = fmaxf(gv[DEPTH - 1], other);
   }
 }
 
 // ---- exact fp32 dot product of two 192-vectors by a group of 8 consecutive lanes ---------------
 // lane j of the group owns elements [24 j, 24 j + 24); fixed order: sequential fma inside the lane,
 // then the xor-butterfly 1,2,4 (fp add is commutative, so all 8 lanes hold the same bits).
-__device__ __forceinline__ float dot192_group8(const float* __restrict__ e24, const float* __restrict__ prow, int j) {
-  const f32x4* p = reinterpret_cast<const f32x4*>(prow + 24 * j);
+__device__ __forceinline__ float dot192_regs(const float* __restrict__ e24, const f32x4* __restrict__ pv) {
   float a = 0.f;
 #pragma unroll
   for (int q = 0; q < 6; ++q) {
-    const f32x4 v = p[q];
+    const f32x4 v = pv[q];
     a = fmaf(e24[4 * q + 0], v[0], a);
     a = fmaf(e24[4 * q + 1], v[1], a);
     a = fmaf(e24[4 * q + 2], v[2], a);
@@ -189,6 +208,16 @@ __device__ __forceinline__ float dot192_group8(const float* __restrict__ e24, co
   a += __shfl_xor(a, 2, 64);
   a += __shfl_xor(a, 4, 64);
   return a;
+}
+__device__ __forceinline__ void load_prow(const float* __restrict__ prow, int j, f32x4* pv) {
+  const f32x4* p = reinterpret_cast<const f32x4*>(prow + 24 * j);
+#pragma unroll
+  for (int q = 0; q < 6; ++q) pv[q] = p[q];
+}
+__device__ __forceinline__ float dot192_group8(const float* __restrict__ e24, const float* __restrict__ prow, int j) {
+  f32x4 pv[6];
+  load_prow(prow, j, pv);
+  return dot192_regs(e24, pv);
 }
 
 __device__ __forceinline__ bool better(float s, int i, float s2, int i2) { return s > s2 || (s == s2 && i < i2); }
@@ -288,17 +317,43 @@ __global__ __launch_bounds__(256) void affinity_rescore_kernel(const float* __re
   }
 }
 
-// One workgroup per uncertain row: 32 lane-groups scan P/32 profiles each, then merge.
+// Exact rescan of the uncertain rows.  Work item = (flagged row, slice of 1024 profiles): 32 lane groups
+// score 32 profiles each (four rows in flight per group), the 128 partial entries meet in LDS and one
+// wave selects the slice's best four by shuffles.  A second tiny kernel merges a row's slices.
+constexpr int SLICE = 1024;
+
+// wave-wide selection of the K best (score desc, index asc) among 2 entries per lane; result on every lane
+__device__ __forceinline__ void wave_select4(float s0, int i0, float s1, int i1, float* os, int* oi) {
+#pragma unroll
+  for (int q = 0; q < 4; ++q) {
+    float bs = s0; int bi = i0;
+    if (better(s1, i1, bs, bi)) { bs = s1; bi = i1; }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) {
+      const float ts = __shfl_xor(bs, o, 64);
+      const int ti = __shfl_xor(bi, o, 64);
+      if (better(ts, ti, bs, bi)) { bs = ts; bi = ti; }
+    }
+    os[q] = bs; oi[q] = bi;
+    if (s0 == bs && i0 == bi) { s0 = -INFINITY; i0 = 0x7fffffff; }      // the winner leaves the pool
+    if (s1 == bs && i1 == bi) { s1 = -INFINITY; i1 = 0x7fffffff; }
+  }
+}
+
 __global__ __launch_bounds__(256) void affinity_rescan_kernel(const float* __restrict__ E, const float* __restrict__ Pm,
                                                              int P, int k, const int32_t* __restrict__ flag_count,
                                                              const int32_t* __restrict__ flag_rows,
+                                                             float* __restrict__ part_s, int32_t* __restrict__ part_i,
                                                              int32_t* __restrict__ idx, float* __restrict__ score) {
-  __shared__ float ls[32][4];
-  __shared__ int li[32][4];
+  __shared__ float ls[128];
+  __shared__ int li[128];
   const int tid = threadIdx.x, j = tid & 7, g = tid >> 3;
   const int count = *flag_count;
-  for (int f = blockIdx.x; f < count; f += gridDim.x) {
+  const int nsl = (P + SLICE - 1) / SLICE;
+  for (int item = blockIdx.x; item < count * nsl; item += gridDim.x) {
+    const int f = item / nsl, sl = item - f * nsl;
     const int row = flag_rows[f];
+    const int p0 = sl * SLICE, p1 = min(P, p0 + SLICE);
     float e24[24];
 #pragma unroll
     for (int q = 0; q < 6; ++q) {
@@ -307,27 +362,67 @@ __global__ __launch_bounds__(256) void affinity_rescan_kernel(const float* __res
     }
     float bs[4] = {-INFINITY, -INFINITY, -INFINITY, -INFINITY};
     int bi[4] = {0x7fffffff, 0x7fffffff, 0x7fffffff, 0x7fffffff};
-    for (int p = g; p < P; p += 32) {
-      const float s = dot192_group8(e24, Pm + (int64_t)p * D, j);
-      insert_exact<4>(s, p, bs, bi);
+    for (int p = p0 + g; p < p1; p += 4 * 32) {             // four profile rows in flight per lane group
+      f32x4 pv[4][6];
+#pragma unroll
+      for (int u = 0; u < 4; ++u) {
+        const int pp = p + 32 * u;
+        load_prow(Pm + (int64_t)(pp < p1 ? pp : p1 - 1) * D, j, pv[u]);
+      }
+#pragma unroll
+      for (int u = 0; u < 4; ++u) {
+        const int pp = p + 32 * u;
+        const float sc = dot192_regs(e24, pv[u]);         // every lane of the group runs the shuffles
+        if (pp < p1) insert_exact<4>(sc, pp, bs, bi);
+      }
     }
     if (j == 0) {
 #pragma unroll
-      for (int q = 0; q < 4; ++q) { ls[g][q] = bs[q]; li[g][q] = bi[q]; }
+      for (int q = 0; q < 4; ++q) { ls[g * 4 + q] = bs[q]; li[g * 4 + q] = bi[q]; }
     }
     __syncthreads();
-    if (tid == 0) {
-      float fs[4] = {-INFINITY, -INFINITY, -INFINITY, -INFINITY};
-      int fi[4] = {0x7fffffff, 0x7fffffff, 0x7fffffff, 0x7fffffff};
-      for (int gg = 0; gg < 32; ++gg)
-        for (int q = 0; q < 4; ++q)
-          if (li[gg][q] != 0x7fffffff) insert_exact<4>(ls[gg][q], li[gg][q], fs, fi);
-      for (int q = 0; q < k; ++q) {
-        idx[(int64_t)row * k + q] = fi[q];
-        score[(int64_t)row * k + q] = fs[q];
+    if (tid < 64) {
+      float os[4]; int oi[4];
+      wave_select4(ls[tid], li[tid], ls[tid + 64], li[tid + 64], os, oi);
+      if (tid == 0) {
+        if (nsl == 1) {
+          for (int q = 0; q < k; ++q) { idx[(int64_t)row * k + q] = oi[q]; score[(int64_t)row * k + q] = os[q]; }
+        } else {
+#pragma unroll
+          for (int q = 0; q < 4; ++q) { part_s[(int64_t)item * 4 + q] = os[q]; part_i[(int64_t)item * 4 + q] = oi[q]; }
+        }
       }
     }
     __syncthreads();
+  }
+}
+
+__global__ __launch_bounds__(64) void affinity_rescan_merge_kernel(int P, int k, const int32_t* __restrict__ flag_count,
+                                                                  const int32_t* __restrict__ flag_rows,
+                                                                  const float* __restrict__ part_s, const int32_t* __restrict__ part_i,
+                                                                  int32_t* __restrict__ idx, float* __restrict__ score) {
+  const int nsl = (P + SLICE - 1) / SLICE;
+  if (nsl == 1) return;
+  const int count = *flag_count, lane = threadIdx.x;
+  for (int f = blockIdx.x; f < count; f += gridDim.x) {
+    float fs[4] = {-INFINITY, -INFINITY, -INFINITY, -INFINITY};
+    int fi[4] = {0x7fffffff, 0x7fffffff, 0x7fffffff, 0x7fffffff};
+    for (int e0 = 0; e0 < nsl * 4; e0 += 128) {            // 128 partial entries per pass, folded into the running best
+      const int ea = e0 + lane, eb = e0 + lane + 64;
+      float s0 = ea < nsl * 4 ? part_s[(int64_t)f * nsl * 4 + ea] : -INFINITY;
+      int i0 = ea < nsl * 4 ? part_i[(int64_t)f * nsl * 4 + ea] : 0x7fffffff;
+      float s1 = eb < nsl * 4 ? part_s[(int64_t)f * nsl * 4 + eb] : -INFINITY;
+      int i1 = eb < nsl * 4 ? part_i[(int64_t)f * nsl * 4 + eb] : 0x7fffffff;
+      float os[4]; int oi[4];
+      wave_select4(s0, i0, s1, i1, os, oi);
+#pragma unroll
+      for (int q = 0; q < 4; ++q)
+        if (oi[q] != 0x7fffffff) insert_exact<4>(os[q], oi[q], fs, fi);
+    }
+    if (lane == 0) {
+      const int row = flag_rows[f];
+      for (int q = 0; q < k; ++q) { idx[(int64_t)row * k + q] = fi[q]; score[(int64_t)row * k + q] = fs[q]; }
+    }
   }
 }
 
@@ -335,7 +430,7 @@ __global__ void copy_count_kernel(const int32_t* src, int32_t* dst) { *dst = *sr
 
 }  // namespace
 
-extern "C" size_t sdk_affinity_workspace_bytes(int N) { return N > 0 ? ws_layout(N, nullptr, nullptr) : 0; }
+extern "C" size_t sdk_affinity_workspace_bytes(int N, int P) { return N > 0 && P > 0 ? ws_layout(N, P, nullptr, nullptr) : 0; }
 
 extern "C" int sdk_affinity_topk(sdk_ctx* ctx, const float* E, const uint16_t* Eb, const float* resid_e,
                                  const float* P, const uint16_t* Pb, const float* resid_p, int N, int Pn, int d, int k,
@@ -345,12 +440,12 @@ extern "C" int sdk_affinity_topk(sdk_ctx* ctx, const float* E, const uint16_t* E
   SDK_REQUIRE(d == D, "sdk_affinity_topk: d=%d, this build is specialised for d=%d", d, D);
   SDK_REQUIRE(N > 0 && Pn > 0, "sdk_affinity_topk: empty problem (N=%d P=%d)", N, Pn);
   SDK_REQUIRE(k >= 1 && k <= 4 && k <= Pn, "sdk_affinity_topk: k=%d must be in [1, min(4, P)]", k);
-  SDK_REQUIRE(ws_bytes >= sdk_affinity_workspace_bytes(N), "sdk_affinity_topk: workspace too small");
+  SDK_REQUIRE(ws_bytes >= sdk_affinity_workspace_bytes(N, Pn), "sdk_affinity_topk: workspace too small");
   SDK_REQUIRE(((uintptr_t)E % 16) == 0 && ((uintptr_t)Eb % 16) == 0 && ((uintptr_t)P % 16) == 0 && ((uintptr_t)Pb % 16) == 0,
               "sdk_affinity_topk: matrices must be 16-byte aligned");
   hipStream_t s = (hipStream_t)stream;
   Workspace w;
-  ws_layout(N, (char*)ws, &w);
+  ws_layout(N, Pn, (char*)ws, &w);
   SDK_HIP_OK(hipMemsetAsync(w.flag_count, 0, sizeof(int32_t), s));
   {
   ProfScope ps(ctx, stream, SDK_K_AFF_COARSE, 2.0 * N * (double)Pn * D, 2.0 * ((double)N + Pn) * D + 68.0 * N);
@@ -366,8 +461,11 @@ extern "C" int sdk_affinity_topk(sdk_ctx* ctx, const float* E, const uint16_t* E
   SDK_LAUNCH_CHECK();
   {
   ProfScope ps(ctx, stream, SDK_K_AFF_RESCAN, 0.0, 0.0);
-  hipLaunchKernelGGL(affinity_rescan_kernel, dim3(1024), dim3(256), 0, s, E, P, Pn, k, w.flag_count, w.flag_rows, idx,
-                     score);
+  hipLaunchKernelGGL(affinity_rescan_kernel, dim3(2048), dim3(256), 0, s, E, P, Pn, k, w.flag_count, w.flag_rows, w.part_s,
+                     w.part_i, idx, score);
+  if (Pn > SLICE)
+    hipLaunchKernelGGL(affinity_rescan_merge_kernel, dim3(512), dim3(64), 0, s, Pn, k, w.flag_count, w.flag_rows, w.part_s, w.part_i,
+                       idx, score);
   }
   SDK_LAUNCH_CHECK();
   if (n_rescanned) {

@@ -158,7 +158,7 @@ class Engine:
         idx = torch.empty((N, k), dtype=torch.int32, device=self.device)
         sc = torch.empty((N, k), dtype=torch.float32, device=self.device)
         cnt = torch.zeros((1,), dtype=torch.int32, device=self.device) if want_count else None
-        ws = self._scratch_bytes("affinity", self.lib.sdk_affinity_workspace_bytes(N))
+        ws = self._scratch_bytes("affinity", self.lib.sdk_affinity_workspace_bytes(N, Pn))
         check(self.lib.sdk_affinity_topk(self.ctx, E.data_ptr(), Eb.data_ptr(), re.data_ptr(), P.data_ptr(), Pb.data_ptr(),
                                          rp_max.data_ptr(), N, Pn, d, k, idx.data_ptr(), sc.data_ptr(), _ptr(cnt),
                                          ws.data_ptr(), ws.numel(), _stream()), "sdk_affinity_topk")

@@ -54,7 +54,7 @@ def test_host_only_entry_points_work_without_gpu():
         assert np.allclose(melw[of:of + ln], Wm[st:st + ln, m], rtol=0, atol=1e-7)
     assert lib.sdk_fbank_tables_fill(buf.ctypes.data, 10) != 0 and b"too small" in lib.sdk_last_error()
     assert lib.sdk_fbank_workspace_bytes(1000, 32000) == 1000 * 201 * 80 * 4
-    assert lib.sdk_affinity_workspace_bytes(100000) > 100000 * 72
+    assert lib.sdk_affinity_workspace_bytes(100000, 1000) > 100000 * 56
 
 
 def test_no_gpu_means_loud_failure():

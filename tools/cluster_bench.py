@@ -1,0 +1,29 @@
+#!/usr/bin/env python3
+"""Config #5 (down-scaled on one GPU): rectified-affinity mat-vec rate and a full spectral clustering run."""
+import importlib, sys, time, json
+from pathlib import Path
+import numpy as np, torch
+sys.path.insert(0, str(Path(__file__).resolve().parent.parent))
+ops = importlib.import_module("speaker-diarization-toolkit_amd.ops")
+CL = importlib.import_module("speaker-diarization-toolkit_amd.cluster")
+from oracle import spectral as ospec
+eng = ops.get_engine(0)
+N = int(sys.argv[1]) if len(sys.argv) > 1 else 100_000
+k = 16
+E, truth = ospec.vmf_mixture(N, 192, k, seed=5, noise=0.6)
+En, Eb, _ = eng.l2norm(torch.from_numpy(E).cuda())
+X = torch.randn(N, k, device="cuda")
+for _ in range(2): eng.affinity_matvec(Eb, X)
+eng.profile_begin()
+for _ in range(3): eng.affinity_matvec(Eb, X)
+p = eng.profile_end()["affinity_matvec"]
+ms = p["ms"] / 3
+out = {"N": N, "kv": k, "matvec_ms": round(ms, 3), "pairs_per_sec": round(N * N / (ms * 1e-3), 1),
+       "mfma_tflops_executed": round(p["flops"] / 3 / (ms * 1e-3) / 1e12, 1),
+       "algorithmic_tflops_2N2(d+k)": round(2.0 * N * N * (192 + k) / (ms * 1e-3) / 1e12, 1)}
+torch.cuda.synchronize(); t0 = time.perf_counter()
+res = CL.spectral_cluster(eng, En, Eb, N, k, n_iter=15, n_kmeans=15)
+torch.cuda.synchronize(); out["spectral_cluster_s"] = round(time.perf_counter() - t0, 3)
+out["ari_vs_truth"] = ospec.adjusted_rand_index(res.labels, truth)
+out["eigenvalues"] = [round(float(x), 5) for x in res.eigenvalues[:6]]
+print(json.dumps(out))
