@@ -111,10 +111,14 @@ int sdk_set_gemm_variant(int variant);
 /* Squeeze-excitation gate + residual, one workgroup per segment:
  *   mean[c] = (1/T) sum_t z[b,t,c];  h = relu(W1 mean + b1);  g = sigmoid(W2 h + b2)
  *   out[b,t,c] = bf16(g[c]*z[b,t,c] + x[b,t,c])
- * w1t [C, Cse] fp32 (transposed), w2t [Cse, C] fp32 (transposed). C % 8 == 0, C <= 1024*?; */
+ * w1t [C, Cse] fp32 (transposed), w2t [Cse, C] fp32 (transposed).  C % 8 == 0 and (C/8) | 256, Cse | 256.
+ * With a workspace the work is split into a mean sweep, two batched FCs on the fp32 matrix pipe and an
+ * apply sweep (same arithmetic, weights read once per 32 segments). */
+size_t sdk_se_workspace_bytes(int B, int C, int Cse);   /* fp32 [B,C] means + [B,Cse] hidden + [B,C] gates */
 int sdk_se_gate_residual(sdk_ctx* ctx, const uint16_t* z, int64_t ldz, const uint16_t* x, int64_t ldx,
                          const float* w1t, const float* b1, const float* w2t, const float* b2,
-                         uint16_t* out, int64_t ldo, int B, int T, int C, int Cse, void* stream);
+                         uint16_t* out, int64_t ldo, int B, int T, int C, int Cse,
+                         void* ws, size_t ws_bytes, void* stream);   /* ws may be NULL: one-kernel-per-segment form */
 
 /* Attentive statistics pooling pieces.
  *   sdk_asp_stats : ctx[b, 0:C] = mean_t h, ctx[b, C:2C] = sqrt(max(var_t h, 1e-12))   fp32

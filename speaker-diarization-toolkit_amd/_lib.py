@@ -71,7 +71,8 @@ SIGNATURES = {
     "sdk_fbank": (_i, [_vp, _vp, _i, _i, _vp, _vp, _i, _vp, _sz, _vp]),
     "sdk_conv_gemm": (_i, [_vp, C.POINTER(ConvGemmArgs), _vp]),
     "sdk_set_gemm_variant": (_i, [_i]),
-    "sdk_se_gate_residual": (_i, [_vp, _vp, _i64, _vp, _i64, _vp, _vp, _vp, _vp, _vp, _i64, _i, _i, _i, _i, _vp]),
+    "sdk_se_workspace_bytes": (_sz, [_i, _i, _i]),
+    "sdk_se_gate_residual": (_i, [_vp, _vp, _i64, _vp, _i64, _vp, _vp, _vp, _vp, _vp, _i64, _i, _i, _i, _i, _vp, _sz, _vp]),
     "sdk_asp_stats": (_i, [_vp, _vp, _i64, _i, _i, _i, _vp, _vp]),
     "sdk_rows_fc": (_i, [_vp, _vp, _i64, _vp, _vp, _vp, _vp, _vp, _i64, _i, _i, _i, _i, _vp]),
     "sdk_asp_pool": (_i, [_vp, _vp, _i64, _vp, _i64, _i, _i, _i, _vp, _vp]),

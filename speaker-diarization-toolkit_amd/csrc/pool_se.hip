@@ -61,6 +61,7 @@ __global__ __launch_bounds__(NT) void se_gate_residual_kernel(
     mean[c] = m * invT;
   }
   __syncthreads();
+#ifndef SE_ABLATE_FC
   // FC1 (C -> Cse) : thread = (output j, slice k of the input range)
   {
     const int nsl = NT / Cse;              // Cse divides NT
@@ -84,6 +85,7 @@ __global__ __launch_bounds__(NT) void se_gate_residual_kernel(
     mean[c] = 1.0f / (1.0f + __expf(-a));
   }
   __syncthreads();
+#endif
   float g[8];
 #pragma unroll
   for (int e = 0; e < 8; ++e) g[e] = mean[c8 * 8 + e];
@@ -219,6 +221,126 @@ __global__ __launch_bounds__(NT) void rows_fc_kernel(const float* __restrict__ i
       else if (act == 2) v = 1.0f / (1.0f + __expf(-v));
       out[(int64_t)(b0 + r) * ldout + jo] = v;
     }
+  }
+}
+
+// ------------------------------------------------------------------------------------------
+// The same layer on the exact-fp32 matrix pipe (v_mfma_f32_32x32x2_f32 = a k-ordered fmaf chain, so the
+// result is still plain fp32 arithmetic in a fixed order).  Block = 32 rows x 32 outputs, the 4 waves
+// split K; lane half h of a wave takes k = 8g + 4h + u in MFMA step u, so every lane fetches its four
+// A values with ONE 16-byte load and the B values as four coalesced 128-byte weight-row segments.
+__global__ __launch_bounds__(NT) void rows_fc_mfma_kernel(const float* __restrict__ in, int64_t ldin,
+                                                         const float* __restrict__ isc, const float* __restrict__ ish,
+                                                         const float* __restrict__ wt, const float* __restrict__ bias,
+                                                         float* __restrict__ out, int64_t ldout, int B, int Cin, int Nout,
+                                                         int act) {
+  __shared__ float red[4][32 * 33];
+  const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
+  const int i = lane & 31, hh = lane >> 5;
+  const int b0 = blockIdx.x * 32, n0 = blockIdx.y * 32;
+  const int row = min(b0 + i, B - 1), colw = min(n0 + i, Nout - 1);
+  const int kw = Cin / 4;                                  // K range of this wave (multiple of 8)
+  const float* ap = in + (int64_t)row * ldin + wid * kw + 4 * hh;
+  const float* bp = wt + (int64_t)(wid * kw + 4 * hh) * Nout + colw;
+  const float* sp = isc ? isc + wid * kw + 4 * hh : nullptr;
+  const float* tp = isc ? ish + wid * kw + 4 * hh : nullptr;
+  f32x16 acc;
+#pragma unroll
+  for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+  for (int g = 0; g < kw; g += 8) {
+    f32x4 a = *reinterpret_cast<const f32x4*>(ap + g);
+    if (sp) {
+      const f32x4 s4 = *reinterpret_cast<const f32x4*>(sp + g), t4 = *reinterpret_cast<const f32x4*>(tp + g);
+#pragma unroll
+      for (int u = 0; u < 4; ++u) a[u] = a[u] * s4[u] + t4[u];
+    }
+    float b[4];
+#pragma unroll
+    for (int u = 0; u < 4; ++u) b[u] = bp[(int64_t)(g + u) * Nout];
+#pragma unroll
+    for (int u = 0; u < 4; ++u) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a[u], b[u], acc, 0, 0, 0);
+  }
+#pragma unroll
+  for (int r = 0; r < 16; ++r) red[wid][((r & 3) + 8 * (r >> 2) + 4 * hh) * 33 + i] = acc[r];
+  __syncthreads();
+  for (int e = tid; e < 32 * 32; e += NT) {
+    const int r = e >> 5, c = e & 31;
+    if (b0 + r < B && n0 + c < Nout) {
+      float v = ((red[0][r * 33 + c] + red[1][r * 33 + c]) + red[2][r * 33 + c]) + red[3][r * 33 + c];
+      v += bias ? bias[n0 + c] : 0.f;
+      if (act == 1) v = fmaxf(v, 0.f);
+      else if (act == 2) v = 1.0f / (1.0f + __expf(-v));
+      out[(int64_t)(b0 + r) * ldout + n0 + c] = v;
+    }
+  }
+}
+
+// SE building blocks used by the forward schedule: per-segment channel means, and the gate application.
+__global__ __launch_bounds__(NT) void seg_mean_kernel(const bf16_t* __restrict__ z, int64_t ldz, int T, int C, float* __restrict__ out) {
+  __shared__ float red[2][1024];
+  const int tid = threadIdx.x, c8 = tid & 127, grp = tid >> 7;
+  const int cbase = blockIdx.y * 1024 + c8 * 8;
+  const int64_t base = (int64_t)blockIdx.x * T;
+  float s[8];
+#pragma unroll
+  for (int e = 0; e < 8; ++e) s[e] = 0.f;
+  if (cbase < C) {
+    const bf16_t* zp = z + base * ldz + cbase;
+    int t = grp;
+    for (; t + 6 < T; t += 8) {
+      u32x4 v[4];
+#pragma unroll
+      for (int u = 0; u < 4; ++u) v[u] = *reinterpret_cast<const u32x4*>(zp + (int64_t)(t + 2 * u) * ldz);
+#pragma unroll
+      for (int u = 0; u < 4; ++u) {
+        float f[8];
+        unpack8(v[u], f);
+#pragma unroll
+        for (int e = 0; e < 8; ++e) s[e] += f[e];
+      }
+    }
+    for (; t < T; t += 2) {
+      float f[8];
+      unpack8(*reinterpret_cast<const u32x4*>(zp + (int64_t)t * ldz), f);
+#pragma unroll
+      for (int e = 0; e < 8; ++e) s[e] += f[e];
+    }
+  }
+#pragma unroll
+  for (int e = 0; e < 8; ++e) red[grp][c8 * 8 + e] = s[e];
+  __syncthreads();
+  if (grp == 0 && cbase < C) {
+    const float invT = 1.0f / (float)T;
+#pragma unroll
+    for (int e = 0; e < 8; ++e) out[(int64_t)blockIdx.x * C + cbase + e] = (red[0][c8 * 8 + e] + red[1][c8 * 8 + e]) * invT;
+  }
+}
+
+// out[b,t,c] = bf16(gate[b,c] * z[b,t,c] + x[b,t,c]);  grid (B, ceil(T/TCH)), thread = 8 channels x frame stripe
+constexpr int SE_TCH = 32;
+__global__ __launch_bounds__(NT) void se_apply_kernel(const bf16_t* __restrict__ z, int64_t ldz, const bf16_t* __restrict__ x,
+                                                     int64_t ldx, const float* __restrict__ gate, bf16_t* __restrict__ out,
+                                                     int64_t ldo, int T, int C) {
+  const int nch8 = C >> 3, ngrp = NT / nch8;
+  const int tid = threadIdx.x, c8 = tid % nch8, grp = tid / nch8;
+  const int64_t base = (int64_t)blockIdx.x * T;
+  const int t0 = blockIdx.y * SE_TCH, t1 = min(T, t0 + SE_TCH);
+  float g[8];
+  {
+    const f32x4 g0 = *reinterpret_cast<const f32x4*>(gate + (int64_t)blockIdx.x * C + c8 * 8);
+    const f32x4 g1 = *reinterpret_cast<const f32x4*>(gate + (int64_t)blockIdx.x * C + c8 * 8 + 4);
+    g[0] = g0[0]; g[1] = g0[1]; g[2] = g0[2]; g[3] = g0[3]; g[4] = g1[0]; g[5] = g1[1]; g[6] = g1[2]; g[7] = g1[3];
+  }
+  const bf16_t* zp = z + base * ldz + c8 * 8;
+  const bf16_t* xp = x + base * ldx + c8 * 8;
+  bf16_t* op = out + base * ldo + c8 * 8;
+  for (int t = t0 + grp; t < t1; t += ngrp) {
+    float fz[8], fx[8];
+    unpack8(*reinterpret_cast<const u32x4*>(zp + (int64_t)t * ldz), fz);
+    unpack8(*reinterpret_cast<const u32x4*>(xp + (int64_t)t * ldx), fx);
+#pragma unroll
+    for (int e = 0; e < 8; ++e) fz[e] = g[e] * fz[e] + fx[e];
+    *reinterpret_cast<u32x4*>(op + (int64_t)t * ldo) = pack8(fz);
   }
 }
 
@@ -393,14 +515,40 @@ __global__ __launch_bounds__(NT) void l2norm_kernel(const float* __restrict__ X,
 
 }  // namespace
 
+extern "C" size_t sdk_se_workspace_bytes(int B, int C, int Cse) {
+  return B > 0 ? ((size_t)B * C * 2 + (size_t)B * Cse) * sizeof(float) : 0;
+}
+
 extern "C" int sdk_se_gate_residual(sdk_ctx* ctx, const uint16_t* z, int64_t ldz, const uint16_t* x, int64_t ldx,
                                     const float* w1t, const float* b1, const float* w2t, const float* b2,
-                                    uint16_t* out, int64_t ldo, int B, int T, int C, int Cse, void* stream) {
+                                    uint16_t* out, int64_t ldo, int B, int T, int C, int Cse, void* ws, size_t ws_bytes,
+                                    void* stream) {
   SDK_REQUIRE(ctx && z && x && w1t && b1 && w2t && b2 && out, "sdk_se_gate_residual: null argument");
   SDK_REQUIRE(B > 0 && T > 0, "sdk_se_gate_residual: empty batch");
   SDK_REQUIRE(C % 8 == 0 && C / 8 <= NT && NT % (C / 8) == 0, "sdk_se_gate_residual: C=%d unsupported (need C/8 | 256)", C);
   SDK_REQUIRE(Cse > 0 && Cse <= NT && NT % Cse == 0 && Cse <= C, "sdk_se_gate_residual: Cse=%d unsupported (need Cse | 256)", Cse);
   SDK_REQUIRE(ldz % 8 == 0 && ldx % 8 == 0 && ldo % 8 == 0, "sdk_se_gate_residual: row strides must be multiples of 8");
+  if (ws && ws_bytes >= sdk_se_workspace_bytes(B, C, Cse)) {
+    // split schedule: channel means (one sweep of z) -> the two gate FCs batched over all segments on the
+    // matrix pipe (weights read once per 32 segments instead of once per segment) -> gate*z + x sweep
+    float* mean = (float*)ws;
+    float* hid = mean + (size_t)B * C;
+    float* gate = hid + (size_t)B * Cse;
+    {
+      ProfScope ps(ctx, stream, SDK_K_SE_GATE, 1.0 * B * T * C, 2.0 * B * T * C);
+      hipLaunchKernelGGL(seg_mean_kernel, dim3(B, ceil_div(C, 1024)), dim3(NT), 0, (hipStream_t)stream, (const bf16_t*)z, ldz, T, C, mean);
+    }
+    SDK_LAUNCH_CHECK();
+    if (int rc = sdk_rows_fc(ctx, mean, C, nullptr, nullptr, w1t, b1, hid, Cse, B, C, Cse, 1, stream)) return rc;
+    if (int rc = sdk_rows_fc(ctx, hid, Cse, nullptr, nullptr, w2t, b2, gate, C, B, Cse, C, 2, stream)) return rc;
+    {
+      ProfScope ps(ctx, stream, SDK_K_SE_GATE, 2.0 * B * T * C, 6.0 * B * T * C);
+      hipLaunchKernelGGL(se_apply_kernel, dim3(B, ceil_div(T, SE_TCH)), dim3(NT), 0, (hipStream_t)stream, (const bf16_t*)z, ldz,
+                         (const bf16_t*)x, ldx, gate, (bf16_t*)out, ldo, T, C);
+    }
+    SDK_LAUNCH_CHECK();
+    return 0;
+  }
   const int ngrp = NT / (C / 8);
   const size_t lds = (size_t)(ngrp * C + C + Cse) * sizeof(float);
   SDK_REQUIRE((size_t)(NT / Cse) * Cse <= (size_t)ngrp * C, "sdk_se_gate_residual: scratch too small");
@@ -430,8 +578,12 @@ extern "C" int sdk_rows_fc(sdk_ctx* ctx, const float* in, int64_t ldin, const fl
   SDK_REQUIRE((in_scale == nullptr) == (in_shift == nullptr), "sdk_rows_fc: in_scale and in_shift go together");
   SDK_REQUIRE(act >= 0 && act <= 2, "sdk_rows_fc: act=%d", act);
   ProfScope ps(ctx, stream, SDK_K_ROWS_FC, 2.0 * B * Cin * Nout, 4.0 * ((double)B * Cin + (double)Cin * Nout + (double)B * Nout));
-  hipLaunchKernelGGL(rows_fc_kernel, dim3(ceil_div(B, FC_ROWS), ceil_div(Nout, FC_OUT)), dim3(NT), 0, (hipStream_t)stream,
-                     in, ldin, in_scale, in_shift, wt, bias, out, ldout, B, Cin, Nout, act);
+  if (Cin % 32 == 0 && ldin % 4 == 0 && ((uintptr_t)in % 16) == 0 && (!in_scale || (((uintptr_t)in_scale | (uintptr_t)in_shift) % 16) == 0))
+    hipLaunchKernelGGL(rows_fc_mfma_kernel, dim3(ceil_div(B, 32), ceil_div(Nout, 32)), dim3(NT), 0, (hipStream_t)stream,
+                       in, ldin, in_scale, in_shift, wt, bias, out, ldout, B, Cin, Nout, act);
+  else
+    hipLaunchKernelGGL(rows_fc_kernel, dim3(ceil_div(B, FC_ROWS), ceil_div(Nout, FC_OUT)), dim3(NT), 0, (hipStream_t)stream,
+                       in, ldin, in_scale, in_shift, wt, bias, out, ldout, B, Cin, Nout, act);
   SDK_LAUNCH_CHECK();
   return 0;
 }

@@ -103,7 +103,7 @@ inline size_t a256(size_t v) { return (v + 255) & ~(size_t)255; }
 
 struct FwdWs {
   uint16_t *X0, *U, *R, *Z, *Sa, *Sb, *CAT, *H, *AH;
-  float *ctx, *ubias, *logits, *pooled;
+  float *ctx, *ubias, *logits, *pooled, *se;
 };
 
 size_t fwd_layout(const sdk_ecapa_desc* d, int B, int T, char* base, FwdWs* w) {
@@ -123,6 +123,8 @@ size_t fwd_layout(const sdk_ecapa_desc* d, int B, int T, char* base, FwdWs* w) {
   char* ub = take((size_t)B * A * 4);
   char* lg = take(M * Cm * 4);
   char* po = take((size_t)B * 2 * Cm * 4);
+  char* se = take(sdk_se_workspace_bytes(B, (int)C, d->se_channels));
+  if (w) w->se = (float*)se;
   if (w) {
     w->X0 = (uint16_t*)x0; w->U = (uint16_t*)u; w->R = (uint16_t*)r; w->Z = (uint16_t*)z;
     w->Sa = (uint16_t*)sa; w->Sb = (uint16_t*)sb; w->CAT = (uint16_t*)cat; w->H = (uint16_t*)h; w->AH = (uint16_t*)ah;
@@ -214,7 +216,8 @@ extern "C" int sdk_ecapa_forward(sdk_ctx* ctx, const void* wblob, const sdk_ecap
     if (int rc = tdnn(w.R, C, C, 1, 1, base + EL_TDNN2, C, w.Z, C, nullptr, 0, nullptr, 0)) return rc;
     uint16_t* slab = w.CAT + (int64_t)C * (i - 1);
     if (int rc = sdk_se_gate_residual(ctx, w.Z, C, xin, ldx, P32(base + EL_SE_W1T), P32(base + EL_SE_B1), P32(base + EL_SE_W2T),
-                                      P32(base + EL_SE_B2), slab, Cm, B, T, C, d->se_channels, stream)) return rc;
+                                      P32(base + EL_SE_B2), slab, Cm, B, T, C, d->se_channels, w.se, sdk_se_workspace_bytes(B, C, d->se_channels),
+                                      stream)) return rc;
     xin = slab;
     ldx = Cm;
   }

@@ -193,12 +193,13 @@ class Engine:
         check(self.lib.sdk_conv_gemm(self.ctx, C.byref(g), _stream()), "sdk_conv_gemm")
         return Cout, C32, S
 
-    def se_gate_residual(self, z, x, w1t, b1, w2t, b2, B, T):
+    def se_gate_residual(self, z, x, w1t, b1, w2t, b2, B, T, split: bool = True):
         C_ = z.shape[1]
         out = torch.empty_like(z)
+        ws = self._scratch_bytes("se", self.lib.sdk_se_workspace_bytes(B, C_, w1t.shape[1])) if split else None
         check(self.lib.sdk_se_gate_residual(self.ctx, z.data_ptr(), z.stride(0), x.data_ptr(), x.stride(0), w1t.data_ptr(),
                                             b1.data_ptr(), w2t.data_ptr(), b2.data_ptr(), out.data_ptr(), out.stride(0),
-                                            B, T, C_, w1t.shape[1], _stream()), "sdk_se_gate_residual")
+                                            B, T, C_, w1t.shape[1], _ptr(ws), ws.numel() if split else 0, _stream()), "sdk_se_gate_residual")
         return out
 
     def asp_stats(self, h, B, T):

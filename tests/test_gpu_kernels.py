@@ -135,14 +135,17 @@ def test_se_gate_residual(engine):
     w2 = torch.randn(C, Cse, generator=g) / 11
     b1, b2 = torch.randn(Cse, generator=g) * 0.1, torch.randn(C, generator=g) * 0.1
     out = engine.se_gate_residual(dev(z, torch.bfloat16), dev(x, torch.bfloat16), dev(w1.T.contiguous()), dev(b1),
-                                  dev(w2.T.contiguous()), dev(b2), B, T)
+                                  dev(w2.T.contiguous()), dev(b2), B, T, split=True)
+    mono = engine.se_gate_residual(dev(z, torch.bfloat16), dev(x, torch.bfloat16), dev(w1.T.contiguous()), dev(b1),
+                                   dev(w2.T.contiguous()), dev(b2), B, T, split=False)
     mean = z.double().reshape(B, T, C).mean(1)
     h = torch.relu(mean @ w1.double().T + b1)
     gate = torch.sigmoid(h @ w2.double().T + b2).float()
     want = gate[:, None, :] * z.reshape(B, T, C) + x.reshape(B, T, C)
     torch.cuda.synchronize()
     mag = (gate[:, None, :] * z.reshape(B, T, C)).abs() + x.reshape(B, T, C).abs()
-    assert_bf16_close(out, want.reshape(B * T, C), "se_gate_residual", frac_exact=0.995, magnitude=mag.reshape(B * T, C) * 2 ** -9)
+    assert_bf16_close(out, want.reshape(B * T, C), "se_gate_residual (split schedule)", frac_exact=0.995, magnitude=mag.reshape(B * T, C) * 2 ** -9)
+    assert_bf16_close(mono, want.reshape(B * T, C), "se_gate_residual (one kernel per segment)", frac_exact=0.995, magnitude=mag.reshape(B * T, C) * 2 ** -9)
 
 
 def test_asp_stats_and_pool(engine):
@@ -186,7 +189,7 @@ def test_asp_fused_matches_unfused_oracle(engine, B, T):
 
 def test_rows_fc(engine):
     g = torch.Generator().manual_seed(3)
-    for B, Cin, Nout, act in [(7, 6144, 192, 0), (5, 6144, 128, 0), (9, 1000, 70, 1), (1, 33, 200, 2)]:
+    for B, Cin, Nout, act in [(7, 6144, 192, 0), (5, 6144, 128, 0), (9, 1000, 70, 1), (1, 33, 200, 2), (1000, 1024, 128, 1), (77, 128, 1024, 2), (33, 96, 40, 0)]:
         x = torch.randn(B, Cin, generator=g)
         wt = torch.randn(Cin, Nout, generator=g) / Cin ** 0.5
         bias, isc, ish = torch.randn(Nout, generator=g), torch.rand(Cin, generator=g) + 0.5, torch.randn(Cin, generator=g)
