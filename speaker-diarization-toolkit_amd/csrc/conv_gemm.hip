@@ -230,10 +230,18 @@ __global__ __launch_bounds__(NT2, 2) void conv_gemm256_kernel(Params p) {
   const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
   const int wm = wid >> 2, wn = wid & 3;
 
+  // Tile order: every XCD owns a contiguous run of tile ids (xcd_remap); inside the run, tiles are walked in
+  // groups of GM m-tiles with m fastest, so the ~32 workgroups an XCD runs at once form an 8 x 4 block of the
+  // output: 12 distinct operand slices per K-step instead of 16+ and a working set that stays in the 4 MiB L2.
   const int nbn = p.N / BN2;
   const int nbm = (p.M + BM2 - 1) / BM2;
   const int tile = xcd_remap(blockIdx.x, nbn * nbm);
-  const int bn = tile % nbn, bm = tile / nbn;
+  constexpr int GM = 8;
+  const int per_group = GM * nbn;
+  const int grp = tile / per_group, in_grp = tile - grp * per_group;
+  const int gm = min(nbm - grp * GM, GM);
+  const bool rowmajor = (p.tune & 4) != 0;            // A/B knob: plain n-fastest order
+  const int bm = rowmajor ? tile / nbn : grp * GM + in_grp % gm, bn = rowmajor ? tile % nbn : in_grp / gm;
   const int m0 = bm * BM2, n0 = bn * BN2;
 
   // ---- DMA assignment: wave wid fills rows [32 wid, 32 wid + 32) of A and of B, 8 rows per instruction
@@ -297,7 +305,7 @@ __global__ __launch_bounds__(NT2, 2) void conv_gemm256_kernel(Params p) {
   // so the LDS latency of the next tile's first reads and the DMA issue hide under P3's MFMAs, and a
   // DMA always has a whole iteration to land.  The two waves that share a SIMD issue their DMA at
   // different points (before / after P3) so one of them always has MFMAs for the matrix pipe.
-  const int pol = p.tune;   // 0: waves 0-3 early / 4-7 late (default), 1: all early, 2: all late, 3: odd/even
+  const int pol = p.tune & 3;   // 0: waves 0-3 early / 4-7 late (default), 1: all early, 2: all late, 3: odd/even
   const int wu = __builtin_amdgcn_readfirstlane(wid);
   const bool dma_early = pol == 1 ? true : pol == 2 ? false : pol == 3 ? (wu & 1) == 0 : wu < 4;
   bf16x8 b0[4], b1[4], a0[4], a1[4];

@@ -1,0 +1,98 @@
+"""End-to-end through the drop-in boundary on a real GPU: Backend.enroll_speaker / identify_speaker /
+verify_speaker (the EmbeddingBackend contract, speaker_detection_backends/base.py:107-180) and the
+speaker-assign compatible driver, checked against the CPU oracle running the same pipeline."""
+import json
+import os
+
+import numpy as np
+import pytest
+import torch
+
+from conftest import sub
+from oracle import ecapa as oecapa
+from oracle import fbank as ofbank
+from oracle import scoring as oscoring
+
+pytestmark = pytest.mark.gpu
+
+wav = sub("wav")
+W = sub("weights")
+
+
+def _voice(seed, seconds, f0):
+    """Synthetic 'speaker': a harmonic stack with a speaker-specific pitch and formant tilt + noise."""
+    rng = np.random.default_rng(seed)
+    t = np.arange(int(16000 * seconds)) / 16000.0
+    x = sum((0.5 / h ** (1.0 + 0.2 * (seed % 3))) * np.sin(2 * np.pi * f0 * h * t + rng.uniform(0, 6.28)) for h in range(1, 12))
+    x = x * (0.6 + 0.4 * np.sin(2 * np.pi * 3.1 * t)) + rng.normal(0, 0.02, t.shape)
+    return np.clip(np.round(x / np.abs(x).max() * 0.5 * 32767), -32768, 32767).astype(np.int16)
+
+
+def _oracle_embed(pcm_windows):
+    feats = torch.from_numpy(ofbank.fbank(pcm_windows))
+    return oecapa.l2_normalise(oecapa.EcapaOracle(W.synthetic_weights(0), "bf16", torch.float64).embed(feats).numpy())
+
+
+def test_enroll_identify_verify_roundtrip(tmp_path, monkeypatch):
+    monkeypatch.setenv("SPEAKERS_EMBEDDINGS_DIR", str(tmp_path / "store"))
+    be = sub("backend").Backend()
+    voices = {"alice": 140.0, "bob": 95.0, "carol": 210.0}
+    profiles, oracle_vecs = [], {}
+    for i, (sid, f0) in enumerate(voices.items()):
+        path = tmp_path / f"enroll_{sid}.wav"
+        wav.write_wav_s16(path, _voice(10 + i, 6.0, f0))
+        rec = be.enroll_speaker(path, [(0.5, 5.5)])
+        assert rec["external_id"].startswith("npy:") and rec["model_version"].startswith("mi355x-ecapa1024-")
+        assert os.path.exists(rec["file"]) and rec["n_windows"] == 4
+        profiles.append({"id": sid, "names": {"default": sid.title()}, "embeddings": {"mi355x": [
+            {"id": f"emb-{sid}", "external_id": rec["external_id"], "model_version": rec["model_version"], "trust_level": "high"}]}})
+        # oracle enrollment on the same windows
+        pcm, _ = wav.cut_windows(wav.read_wav_s16(path), [(0.5, 5.5)])
+        e = _oracle_embed(pcm).astype(np.float64).mean(0)
+        oracle_vecs[sid] = (e / np.linalg.norm(e)).astype(np.float32)
+        stored = np.load(rec["file"])
+        assert float(stored @ oracle_vecs[sid]) > 1 - 1e-4, "stored enrollment vector vs oracle"
+
+    # test recording: bob for 4 s, then alice for 4 s (different noise seeds than enrollment)
+    test = np.concatenate([_voice(40, 4.0, 95.0), _voice(41, 4.0, 140.0)])
+    tpath = tmp_path / "meeting.wav"
+    wav.write_wav_s16(tpath, test)
+    rows = be.identify_speaker(tpath, profiles, threshold=0.354)
+    assert {r["speaker_id"] for r in rows} >= {"alice", "bob"}
+    assert all(set(r) >= {"speaker_id", "similarity", "confidence", "embedding_id", "segment"} for r in rows)
+
+    # oracle: same windows, same profiles, same aggregation
+    pcm, spans = wav.cut_windows(wav.read_wav_s16(tpath), None)
+    Eo = _oracle_embed(pcm)
+    Pm = oecapa.l2_normalise(np.stack([np.load(str(tmp_path / "store/embeddings/by-hash" / (p["embeddings"]["mi355x"][0]["external_id"][4:] + ".npy")))
+                                       for p in profiles]))
+    oidx, osc = oscoring.affinity_topk(Eo, Pm, 1)
+    # GPU per-window assignments (recomputed through the same public pieces)
+    E, Eb, re = be.embed_windows(pcm)
+    batch = sub("store").load_profile_batch(profiles, "mi355x", model_prefix="mi355x-")
+    gidx, gsc = be.score_windows(E, Eb, re, batch)
+    cos = (E.cpu().numpy().astype(np.float64) * Eo).sum(1)
+    assert (cos > 1 - 1e-4).all(), cos
+    margin = np.sort(oscoring.affinity(Eo, Pm), axis=1)
+    clear = (margin[:, -1] - margin[:, -2]) > 1e-3          # windows whose oracle decision is not a near-tie
+    assert np.array_equal(gidx[clear, 0], oidx[clear, 0]), (gidx[:, 0], oidx[:, 0])
+    assert np.abs(gsc[:, 0] - osc[:, 0])[clear].max() < 5e-4   # end-to-end (embedding + score) tolerance; score-only is 1e-5
+
+    ok = be.verify_speaker(tpath, profiles[0], threshold=0.354)
+    assert ok["match"] is True and ok["confidence"] == ok["similarity"] and ok["embedding_id"] == "emb-alice"
+    assert be.verify_speaker(tpath, profiles[2], threshold=0.99) == {"match": False, "similarity": 0.0, "confidence": 0.0, "embedding_id": None}
+
+    # speaker-assign compatible driver on top (in-process rows instead of a subprocess per label)
+    db = tmp_path / "store" / "db"
+    db.mkdir(parents=True, exist_ok=True)
+    for p in profiles:
+        (db / f"{p['id']}.json").write_text(json.dumps(p))
+    transcript = tmp_path / "t.json"
+    transcript.write_text(json.dumps({"results": [
+        {"type": "word", "start_time": 0.2, "end_time": 3.8, "alternatives": [{"content": "hello", "speaker": "S1"}]},
+        {"type": "word", "start_time": 4.2, "end_time": 7.8, "alternatives": [{"content": "there", "speaker": "S2"}]}]}))
+    asg, ident = sub("assign"), sub("identify")
+    rows_fn = ident.make_rows_fn(tpath, per_label=True, backend=be)
+    out = asg.assign_recording(tpath, transcript, rows_fn=rows_fn, use_embeddings=True, threshold=0.1)
+    assert out["mappings"]["S1"]["speaker_id"] == "bob" and out["mappings"]["S2"]["speaker_id"] == "alice", out["mappings"]
+    assert out["mappings"]["S1"]["signals"][0]["trust_level"] == "high" and out["mappings"]["S1"]["signals"][0]["backend"] == "mi355x"

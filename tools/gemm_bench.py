@@ -26,7 +26,7 @@ for name, M, N, Cin, taps, dil, T in shapes:
             eng.profile_begin()
             for _ in range(5):
                 eng.conv_gemm(A, W, N, Cin, taps=taps, dil=dil, T=T, bias=bias, scale=bias, shift=bias, relu=True)
-            p = eng.profile_end()["conv_gemm"]
+            pe = eng.profile_end(); p = pe.get("conv_gemm256") or pe["conv_gemm"]
             res.setdefault(v, []).append(p["ms"] / 5)
     fl = 2.0 * M * N * taps * Cin
     print(name, {v: f"{min(t):.3f} ms {fl / min(t) / 1e9:.0f} TF" for v, t in res.items()}, flush=True)
