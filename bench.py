@@ -103,7 +103,8 @@ def main() -> int:
         return 2
     torch.cuda.set_device(local)
     dist = None
-    if world > 1:
+    use_dist = world > 1 or ("RANK" in os.environ and "MASTER_PORT" in os.environ)   # launched by torch.distributed.run
+    if use_dist:
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         dist.init_process_group(backend="nccl", device_id=torch.device("cuda", local))
@@ -120,14 +121,14 @@ def main() -> int:
     P_host = unit_rows(args.profiles, 192, seed=1)
     Pn, Pb, rp = eng.l2norm(torch.from_numpy(P_host).to(dev))
     rpm = rp.max().reshape(1)
-    gathered = torch.empty((world * B, 192), dtype=torch.float32, device=dev) if world > 1 else None
+    gathered = torch.empty((world * B, 192), dtype=torch.float32, device=dev) if use_dist else None
     eng.desc                                   # upload weights before timing
 
     def step():
         E, Eb, re = eng.embed_pcm(pcm)
         idx, sc = eng.affinity_topk(E, Eb, re, Pn, Pb, rpm, k=1)
-        if world > 1:
-            dist.all_gather_into_tensor(gathered, E)
+        if use_dist:
+            dist.all_gather_into_tensor(gathered, E)          # k5: the embedding exchange (RCCL over xGMI)
         return idx, sc
 
     for _ in range(args.warmup):
@@ -135,7 +136,7 @@ def main() -> int:
 
     def fence():
         torch.cuda.synchronize()
-        if world > 1:
+        if use_dist:
             dist.barrier()
         torch.cuda.synchronize()
 
@@ -145,7 +146,7 @@ def main() -> int:
         step()
     fence()
     elapsed = time.perf_counter() - t0
-    if world > 1:
+    if use_dist:
         tt = torch.tensor([elapsed], dtype=torch.float64, device=dev)
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         elapsed = float(tt.item())
@@ -169,8 +170,17 @@ def main() -> int:
                        "gbps": round(v["bytes"] / (v["ms"] * 1e-3) / 1e9, 1) if v["bytes"] else None}
                    for k, v in prof.items()}
         step_dev_ms = sum(v["ms"] for v in prof.values())
+        traffic = None
+        pmc_files = sorted((ROOT / "profiles").glob("*pmc_bench.json"))
+        if pmc_files:      # HBM-side bytes per launch from a separate rocprofv3 --pmc pass (tools/pmc_bench.sh), gfx950-corrected
+            try:
+                pm = json.loads(pmc_files[-1].read_text())["conv_gemm256_kernel"]
+                traffic = round((2.0 * pm["FETCH_SIZE_KB"] + pm["WRITE_SIZE_KB"]) * 1024.0 / pm["launches"], 1)
+            except Exception:  # noqa: BLE001
+                traffic = None
         roofline = {"kernel": "conv_gemm256_kernel", "bound": "mfma", "achieved": round(achieved / 1e12, 2), "peak": PEAK_BF16_MFMA / 1e12,
-                    "unit": "TFLOP/s", "frac": round(achieved / PEAK_BF16_MFMA, 4), "traffic": None,
+                    "unit": "TFLOP/s", "frac": round(achieved / PEAK_BF16_MFMA, 4), "traffic": traffic,
+                    "traffic_note": "bytes leaving L2 per launch (FETCH_SIZE x2 + WRITE_SIZE, Infinity-Cache hits included), separate --pmc pass" if traffic else None,
                     "launches_per_step": big["launches"], "avg_launch_ms": round(big["ms"] / big["launches"], 4),
                     "algorithmic_flops_per_step": big_alg_flops, "share_of_step_device_time": round(big["ms"] / step_dev_ms, 3),
                     "executed_tflops": round(big["flops"] / (big["ms"] * 1e-3) / 1e12, 2)}
@@ -232,7 +242,7 @@ def main() -> int:
             "config": {"workload": "config #2: 1k synthetic 2-s segments/GPU -> fbank -> ECAPA-TDNN C=1024 -> L2 -> cosine argmax vs 100 profiles",
                        "segments_per_gpu": B, "profiles": args.profiles, "embed_dim": 192, "frames_per_segment": T_FRAMES,
                        "weights": "random-init seed 0 (20.77 M params)", "parallelism": f"segments sharded x{world}, profiles replicated"
-                       + (", RCCL all-gather of embeddings per step" if world > 1 else "")},
+                       + (", RCCL all-gather of embeddings per step" if use_dist else "")},
             "affinity_pairs_per_sec": aff["pairs_per_sec"] if aff else None,
             "roofline": roofline, "roofline_forward_mfma": fwd_mfma, "roofline_forward_hbm_model": fwd_hbm, "affinity": aff,
             "affinity_cluster": clus,
@@ -244,7 +254,7 @@ def main() -> int:
             out["cpu_baseline"] = cpu_baseline(pcm_host, P_host)
         print(json.dumps(out), flush=True)
 
-    if world > 1:
+    if use_dist:
         dist.barrier()
         dist.destroy_process_group()
     return 0

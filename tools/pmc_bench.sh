@@ -1,0 +1,26 @@
+#!/bin/bash
+# HBM-side traffic of the bench step per kernel: separate --pmc passes (FETCH_SIZE and WRITE_SIZE do not fit one pass)
+cd "${GRAFT_REPO_ROOT:-/root/repo}"; mkdir -p gpurun_out/pmcb; export TMPDIR=/tmp
+for c in FETCH_SIZE WRITE_SIZE; do
+  timeout -k 10 400 rocprofv3 --kernel-trace --pmc $c --output-format csv -d gpurun_out/pmcb/$c -o b -- python3 bench.py --steps 1 --warmup 1 --no-cpu-baseline --no-affinity-config3 > gpurun_out/pmcb/$c.log 2>&1 || { tail -5 gpurun_out/pmcb/$c.log; exit 1; }
+done
+python3 - <<'PY'
+import csv, glob, json, collections
+out = collections.defaultdict(lambda: collections.defaultdict(float))
+for c in ("FETCH_SIZE", "WRITE_SIZE"):
+    f = glob.glob(f"gpurun_out/pmcb/{c}/*counter_collection.csv")[0]
+    rows = list(csv.DictReader(open(f)))
+    per_kernel = collections.defaultdict(list)
+    for r in rows:
+        if r["Counter_Name"] != c: continue
+        name = r["Kernel_Name"].split("(")[1].split("::")[-1] if "anonymous" in r["Kernel_Name"] else r["Kernel_Name"].split("(")[0]
+        name = r["Kernel_Name"].replace("(anonymous namespace)::", "").split("(")[0].split("<")[0]
+        per_kernel[name].append(float(r["Counter_Value"]))
+    for k, v in per_kernel.items():
+        n = len(v) // 3          # bench ran warmup + timed + profiled step = 3 identical steps
+        last = v[-n:] if n else v
+        out[k][c + "_KB"] = sum(last)
+        out[k]["launches"] = len(last)
+json.dump(out, open("gpurun_out/pmcb/pmc_bench.json", "w"), indent=1)
+for k, v in out.items(): print(k, dict(v))
+PY
