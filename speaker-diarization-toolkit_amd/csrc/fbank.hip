@@ -7,7 +7,8 @@
 //
 // Kernel A (fbank_tile_kernel): one workgroup = 32 frames of one segment, 7 waves.  The windowed
 // real DFT is a [32 x 400] x [400 x 2*224] product on the exact-fp32 matrix pipe
-// (v_mfma_f32_32x32x2_f32): wave w owns frequency bins 32w..32w+31 and keeps the cos and sin
+// (v_mfma_f32_32x32x2_f32; K folded 400 -> 201 by the real-input/symmetric-window identity):
+// wave w owns frequency bins 32w..32w+31 and keeps the cos and sin
 // accumulators of those bins in the SAME lane/register positions, so |X|^2 is formed in registers.
 //   A operand: raw samples from an LDS image skewed by one word per hop (row stride 161 words:
 //              the 32 frames of a wave-instruction hit 32 different banks instead of one).
@@ -26,7 +27,8 @@ namespace {
 constexpr int NFFT = 400, HOP = 160, NMEL = 80, NBIN = 201;
 constexpr int FT = 32;                  // frames per tile
 constexpr int NW = 7;                   // waves per workgroup = bin blocks of 32 (224 >= 201)
-constexpr int KG = NFFT / 2 / 4;        // 50 groups of 4 MFMA k-steps (2 samples each)
+constexpr int NSYM = 208;                // folded sample index n = 0..200 (x[n] +- x[400-n]), padded to a multiple of 8
+constexpr int KG = NSYM / 2 / 4;        // 26 groups of 4 MFMA k-steps (2 folded samples each)
 constexpr int TILE_SAMPLES = (FT - 1) * HOP + NFFT;   // 5360
 constexpr int XS_WORDS = TILE_SAMPLES + TILE_SAMPLES / HOP + 1;
 constexpr int PW_STRIDE = NW * 32 + 1;  // 225
@@ -64,6 +66,11 @@ __global__ __launch_bounds__(NW * 64) void fbank_tile_kernel(const int16_t* __re
 #pragma unroll
   for (int r = 0; r < 16; ++r) { are[r] = 0.f; aim[r] = 0.f; }
 
+  // The frame is real and the periodic Hamming window is symmetric (w[n] = w[400-n]), so
+  //   Re X[f] =  sum_{n=0..200} c_n w[n] (x[n] + x[400-n]) cos(2 pi f n / 400),  c_0 = c_200 = 1/2
+  //   Im X[f] = -sum_{n=1..199}     w[n] (x[n] - x[400-n]) sin(2 pi f n / 400)
+  // (index 400-n taken mod 400): K shrinks from 400 to 201 - half the MFMAs - for one extra LDS read and
+  // one add/sub per A value.  The constants c_n and the window live in the packed tables.
   const int fi = lane & 31, kk = lane >> 5;
   const int arow = fi * (HOP + 1);
   const f32x4* bre = reinterpret_cast<const f32x4*>(&tab->dft[w][0][0][lane][0]);
@@ -77,10 +84,13 @@ __global__ __launch_bounds__(NW * 64) void fbank_tile_kernel(const int16_t* __re
     }
 #pragma unroll
     for (int u = 0; u < 4; ++u) {
-      const int n = (g * 4 + u) * 2 + kk;
-      const float a = xs[arow + n + (n >= HOP) + (n >= 2 * HOP)];
-      are = __builtin_amdgcn_mfma_f32_32x32x2f32(a, cre[u], are, 0, 0, 0);
-      aim = __builtin_amdgcn_mfma_f32_32x32x2f32(a, cim[u], aim, 0, 0, 0);
+      int n = (g * 4 + u) * 2 + kk;
+      n = n <= NFFT / 2 ? n : NFFT / 2;                       // padded k (201..207): table rows are zero
+      const int m = n == 0 ? 0 : NFFT - n;                    // mirror sample, (400 - n) mod 400
+      const float xa = xs[arow + n + (n >= HOP)];             // n <= 200 < 2*HOP
+      const float xb = xs[arow + m + (m >= HOP) + (m >= 2 * HOP)];
+      are = __builtin_amdgcn_mfma_f32_32x32x2f32(xa + xb, cre[u], are, 0, 0, 0);
+      aim = __builtin_amdgcn_mfma_f32_32x32x2f32(xa - xb, cim[u], aim, 0, 0, 0);
     }
     cre = nre;
     cim = nim;
@@ -159,10 +169,11 @@ extern "C" int sdk_fbank_tables_fill(void* host_dst, size_t bytes) {
         for (int u = 0; u < 4; ++u) {
           const int n = (g * 4 + u) * 2 + (l >> 5);
           const int f = w * 32 + (l & 31);
-          if (f >= NBIN) continue;
+          if (f >= NBIN || n > NFFT / 2) continue;
           const double win = 0.54 - 0.46 * cos(2.0 * PI * n / NFFT);
           const double ang = 2.0 * PI * (double)((n * f) % NFFT) / NFFT;
-          t->dft[w][0][g][l][u] = (float)(win * cos(ang));
+          const double half = (n == 0 || n == NFFT / 2) ? 0.5 : 1.0;   // these samples are their own mirror
+          t->dft[w][0][g][l][u] = (float)(half * win * cos(ang));
           t->dft[w][1][g][l][u] = (float)(-win * sin(ang));
         }
   // HTK-mel triangular filters, 0..8000 Hz, unit peak (oracle/fbank.py: mel_matrix)
@@ -212,7 +223,7 @@ extern "C" int sdk_fbank(sdk_ctx* ctx, const int16_t* pcm, int B, int S, const v
   const int tps = ceil_div(T, FT);
   SDK_REQUIRE((int64_t)B * tps < (1ll << 31), "sdk_fbank: batch too large for one launch");
   {
-  ProfScope ps(ctx, stream, SDK_K_FBANK_TILE, 2.0 * B * T * (double)NFFT * 2 * NBIN + 2.0 * B * T * NBIN * NMEL, 2.0 * B * S + 4.0 * B * T * NMEL);
+  ProfScope ps(ctx, stream, SDK_K_FBANK_TILE, 2.0 * B * T * (double)NSYM * 2 * (NW * 32) + 2.0 * B * T * NBIN * NMEL, 2.0 * B * S + 4.0 * B * T * NMEL);
   hipLaunchKernelGGL(fbank_tile_kernel, dim3(B * tps), dim3(NW * 64), 0, (hipStream_t)stream, pcm, S, T, tps,
                      (const FbankTables*)tabs, (float*)ws);
   }

@@ -40,9 +40,12 @@ def test_host_only_entry_points_work_without_gpu():
     n = lib.sdk_fbank_tables_bytes()
     buf = np.zeros(n, dtype=np.uint8)
     assert lib.sdk_fbank_tables_fill(buf.ctypes.data, n) == 0
-    tab = buf[:7 * 2 * 50 * 64 * 4 * 4].view(np.float32).reshape(7, 2, 50, 64, 4)
-    # DFT table entry (wave 0, cos, group 0, lane 0, step 0): n = 0, f = 0 -> window(0) * cos(0) = 0.08
-    assert abs(tab[0, 0, 0, 0, 0] - 0.08) < 1e-7
+    tab = buf[:7 * 2 * 26 * 64 * 4 * 4].view(np.float32).reshape(7, 2, 26, 64, 4)
+    # folded DFT table (n = 0..200): entry (wave 0, cos, group 0, lane 0, step 0) is n = 0, f = 0 ->
+    # 1/2 * window(0) * cos(0) = 0.04 (samples 0 and 200 are their own mirror); sin rows of n = 0 are zero
+    assert abs(tab[0, 0, 0, 0, 0] - 0.04) < 1e-7 and tab[0, 1, 0, 0, 0] == 0
+    # lane 32 (k-half 1) of step 0 is n = 1: window(1) * cos(2 pi f / 400) at f = 0
+    assert abs(tab[0, 0, 0, 32, 0] - (0.54 - 0.46 * np.cos(2 * np.pi / 400))) < 1e-7
     # mel table must equal the oracle's filterbank
     from oracle import fbank as ofb
     ints = buf[tab.nbytes:tab.nbytes + 3 * 80 * 4].view(np.int32).reshape(3, 80)
