@@ -96,3 +96,21 @@ def test_enroll_identify_verify_roundtrip(tmp_path, monkeypatch):
     out = asg.assign_recording(tpath, transcript, rows_fn=rows_fn, use_embeddings=True, threshold=0.1)
     assert out["mappings"]["S1"]["speaker_id"] == "bob" and out["mappings"]["S2"]["speaker_id"] == "alice", out["mappings"]
     assert out["mappings"]["S1"]["signals"][0]["trust_level"] == "high" and out["mappings"]["S1"]["signals"][0]["backend"] == "mi355x"
+
+
+def test_pipeline_run_shard_single_rank(engine):
+    """configs #2 + #5 glued: embed -> assign vs profiles -> cluster the same segments; every stage vs the oracle."""
+    from oracle import spectral as ospec
+    P = sub("pipeline")
+    # 3 synthetic 'speakers' x 8 two-second windows each
+    pcm = np.stack([_voice(100 + s * 17 + i, 2.0, f0)[:32000] for s, f0 in enumerate((95.0, 150.0, 220.0)) for i in range(8)])
+    rng = np.random.default_rng(5)
+    profiles = oecapa.l2_normalise(rng.standard_normal((7, 192)).astype(np.float32))
+    res = P.run_shard(engine, torch.from_numpy(pcm).cuda(), torch.from_numpy(profiles).cuda(), k=1, threshold=-1.0, n_clusters=3, cluster_iters=20)
+    Eo = _oracle_embed(pcm)
+    Eg = res.embeddings.cpu().numpy()
+    assert ((Eg.astype(np.float64) * Eo).sum(1) > 1 - 1e-4).all()
+    oidx, osc = oscoring.affinity_topk(Eg, profiles, 1)
+    assert np.array_equal(res.best_profile, oidx) and np.abs(res.best_score - osc).max() <= 1e-5
+    olab, _ = ospec.spectral_cluster(oecapa.to_bf16_f32(Eg), 3, n_iter=20, n_kmeans=20)
+    assert np.array_equal(res.cluster_labels, olab)
