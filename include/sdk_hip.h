@@ -102,8 +102,18 @@ typedef struct sdk_conv_gemm_args {
   uint16_t* S;        int64_t lds;
   int M, N, Cin, taps, dil, T;
   uint32_t flags;
+  /* optional fused per-segment column statistics of the stored output (SE squeeze means, ASP global
+   * context): stats_mode 1 = sum, 2 = sum and sum of squares; stats_part = scratch of
+   * sdk_conv_gemm_stats_bytes(); finish with sdk_colstats_finish().  Only where
+   * sdk_conv_gemm_stats_fusable(M, N, T) is true. */
+  int32_t stats_mode;
+  float* stats_part;
 } sdk_conv_gemm_args;
 int sdk_conv_gemm(sdk_ctx* ctx, const sdk_conv_gemm_args* a, void* stream);
+size_t sdk_conv_gemm_stats_bytes(int M, int N, int mode);
+int sdk_conv_gemm_stats_fusable(int M, int N, int T);
+/* out: mode 1 -> [B, N] per-segment column means; mode 2 -> [B, 2N] mean | sqrt(max(var, 1e-12)) */
+int sdk_colstats_finish(sdk_ctx* ctx, const float* stats_part, int M, int N, int T, int mode, float* out, void* stream);
 /* Tuning knob (A/B measurements): 1 = 128x128 register-staged tile, 2 = 256x256 LDS-DMA tile where
  * the shape allows it (default; also settable once via $SDK_GEMM_VARIANT). */
 int sdk_set_gemm_variant(int variant);
@@ -118,6 +128,7 @@ size_t sdk_se_workspace_bytes(int B, int C, int Cse);   /* fp32 [B,C] means + [B
 int sdk_se_gate_residual(sdk_ctx* ctx, const uint16_t* z, int64_t ldz, const uint16_t* x, int64_t ldx,
                          const float* w1t, const float* b1, const float* w2t, const float* b2,
                          uint16_t* out, int64_t ldo, int B, int T, int C, int Cse,
+                         const float* mean_in,      /* optional [B, C] squeeze means already computed (fused GEMM epilogue) */
                          void* ws, size_t ws_bytes, void* stream);   /* ws may be NULL: one-kernel-per-segment form */
 
 /* Attentive statistics pooling pieces.

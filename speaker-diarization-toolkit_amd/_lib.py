@@ -34,7 +34,7 @@ class ConvGemmArgs(C.Structure):
                 ("ubias", C.c_void_p), ("ldub", C.c_int64),
                 ("X2", C.c_void_p), ("ldx2", C.c_int64), ("S", C.c_void_p), ("lds", C.c_int64),
                 ("M", C.c_int), ("N", C.c_int), ("Cin", C.c_int), ("taps", C.c_int), ("dil", C.c_int),
-                ("T", C.c_int), ("flags", C.c_uint32)]
+                ("T", C.c_int), ("flags", C.c_uint32), ("stats_mode", C.c_int32), ("stats_part", C.c_void_p)]
 
 
 class EcapaDesc(C.Structure):
@@ -71,8 +71,11 @@ SIGNATURES = {
     "sdk_fbank": (_i, [_vp, _vp, _i, _i, _vp, _vp, _i, _vp, _sz, _vp]),
     "sdk_conv_gemm": (_i, [_vp, C.POINTER(ConvGemmArgs), _vp]),
     "sdk_set_gemm_variant": (_i, [_i]),
+    "sdk_conv_gemm_stats_bytes": (_sz, [_i, _i, _i]),
+    "sdk_conv_gemm_stats_fusable": (_i, [_i, _i, _i]),
+    "sdk_colstats_finish": (_i, [_vp, _vp, _i, _i, _i, _i, _vp, _vp]),
     "sdk_se_workspace_bytes": (_sz, [_i, _i, _i]),
-    "sdk_se_gate_residual": (_i, [_vp, _vp, _i64, _vp, _i64, _vp, _vp, _vp, _vp, _vp, _i64, _i, _i, _i, _i, _vp, _sz, _vp]),
+    "sdk_se_gate_residual": (_i, [_vp, _vp, _i64, _vp, _i64, _vp, _vp, _vp, _vp, _vp, _i64, _i, _i, _i, _i, _vp, _vp, _sz, _vp]),
     "sdk_asp_stats": (_i, [_vp, _vp, _i64, _i, _i, _i, _vp, _vp]),
     "sdk_rows_fc": (_i, [_vp, _vp, _i64, _vp, _vp, _vp, _vp, _vp, _i64, _i, _i, _i, _i, _vp]),
     "sdk_asp_pool": (_i, [_vp, _vp, _i64, _vp, _i64, _i, _i, _i, _vp, _vp]),

@@ -36,6 +36,7 @@ struct Params {
   int M, N, Cin, taps, dil, T;
   uint32_t flags;
   int tune;
+  float* stats_part; int stats_mode;   // fused per-segment column statistics (256^2 kernel only)
 };
 
 __global__ __launch_bounds__(NT, 2) void conv_gemm_kernel(Params p) {
@@ -372,6 +373,11 @@ __global__ __launch_bounds__(NT2, 2) void conv_gemm256_kernel(Params p) {
   // epilogue math in fp32, one 16-byte bf16 store (and two 16-byte fp32 stores for C32).
   float* ct32 = reinterpret_cast<float*>(smem);
   const bool relu = p.flags & SDK_GEMM_RELU, tnh = p.flags & SDK_GEMM_TANH;
+  // fused per-segment column statistics of the STORED (bf16-rounded) output: thread = (column, row half);
+  // a 256-row tile overlaps at most 3 segments (T >= 128), told apart by the tile-local row bounds b1, b2
+  const bool stats = p.stats_part != nullptr;
+  const int sb1 = (m0 / p.T + 1) * p.T - m0, sb2 = sb1 + p.T;
+  float ss0 = 0.f, ss1 = 0.f, ss2 = 0.f, sq0 = 0.f, sq1 = 0.f, sq2 = 0.f;
 #pragma unroll
   for (int q = 0; q < 4; ++q) {
     if (wm == (q >> 1)) {
@@ -428,6 +434,12 @@ __global__ __launch_bounds__(NT2, 2) void conv_gemm256_kernel(Params p) {
         }
         const u32x4 packed = pack8(v);
         if (p.C) *reinterpret_cast<u32x4*>(p.C + (int64_t)m * p.ldc + col) = packed;
+        if (stats) {                                           // leave the rounded values in LDS for the column pass
+          float fr8[8];
+          unpack8(packed, fr8);
+          *reinterpret_cast<f32x4*>(ct32 + lrow * CT2_F32 + cc * 8) = f32x4{fr8[0], fr8[1], fr8[2], fr8[3]};
+          *reinterpret_cast<f32x4*>(ct32 + lrow * CT2_F32 + cc * 8 + 4) = f32x4{fr8[4], fr8[5], fr8[6], fr8[7]};
+        }
         if (p.S) {
           const u32x4 x = *reinterpret_cast<const u32x4*>(p.X2 + (int64_t)m * p.ldx2 + col);
           float fv[8], fx[8];
@@ -440,12 +452,90 @@ __global__ __launch_bounds__(NT2, 2) void conv_gemm256_kernel(Params p) {
       }
     }
     __syncthreads();
+    if (stats) {
+      const int c = tid & 255, hsel = tid >> 8;               // 4 waves per row half
+      const int rlim = min(64, p.M - m0 - q * 64);
+      const int lo = hsel * 32, hi = min(lo + 32, rlim);
+      const float* colp = ct32 + c;
+      // three branch-free runs (one per overlapped segment) so the LDS reads pipeline
+      auto run = [&](int a, int b, float& s1, float& s2) {
+        a = max(a, lo); b = min(b, hi);
+        float t1 = 0.f, t2 = 0.f;
+#pragma unroll 8
+        for (int lr = a; lr < b; ++lr) {
+          const float v = colp[lr * CT2_F32];
+          t1 += v;
+          t2 = fmaf(v, v, t2);
+        }
+        s1 += t1; s2 += t2;
+      };
+      run(0, sb1 - q * 64, ss0, sq0);
+      run(sb1 - q * 64, sb2 - q * 64, ss1, sq1);
+      run(sb2 - q * 64, 64, ss2, sq2);
+      __syncthreads();
+    }
+  }
+  if (stats) {
+    const int c = tid & 255, hsel = tid >> 8;
+    const int64_t nbm_ = (p.M + BM2 - 1) / BM2;
+    float* dst = p.stats_part + ((int64_t)(bm * 2 + hsel) * 3) * p.N + n0 + c;
+    dst[0] = ss0; dst[p.N] = ss1; dst[2 * (int64_t)p.N] = ss2;
+    if (p.stats_mode == 2) {
+      float* dq = dst + nbm_ * 6 * p.N;
+      dq[0] = sq0; dq[p.N] = sq1; dq[2 * (int64_t)p.N] = sq2;
+    }
+  }
+}
+
+// Combine the per-tile partials of a segment in tile order: mean (mode 1) or mean | std (mode 2).
+__global__ __launch_bounds__(256) void colstats_finish_kernel(const float* __restrict__ part, int M, int N, int T, int mode,
+                                                             float* __restrict__ out) {
+  const int b = blockIdx.x, n = blockIdx.y * 256 + threadIdx.x;
+  if (n >= N) return;
+  const int64_t nbm = (M + BM2 - 1) / BM2;
+  const int r_lo = b * T, r_hi = (b + 1) * T - 1;
+  float s = 0.f, q = 0.f;
+  for (int t = r_lo / BM2; t <= r_hi / BM2; ++t) {
+    const int slot = b - (t * BM2) / T;
+    const float* ps = part + ((int64_t)(t * 2) * 3 + slot) * N + n;
+    s += ps[0];
+    s += ps[3 * (int64_t)N];
+    if (mode == 2) {
+      const float* pq = ps + nbm * 6 * N;
+      q += pq[0];
+      q += pq[3 * (int64_t)N];
+    }
+  }
+  const float invT = 1.0f / (float)T;
+  const float mean = s * invT;
+  if (mode == 1) {
+    out[(int64_t)b * N + n] = mean;
+  } else {
+    out[(int64_t)b * 2 * N + n] = mean;
+    out[(int64_t)b * 2 * N + N + n] = sqrtf(fmaxf(q * invT - mean * mean, 1e-12f));
   }
 }
 
 int g_gemm_variant = -1;   // -1: read SDK_GEMM_VARIANT once; 1 = force the 128^2 kernel, 2 = prefer 256^2
 
 }  // namespace
+
+extern "C" size_t sdk_conv_gemm_stats_bytes(int M, int N, int mode) {
+  if (M <= 0 || N <= 0 || mode < 1 || mode > 2) return 0;
+  return (size_t)((M + BM2 - 1) / BM2) * 6 * (size_t)N * sizeof(float) * (size_t)mode;
+}
+
+extern "C" int sdk_conv_gemm_stats_fusable(int M, int N, int T) {
+  return ((g_gemm_variant < 0 ? 2 : g_gemm_variant) & 15) != 1 && N % BN2 == 0 && M >= BM2 && T >= 128;
+}
+
+extern "C" int sdk_colstats_finish(sdk_ctx* ctx, const float* stats_part, int M, int N, int T, int mode, float* out, void* stream) {
+  SDK_REQUIRE(ctx && stats_part && out, "sdk_colstats_finish: null argument");
+  SDK_REQUIRE(M > 0 && T > 0 && M % T == 0 && (mode == 1 || mode == 2), "sdk_colstats_finish: bad shape");
+  hipLaunchKernelGGL(colstats_finish_kernel, dim3(M / T, ceil_div(N, 256)), dim3(256), 0, (hipStream_t)stream, stats_part, M, N, T, mode, out);
+  SDK_LAUNCH_CHECK();
+  return 0;
+}
 
 extern "C" int sdk_set_gemm_variant(int v) {   // tuning knob: 1 = 128^2 register-staged, 2 = 256^2 LDS-DMA (default)
   if (g_gemm_variant < 0)
@@ -482,12 +572,18 @@ extern "C" int sdk_conv_gemm(sdk_ctx* ctx, const sdk_conv_gemm_args* a, void* st
   p.X2 = (const bf16_t*)a->X2; p.ldx2 = a->ldx2; p.S = (bf16_t*)a->S; p.lds = a->lds;
   p.M = a->M; p.N = a->N; p.Cin = a->Cin; p.taps = a->taps; p.dil = a->dil; p.T = a->T; p.flags = a->flags;
   p.tune = g_gemm_variant / 16;
+  p.stats_part = nullptr; p.stats_mode = 0;
 
   const double kk = (double)a->taps * a->Cin;
   const bool use256 = (g_gemm_variant & 15) != 1 && a->N % BN2 == 0 && a->M >= BM2;
   ProfScope ps(ctx, stream, use256 ? SDK_K_CONV_GEMM256 : SDK_K_CONV_GEMM, 2.0 * a->M * a->N * kk,
                2.0 * a->M * a->Cin + 2.0 * a->N * kk + (a->C ? 2.0 : 0.0) * a->M * a->N + (a->C32 ? 4.0 : 0.0) * a->M * a->N +
                    (a->S ? 4.0 : 0.0) * a->M * a->N);
+  if (a->stats_mode) {
+    SDK_REQUIRE(a->stats_mode == 1 || a->stats_mode == 2, "sdk_conv_gemm: stats_mode=%d", a->stats_mode);
+    SDK_REQUIRE(use256 && a->T >= 128 && a->stats_part && a->C, "sdk_conv_gemm: fused column statistics need the 256^2 kernel (N %% 256 == 0, M >= 256), T >= 128 and a bf16 output");
+    p.stats_part = a->stats_part; p.stats_mode = a->stats_mode;
+  }
   if (use256) {
     hipLaunchKernelGGL(conv_gemm256_kernel, dim3((a->N / BN2) * ceil_div(a->M, BM2)), dim3(NT2), LDS2, (hipStream_t)stream, p);
   } else {

@@ -521,8 +521,8 @@ extern "C" size_t sdk_se_workspace_bytes(int B, int C, int Cse) {
 
 extern "C" int sdk_se_gate_residual(sdk_ctx* ctx, const uint16_t* z, int64_t ldz, const uint16_t* x, int64_t ldx,
                                     const float* w1t, const float* b1, const float* w2t, const float* b2,
-                                    uint16_t* out, int64_t ldo, int B, int T, int C, int Cse, void* ws, size_t ws_bytes,
-                                    void* stream) {
+                                    uint16_t* out, int64_t ldo, int B, int T, int C, int Cse, const float* mean_in,
+                                    void* ws, size_t ws_bytes, void* stream) {
   SDK_REQUIRE(ctx && z && x && w1t && b1 && w2t && b2 && out, "sdk_se_gate_residual: null argument");
   SDK_REQUIRE(B > 0 && T > 0, "sdk_se_gate_residual: empty batch");
   SDK_REQUIRE(C % 8 == 0 && C / 8 <= NT && NT % (C / 8) == 0, "sdk_se_gate_residual: C=%d unsupported (need C/8 | 256)", C);
@@ -534,7 +534,9 @@ extern "C" int sdk_se_gate_residual(sdk_ctx* ctx, const uint16_t* z, int64_t ldz
     float* mean = (float*)ws;
     float* hid = mean + (size_t)B * C;
     float* gate = hid + (size_t)B * Cse;
-    {
+    if (mean_in) {
+      mean = const_cast<float*>(mean_in);                   // squeeze already produced by the GEMM epilogue
+    } else {
       ProfScope ps(ctx, stream, SDK_K_SE_GATE, 1.0 * B * T * C, 2.0 * B * T * C);
       hipLaunchKernelGGL(seg_mean_kernel, dim3(B, ceil_div(C, 1024)), dim3(NT), 0, (hipStream_t)stream, (const bf16_t*)z, ldz, T, C, mean);
     }
@@ -549,6 +551,7 @@ extern "C" int sdk_se_gate_residual(sdk_ctx* ctx, const uint16_t* z, int64_t ldz
     SDK_LAUNCH_CHECK();
     return 0;
   }
+  SDK_REQUIRE(!mean_in, "sdk_se_gate_residual: a precomputed mean needs the workspace form");
   const int ngrp = NT / (C / 8);
   const size_t lds = (size_t)(ngrp * C + C + Cse) * sizeof(float);
   SDK_REQUIRE((size_t)(NT / Cse) * Cse <= (size_t)ngrp * C, "sdk_se_gate_residual: scratch too small");

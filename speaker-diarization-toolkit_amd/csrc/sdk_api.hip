@@ -103,7 +103,7 @@ inline size_t a256(size_t v) { return (v + 255) & ~(size_t)255; }
 
 struct FwdWs {
   uint16_t *X0, *U, *R, *Z, *Sa, *Sb, *CAT, *H, *AH;
-  float *ctx, *ubias, *logits, *pooled, *se;
+  float *ctx, *ubias, *logits, *pooled, *se, *stats, *mean;
 };
 
 size_t fwd_layout(const sdk_ecapa_desc* d, int B, int T, char* base, FwdWs* w) {
@@ -124,7 +124,9 @@ size_t fwd_layout(const sdk_ecapa_desc* d, int B, int T, char* base, FwdWs* w) {
   char* lg = take(M * Cm * 4);
   char* po = take((size_t)B * 2 * Cm * 4);
   char* se = take(sdk_se_workspace_bytes(B, (int)C, d->se_channels));
-  if (w) w->se = (float*)se;
+  char* stp = take(sdk_conv_gemm_stats_bytes((int)M, (int)Cm, 2));
+  char* mn = take((size_t)B * C * 4);
+  if (w) { w->se = (float*)se; w->stats = (float*)stp; w->mean = (float*)mn; }
   if (w) {
     w->X0 = (uint16_t*)x0; w->U = (uint16_t*)u; w->R = (uint16_t*)r; w->Z = (uint16_t*)z;
     w->Sa = (uint16_t*)sa; w->Sb = (uint16_t*)sb; w->CAT = (uint16_t*)cat; w->H = (uint16_t*)h; w->AH = (uint16_t*)ah;
@@ -180,13 +182,14 @@ extern "C" int sdk_ecapa_forward(sdk_ctx* ctx, const void* wblob, const sdk_ecap
   hipStream_t st = (hipStream_t)stream;
 
   auto tdnn = [&](const uint16_t* Ain, int64_t lda, int Cin, int taps, int dil, int slot, int N, uint16_t* Cout, int64_t ldc,
-                  const uint16_t* X2, int64_t ldx2, uint16_t* Sout, int64_t lds) -> int {
+                  const uint16_t* X2, int64_t ldx2, uint16_t* Sout, int64_t lds, int stats_mode = 0) -> int {
     sdk_conv_gemm_args g;
     memset(&g, 0, sizeof(g));
     g.A = Ain; g.lda = lda; g.W = P16(slot + EL_W); g.C = Cout; g.ldc = ldc;
     g.bias = P32(slot + EL_B); g.scale = P32(slot + EL_SCALE); g.shift = P32(slot + EL_SHIFT);
     g.X2 = X2; g.ldx2 = ldx2; g.S = Sout; g.lds = lds;
     g.M = M; g.N = N; g.Cin = Cin; g.taps = taps; g.dil = dil; g.T = T; g.flags = SDK_GEMM_RELU;
+    g.stats_mode = stats_mode; g.stats_part = stats_mode ? w.stats : nullptr;
     SDK_REQUIRE(g.W && g.bias && g.scale && g.shift, "sdk_ecapa_forward: weight slot %d missing", slot);
     return sdk_conv_gemm(ctx, &g, stream);
   };
@@ -213,20 +216,29 @@ extern "C" int sdk_ecapa_forward(sdk_ctx* ctx, const void* wblob, const sdk_ecap
       const uint16_t* X2 = more ? w.U + (int64_t)S * (j + 2) : nullptr;
       if (int rc = tdnn(Ain, lda, S, 3, dil, base + EL_RES2NET(j), S, w.R + (int64_t)S * (j + 1), C, X2, C, Sout, S)) return rc;
     }
-    if (int rc = tdnn(w.R, C, C, 1, 1, base + EL_TDNN2, C, w.Z, C, nullptr, 0, nullptr, 0)) return rc;
+    // the SE squeeze (per-segment channel means of z) comes out of the tdnn2 epilogue where the shape allows it
+    const bool fuse_se = sdk_conv_gemm_stats_fusable(M, C, T) != 0;
+    if (int rc = tdnn(w.R, C, C, 1, 1, base + EL_TDNN2, C, w.Z, C, nullptr, 0, nullptr, 0, fuse_se ? 1 : 0)) return rc;
+    if (fuse_se)
+      if (int rc = sdk_colstats_finish(ctx, w.stats, M, C, T, 1, w.mean, stream)) return rc;
     uint16_t* slab = w.CAT + (int64_t)C * (i - 1);
     if (int rc = sdk_se_gate_residual(ctx, w.Z, C, xin, ldx, P32(base + EL_SE_W1T), P32(base + EL_SE_B1), P32(base + EL_SE_W2T),
-                                      P32(base + EL_SE_B2), slab, Cm, B, T, C, d->se_channels, w.se, sdk_se_workspace_bytes(B, C, d->se_channels),
-                                      stream)) return rc;
+                                      P32(base + EL_SE_B2), slab, Cm, B, T, C, d->se_channels, fuse_se ? w.mean : nullptr, w.se,
+                                      sdk_se_workspace_bytes(B, C, d->se_channels), stream)) return rc;
     xin = slab;
     ldx = Cm;
   }
 
   const int tb = EL_TAIL_BASE(d->n_blocks);
-  if (int rc = tdnn(w.CAT, Cm, Cm, 1, 1, tb + EL_MFA, Cm, w.H, Cm, nullptr, 0, nullptr, 0)) return rc;
-
-  // attentive statistics pooling with global context
-  if (int rc = sdk_asp_stats(ctx, w.H, Cm, B, T, Cm, w.ctx, stream)) return rc;
+  // attentive statistics pooling with global context; the context (mean | std of h over frames) comes out of
+  // the MFA epilogue where the shape allows it, else from a separate sweep of h
+  const bool fuse_ctx = sdk_conv_gemm_stats_fusable(M, Cm, T) != 0;
+  if (int rc = tdnn(w.CAT, Cm, Cm, 1, 1, tb + EL_MFA, Cm, w.H, Cm, nullptr, 0, nullptr, 0, fuse_ctx ? 2 : 0)) return rc;
+  if (fuse_ctx) {
+    if (int rc = sdk_colstats_finish(ctx, w.stats, M, Cm, T, 2, w.ctx, stream)) return rc;
+  } else {
+    if (int rc = sdk_asp_stats(ctx, w.H, Cm, B, T, Cm, w.ctx, stream)) return rc;
+  }
   if (int rc = sdk_rows_fc(ctx, w.ctx, 2 * Cm, nullptr, nullptr, P32(tb + EL_ASP_WMS_T), P32(tb + EL_ASP_B), w.ubias, A, B, 2 * Cm, A, 0, stream)) return rc;
   {
     sdk_conv_gemm_args g;

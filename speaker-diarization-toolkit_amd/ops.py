@@ -174,7 +174,9 @@ class Engine:
 
     # ------------------------------------------------------------------ building blocks (tests / tuning)
     def conv_gemm(self, A, W, N, Cin, taps=1, dil=1, T=None, bias=None, scale=None, shift=None, ubias=None,
-                  relu=False, tanh=False, out_bf16=True, out_f32=False, X2=None):
+                  relu=False, tanh=False, out_bf16=True, out_f32=False, X2=None, stats_mode=0):
+        """stats_mode 1/2 additionally returns the fused per-segment column statistics as a 4th value
+        ([B, N] means, or [B, 2N] mean | std)."""
         _need(A, torch.bfloat16, "A"); _need(W, torch.bfloat16, "W")
         M = A.shape[0]
         T = T or M
@@ -190,7 +192,15 @@ class Engine:
         g.S, g.lds = _ptr(S), N
         g.M, g.N, g.Cin, g.taps, g.dil, g.T = M, N, Cin, taps, dil, T
         g.flags = (_lib.GEMM_RELU if relu else 0) | (_lib.GEMM_TANH if tanh else 0)
+        part = None
+        if stats_mode:
+            part = torch.empty(self.lib.sdk_conv_gemm_stats_bytes(M, N, stats_mode), dtype=torch.uint8, device=self.device)
+            g.stats_mode, g.stats_part = stats_mode, part.data_ptr()
         check(self.lib.sdk_conv_gemm(self.ctx, C.byref(g), _stream()), "sdk_conv_gemm")
+        if stats_mode:
+            st = torch.empty((M // T, N * stats_mode), dtype=torch.float32, device=self.device)
+            check(self.lib.sdk_colstats_finish(self.ctx, part.data_ptr(), M, N, T, stats_mode, st.data_ptr(), _stream()), "sdk_colstats_finish")
+            return Cout, C32, S, st
         return Cout, C32, S
 
     def se_gate_residual(self, z, x, w1t, b1, w2t, b2, B, T, split: bool = True):
@@ -199,7 +209,7 @@ class Engine:
         ws = self._scratch_bytes("se", self.lib.sdk_se_workspace_bytes(B, C_, w1t.shape[1])) if split else None
         check(self.lib.sdk_se_gate_residual(self.ctx, z.data_ptr(), z.stride(0), x.data_ptr(), x.stride(0), w1t.data_ptr(),
                                             b1.data_ptr(), w2t.data_ptr(), b2.data_ptr(), out.data_ptr(), out.stride(0),
-                                            B, T, C_, w1t.shape[1], _ptr(ws), ws.numel() if split else 0, _stream()), "sdk_se_gate_residual")
+                                            B, T, C_, w1t.shape[1], None, _ptr(ws), ws.numel() if split else 0, _stream()), "sdk_se_gate_residual")
         return out
 
     def asp_stats(self, h, B, T):

@@ -439,3 +439,23 @@ def test_spectral_cluster_matches_oracle(engine, N, k):
     assert ospec.adjusted_rand_index(res.labels, truth) == 1.0
     # eigenvalues of S: bf16 tile rounding inside A V -> 2e-3 absolute (values in [0, 1])
     assert np.abs(res.eigenvalues - olam).max() < 2e-3, (res.eigenvalues, olam)
+
+
+@pytest.mark.parametrize("M,T,N,Cin,mode", [(2010, 201, 1024, 128, 1), (1608, 201, 512, 64, 2), (1280, 128, 256, 64, 2), (3000, 1500, 256, 64, 1)])
+def test_conv_gemm_fused_column_stats(engine, M, T, N, Cin, mode):
+    """Per-segment column statistics produced by the GEMM epilogue (SE squeeze / ASP context) equal the
+    statistics of the STORED bf16 output."""
+    g = torch.Generator().manual_seed(M + mode)
+    A = bf16_round(torch.randn(M, Cin, generator=g))
+    Wt = bf16_round(torch.randn(N, Cin, generator=g) * 0.2)
+    bias = torch.randn(N, generator=g)
+    C, _, _, st = engine.conv_gemm(dev(A, torch.bfloat16), dev(Wt, torch.bfloat16), N, Cin, T=T, bias=dev(bias), relu=True, stats_mode=mode)
+    torch.cuda.synchronize()
+    z = C.float().cpu().double().reshape(M // T, T, N)
+    mean = z.mean(1)
+    got = st.cpu().double()
+    # fp32 partial sums in a fixed order vs float64: rtol 1e-5 (|values| ~ 1)
+    assert torch.allclose(got[:, :N], mean, rtol=1e-5, atol=1e-5), float((got[:, :N] - mean).abs().max())
+    if mode == 2:
+        sd = ((z - mean[:, None]) ** 2).mean(1).clamp_min(1e-12).sqrt()
+        assert torch.allclose(got[:, N:], sd, rtol=2e-4, atol=2e-5), float((got[:, N:] - sd).abs().max())
