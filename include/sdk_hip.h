@@ -108,6 +108,9 @@ typedef struct sdk_conv_gemm_args {
    * sdk_conv_gemm_stats_fusable(M, N, T) is true. */
   int32_t stats_mode;
   float* stats_part;
+  /* optional addend of the A operand, same rows/row map/channels: the GEMM consumes bf16(A + A2)
+   * (Res2Net: y_{c-1} + u_c formed on the way into LDS instead of round-tripping through HBM) */
+  const uint16_t* A2; int64_t lda2;
 } sdk_conv_gemm_args;
 int sdk_conv_gemm(sdk_ctx* ctx, const sdk_conv_gemm_args* a, void* stream);
 size_t sdk_conv_gemm_stats_bytes(int M, int N, int mode);

@@ -34,7 +34,8 @@ class ConvGemmArgs(C.Structure):
                 ("ubias", C.c_void_p), ("ldub", C.c_int64),
                 ("X2", C.c_void_p), ("ldx2", C.c_int64), ("S", C.c_void_p), ("lds", C.c_int64),
                 ("M", C.c_int), ("N", C.c_int), ("Cin", C.c_int), ("taps", C.c_int), ("dil", C.c_int),
-                ("T", C.c_int), ("flags", C.c_uint32), ("stats_mode", C.c_int32), ("stats_part", C.c_void_p)]
+                ("T", C.c_int), ("flags", C.c_uint32), ("stats_mode", C.c_int32), ("stats_part", C.c_void_p),
+                ("A2", C.c_void_p), ("lda2", C.c_int64)]
 
 
 class EcapaDesc(C.Structure):

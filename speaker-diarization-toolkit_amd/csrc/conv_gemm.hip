@@ -37,6 +37,7 @@ struct Params {
   uint32_t flags;
   int tune;
   float* stats_part; int stats_mode;   // fused per-segment column statistics (256^2 kernel only)
+  const bf16_t* A2; int64_t lda2;      // optional addend of the A operand (128^2 kernel only): A := bf16(A + A2)
 };
 
 __global__ __launch_bounds__(NT, 2) void conv_gemm_kernel(Params p) {
@@ -88,7 +89,7 @@ __global__ __launch_bounds__(NT, 2) void conv_gemm_kernel(Params p) {
   const int nk = p.taps * ksteps_per_tap;
   const int half = p.taps >> 1;
 
-  u32x4 ra[4], rb[4];
+  u32x4 ra[4], rb[4], ra2[4];
   auto gload = [&](int s) {
     const int j = s / ksteps_per_tap;
     const int kc = (s - j * ksteps_per_tap) * BK;
@@ -98,6 +99,7 @@ __global__ __launch_bounds__(NT, 2) void conv_gemm_kernel(Params p) {
       const int src = p.taps > 1 ? segbase[i] + reflect_idx(tloc[i] + off, p.T) : segbase[i];
       ra[i] = *reinterpret_cast<const u32x4*>(p.A + (int64_t)src * p.lda + kc + ch * 8);
       rb[i] = *reinterpret_cast<const u32x4*>(wrow[i] + j * p.Cin + kc);
+      if (p.A2) ra2[i] = *reinterpret_cast<const u32x4*>(p.A2 + (int64_t)src * p.lda2 + kc + ch * 8);
     }
   };
 
@@ -121,6 +123,14 @@ __global__ __launch_bounds__(NT, 2) void conv_gemm_kernel(Params p) {
   for (int s = 0; s < nk; ++s) {
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
+      if (p.A2) {                                            // Res2Net running sum formed on the way into LDS
+        float fa[8], fb[8];
+        unpack8(ra[i], fa);
+        unpack8(ra2[i], fb);
+#pragma unroll
+        for (int e = 0; e < 8; ++e) fa[e] += fb[e];
+        ra[i] = pack8(fa);
+      }
       *reinterpret_cast<u32x4*>(sA + lds_w[i]) = ra[i];
       *reinterpret_cast<u32x4*>(sB + lds_w[i]) = rb[i];
     }
@@ -573,9 +583,11 @@ extern "C" int sdk_conv_gemm(sdk_ctx* ctx, const sdk_conv_gemm_args* a, void* st
   p.M = a->M; p.N = a->N; p.Cin = a->Cin; p.taps = a->taps; p.dil = a->dil; p.T = a->T; p.flags = a->flags;
   p.tune = g_gemm_variant / 16;
   p.stats_part = nullptr; p.stats_mode = 0;
+  p.A2 = (const bf16_t*)a->A2; p.lda2 = a->lda2;
+  if (a->A2) SDK_REQUIRE(a->lda2 % 8 == 0 && a->lda2 >= a->Cin && ((uintptr_t)a->A2 % 16) == 0, "sdk_conv_gemm: bad A2/lda2");
 
   const double kk = (double)a->taps * a->Cin;
-  const bool use256 = (g_gemm_variant & 15) != 1 && a->N % BN2 == 0 && a->M >= BM2;
+  const bool use256 = (g_gemm_variant & 15) != 1 && a->N % BN2 == 0 && a->M >= BM2 && !a->A2;
   ProfScope ps(ctx, stream, use256 ? SDK_K_CONV_GEMM256 : SDK_K_CONV_GEMM, 2.0 * a->M * a->N * kk,
                2.0 * a->M * a->Cin + 2.0 * a->N * kk + (a->C ? 2.0 : 0.0) * a->M * a->N + (a->C32 ? 4.0 : 0.0) * a->M * a->N +
                    (a->S ? 4.0 : 0.0) * a->M * a->N);

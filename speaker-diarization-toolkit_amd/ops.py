@@ -174,7 +174,7 @@ class Engine:
 
     # ------------------------------------------------------------------ building blocks (tests / tuning)
     def conv_gemm(self, A, W, N, Cin, taps=1, dil=1, T=None, bias=None, scale=None, shift=None, ubias=None,
-                  relu=False, tanh=False, out_bf16=True, out_f32=False, X2=None, stats_mode=0):
+                  relu=False, tanh=False, out_bf16=True, out_f32=False, X2=None, stats_mode=0, A2=None):
         """stats_mode 1/2 additionally returns the fused per-segment column statistics as a 4th value
         ([B, N] means, or [B, 2N] mean | std)."""
         _need(A, torch.bfloat16, "A"); _need(W, torch.bfloat16, "W")
@@ -182,6 +182,8 @@ class Engine:
         T = T or M
         g = ConvGemmArgs()
         g.A, g.lda, g.W = A.data_ptr(), A.stride(0), W.data_ptr()
+        if A2 is not None:
+            g.A2, g.lda2 = A2.data_ptr(), A2.stride(0)
         Cout = torch.empty((M, N), dtype=torch.bfloat16, device=self.device) if out_bf16 else None
         C32 = torch.empty((M, N), dtype=torch.float32, device=self.device) if out_f32 else None
         S = torch.empty((M, N), dtype=torch.bfloat16, device=self.device) if X2 is not None else None

@@ -459,3 +459,25 @@ def test_conv_gemm_fused_column_stats(engine, M, T, N, Cin, mode):
     if mode == 2:
         sd = ((z - mean[:, None]) ** 2).mean(1).clamp_min(1e-12).sqrt()
         assert torch.allclose(got[:, N:], sd, rtol=2e-4, atol=2e-5), float((got[:, N:] - sd).abs().max())
+
+
+def test_conv_gemm_a2_addend(engine):
+    """A2: the GEMM consumes bf16(A + A2) (Res2Net running sum formed on the way into LDS)."""
+    M, T, N, Cin = 603, 201, 128, 128
+    g = torch.Generator().manual_seed(9)
+    A = torch.randint(-3, 4, (M, 256), generator=g).float()
+    A2 = torch.randint(-2, 3, (M, 384), generator=g).float()
+    Wt = torch.randint(-2, 3, (N, 3 * Cin), generator=g).float()
+    _, C32, _ = engine.conv_gemm(dev(A, torch.bfloat16)[:, 64:192], dev(Wt, torch.bfloat16), N, Cin, taps=3, dil=3, T=T, out_bf16=False,
+                                 out_f32=True, A2=dev(A2, torch.bfloat16)[:, 128:256])
+    want = _conv_ref(A[:, 64:192] + A2[:, 128:256], Wt, Cin, 3, 3, T)
+    torch.cuda.synchronize()
+    assert torch.equal(C32.cpu(), want)
+    # non-integer data: the sum is rounded to bf16 before the MFMA, exactly like a stored S = bf16(A + A2)
+    Af, A2f = bf16_round(torch.randn(M, Cin, generator=g)), bf16_round(torch.randn(M, Cin, generator=g))
+    Wf = bf16_round(torch.randn(N, 3 * Cin, generator=g) * 0.1)
+    _, C32, _ = engine.conv_gemm(dev(Af, torch.bfloat16), dev(Wf, torch.bfloat16), N, Cin, taps=3, dil=2, T=T, out_bf16=False, out_f32=True,
+                                 A2=dev(A2f, torch.bfloat16))
+    want = _conv_ref(bf16_round(Af + A2f), Wf, Cin, 3, 2, T)
+    torch.cuda.synchronize()
+    assert torch.allclose(C32.cpu(), want, rtol=2e-5, atol=2e-5)
