@@ -49,12 +49,15 @@ int sdk_init(int device, sdk_ctx** out);
 int sdk_shutdown(sdk_ctx* ctx);
 const char* sdk_last_error(void);
 int sdk_get_device_info(sdk_ctx* ctx, sdk_device_info* out);
+/* A/B and test knobs: "res2net_chain_fusion" (1 default / 0 = seven conv_gemm launches), "gemm_variant" (see
+ * sdk_set_gemm_variant).  Results do not depend on them. */
+int sdk_set_option(sdk_ctx* ctx, const char* name, int value);
 
 /* ---- measurement: per-kernel-family HIP-event timing on the launch stream (bench.py roofline) -- */
 enum {
   SDK_K_CONV_GEMM = 0, SDK_K_SE_GATE, SDK_K_ASP_STATS, SDK_K_ROWS_FC, SDK_K_ASP_POOL, SDK_K_FBANK_TILE,
   SDK_K_FBANK_NORM, SDK_K_L2NORM, SDK_K_AFF_COARSE, SDK_K_AFF_RESCORE, SDK_K_AFF_RESCAN, SDK_K_COPY,
-  SDK_K_AFF_MATVEC, SDK_K_CONV_GEMM256, SDK_K_ASP_FUSED, SDK_K_COUNT
+  SDK_K_AFF_MATVEC, SDK_K_CONV_GEMM256, SDK_K_ASP_FUSED, SDK_K_RES2NET, SDK_K_COUNT
 };
 typedef struct sdk_profile_report {
   int32_t launches[16];
@@ -127,6 +130,14 @@ int sdk_set_gemm_variant(int variant);
  * w1t [C, Cse] fp32 (transposed), w2t [Cse, C] fp32 (transposed).  C % 8 == 0 and (C/8) | 256, Cse | 256.
  * With a workspace the work is split into a mean sweep, two batched FCs on the fp32 matrix pipe and an
  * apply sweep (same arithmetic, weights read once per 32 segments). */
+/* Res2Net chain of one block fused per segment (T <= sdk_res2net_chain_max_frames(), 128-channel sub-bands):
+ *   R[:, 128c : 128(c+1)] = y_c,  y_1 = TDNN_0(U chunk 1),  y_c = TDNN_{c-1}(bf16(U chunk c + y_{c-1})),  c = 2..nconv
+ * W/bias/scale/shift: HOST arrays of nconv device pointers (W[i]: bf16 [128][3*128]).  Bit-identical to the
+ * same chain expressed as nconv sdk_conv_gemm launches. */
+int sdk_res2net_chain_max_frames(void);
+int sdk_res2net_chain(sdk_ctx* ctx, const uint16_t* U, int64_t ldu, uint16_t* R, int64_t ldr, const uint16_t* const* W,
+                      const float* const* bias, const float* const* scale, const float* const* shift, int nconv,
+                      int B, int T, int dil, void* stream);
 size_t sdk_se_workspace_bytes(int B, int C, int Cse);   /* fp32 [B,C] means + [B,Cse] hidden + [B,C] gates */
 int sdk_se_gate_residual(sdk_ctx* ctx, const uint16_t* z, int64_t ldz, const uint16_t* x, int64_t ldx,
                          const float* w1t, const float* b1, const float* w2t, const float* b2,

@@ -50,7 +50,7 @@ class ProfileReport(C.Structure):
 
 
 KERNEL_FAMILIES = ["conv_gemm", "se_gate", "asp_stats", "rows_fc", "asp_pool", "fbank_tile", "fbank_norm", "l2norm",
-                   "affinity_coarse", "affinity_rescore", "affinity_rescan", "copy", "affinity_matvec", "conv_gemm256", "asp_fused"]
+                   "affinity_coarse", "affinity_rescore", "affinity_rescan", "copy", "affinity_matvec", "conv_gemm256", "asp_fused", "res2net_chain"]
 
 GEMM_RELU = 1
 GEMM_TANH = 2
@@ -64,6 +64,7 @@ SIGNATURES = {
     "sdk_shutdown": (_i, [_vp]),
     "sdk_last_error": (C.c_char_p, []),
     "sdk_get_device_info": (_i, [_vp, C.POINTER(DeviceInfo)]),
+    "sdk_set_option": (_i, [_vp, C.c_char_p, _i]),
     "sdk_profile_begin": (_i, [_vp]),
     "sdk_profile_end": (_i, [_vp, C.POINTER(ProfileReport)]),
     "sdk_fbank_tables_bytes": (_sz, []),
@@ -75,6 +76,8 @@ SIGNATURES = {
     "sdk_conv_gemm_stats_bytes": (_sz, [_i, _i, _i]),
     "sdk_conv_gemm_stats_fusable": (_i, [_i, _i, _i]),
     "sdk_colstats_finish": (_i, [_vp, _vp, _i, _i, _i, _i, _vp, _vp]),
+    "sdk_res2net_chain_max_frames": (_i, []),
+    "sdk_res2net_chain": (_i, [_vp, _vp, _i64, _vp, _i64, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _vp]),
     "sdk_se_workspace_bytes": (_sz, [_i, _i, _i]),
     "sdk_se_gate_residual": (_i, [_vp, _vp, _i64, _vp, _i64, _vp, _vp, _vp, _vp, _vp, _i64, _i, _i, _i, _i, _vp, _vp, _sz, _vp]),
     "sdk_asp_stats": (_i, [_vp, _vp, _i64, _i, _i, _i, _vp, _vp]),

@@ -28,6 +28,7 @@ struct sdk_ctx {
   int num_cu;
   hipDeviceProp_t prop;
   bool prof_on = false;
+  bool no_chain_fusion = false;   // A/B + test knob: run the Res2Net chain as separate conv_gemm launches
   std::vector<sdk_prof_rec> prof;
 };
 

@@ -67,6 +67,14 @@ extern "C" int sdk_get_device_info(sdk_ctx* ctx, sdk_device_info* out) {
   return 0;
 }
 
+extern "C" int sdk_set_option(sdk_ctx* ctx, const char* name, int value) {
+  SDK_REQUIRE(ctx && name, "sdk_set_option: null argument");
+  if (strcmp(name, "res2net_chain_fusion") == 0) { ctx->no_chain_fusion = value == 0; return 0; }
+  if (strcmp(name, "gemm_variant") == 0) return sdk_set_gemm_variant(value);
+  sdk_set_error("sdk_set_option: unknown option '%s'", name);
+  return 2;
+}
+
 extern "C" int sdk_profile_begin(sdk_ctx* ctx) {
   SDK_REQUIRE(ctx, "sdk_profile_begin: null ctx");
   for (auto& r : ctx->prof) { (void)hipEventDestroy(r.a); (void)hipEventDestroy(r.b); }
@@ -208,13 +216,23 @@ extern "C" int sdk_ecapa_forward(sdk_ctx* ctx, const void* wblob, const sdk_ecap
       ProfScope ps(ctx, stream, SDK_K_COPY, 0.0, 2.0 * M * S * 2);
       SDK_HIP_OK(hipMemcpy2DAsync(w.R, (size_t)C * 2, w.U, (size_t)C * 2, (size_t)S * 2, (size_t)M, hipMemcpyDeviceToDevice, st));
     }
+    if (S == 128 && d->scale - 1 <= 7 && T <= sdk_res2net_chain_max_frames() && !ctx->no_chain_fusion) {
+      // the seven dependent convolutions in ONE launch, the running tile resident in LDS per segment
+      const uint16_t* Wp[7]; const float* bp[7]; const float* sp[7]; const float* tp[7];
+      for (int j = 0; j < d->scale - 1; ++j) {
+        const int slot = base + EL_RES2NET(j);
+        Wp[j] = P16(slot + EL_W); bp[j] = P32(slot + EL_B); sp[j] = P32(slot + EL_SCALE); tp[j] = P32(slot + EL_SHIFT);
+      }
+      if (int rc = sdk_res2net_chain(ctx, w.U, C, w.R, C, Wp, bp, sp, tp, d->scale - 1, B, T, dil, stream)) return rc;
+    } else {
     for (int j = 0; j < d->scale - 1; ++j) {
-      const uint16_t* Ain = j == 0 ? w.U + S : ((j & 1) ? w.Sa : w.Sb);
-      const int64_t lda = j == 0 ? C : S;
-      const bool more = j + 1 < d->scale - 1;
-      uint16_t* Sout = more ? ((j & 1) ? w.Sb : w.Sa) : nullptr;
-      const uint16_t* X2 = more ? w.U + (int64_t)S * (j + 2) : nullptr;
-      if (int rc = tdnn(Ain, lda, S, 3, dil, base + EL_RES2NET(j), S, w.R + (int64_t)S * (j + 1), C, X2, C, Sout, S)) return rc;
+        const uint16_t* Ain = j == 0 ? w.U + S : ((j & 1) ? w.Sa : w.Sb);
+        const int64_t lda = j == 0 ? C : S;
+        const bool more = j + 1 < d->scale - 1;
+        uint16_t* Sout = more ? ((j & 1) ? w.Sb : w.Sa) : nullptr;
+        const uint16_t* X2 = more ? w.U + (int64_t)S * (j + 2) : nullptr;
+        if (int rc = tdnn(Ain, lda, S, 3, dil, base + EL_RES2NET(j), S, w.R + (int64_t)S * (j + 1), C, X2, C, Sout, S)) return rc;
+      }
     }
     // the SE squeeze (per-segment channel means of z) comes out of the tdnn2 epilogue where the shape allows it
     const bool fuse_se = sdk_conv_gemm_stats_fusable(M, C, T) != 0;

@@ -95,6 +95,9 @@ class Engine:
             self.load_weights()
         return self._desc
 
+    def set_option(self, name: str, value: int) -> None:
+        check(self.lib.sdk_set_option(self.ctx, name.encode(), int(value)), "sdk_set_option")
+
     # ------------------------------------------------------------------ measurement
     def profile_begin(self) -> None:
         check(self.lib.sdk_profile_begin(self.ctx), "sdk_profile_begin")

@@ -481,3 +481,18 @@ def test_conv_gemm_a2_addend(engine):
     want = _conv_ref(bf16_round(Af + A2f), Wf, Cin, 3, 2, T)
     torch.cuda.synchronize()
     assert torch.allclose(C32.cpu(), want, rtol=2e-5, atol=2e-5)
+
+
+@pytest.mark.parametrize("B,T", [(5, 201), (3, 100), (2, 208), (1, 9)])
+def test_res2net_chain_fusion_is_bit_identical(engine, B, T):
+    """The per-segment fused Res2Net chain (one launch, tile resident in LDS) must reproduce the seven
+    separate conv_gemm launches bit for bit (same k order, same rounding points)."""
+    feats = _feats(B, T, 31)
+    f = torch.zeros(B * T, WP.N_MELS_PADDED, dtype=torch.bfloat16)
+    f[:, :80] = feats.reshape(-1, 80).to(torch.bfloat16)
+    f = f.cuda()
+    engine.set_option("res2net_chain_fusion", 0)
+    ref = engine.ecapa_forward(f, B, T).cpu()
+    engine.set_option("res2net_chain_fusion", 1)
+    fused = engine.ecapa_forward(f, B, T).cpu()
+    assert torch.equal(ref, fused), float((ref - fused).abs().max())
