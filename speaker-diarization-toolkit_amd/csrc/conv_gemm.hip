@@ -328,10 +328,13 @@ __global__ __launch_bounds__(NT2, 2) void conv_gemm256_kernel(Params p) {
 #pragma unroll
     for (int mi = 0; mi < 4; ++mi) dst[mi] = *reinterpret_cast<const bf16x8*>(st + a_base + (mh * 4 + mi) * 2048 + coff);
   };
-  auto mma = [&](const bf16x8* af, const bf16x8* bf, int mh) {
+  // 16 MFMAs of one sub-phase in two halves: the fragment reads of the NEXT sub-phase are issued between
+  // the halves, so they complete under the second half instead of being waited for right after issue
+  // (hipcc waits lgkmcnt(0) before the first MFMA that follows a ds_read group).
+  auto mma_half = [&](const bf16x8* af, const bf16x8* bf, int mh, int part) {
     __builtin_amdgcn_s_setprio(1);
 #pragma unroll
-    for (int mi = 0; mi < 4; ++mi)
+    for (int mi = 2 * part; mi < 2 * part + 2; ++mi)
 #pragma unroll
       for (int ni = 0; ni < 4; ++ni)
         acc[mh * 4 + mi][ni] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[mi], bf[ni], acc[mh * 4 + mi][ni], 0, 0, 0);
@@ -351,15 +354,24 @@ __global__ __launch_bounds__(NT2, 2) void conv_gemm256_kernel(Params p) {
   for (int t = 0; t < nk; ++t) {
     const char* st = smem + (t & 1) * STAGE2;
     __builtin_amdgcn_sched_barrier(0);
+    mma_half(a0, b0, 0, 0);                           // P0
+    __builtin_amdgcn_sched_barrier(0);
     ldA(st, a1, 1, c0);
-    mma(a0, b0, 0);                                   // P0
+    __builtin_amdgcn_sched_barrier(0);
+    mma_half(a0, b0, 0, 1);
+    __builtin_amdgcn_sched_barrier(0);
+    mma_half(a1, b0, 1, 0);                           // P1
     __builtin_amdgcn_sched_barrier(0);
     ldB(st, b1, c1);
     ldA(st, a0, 0, c1);
-    mma(a1, b0, 1);                                   // P1
+    __builtin_amdgcn_sched_barrier(0);
+    mma_half(a1, b0, 1, 1);
+    __builtin_amdgcn_sched_barrier(0);
+    mma_half(a0, b1, 0, 0);                           // P2
     __builtin_amdgcn_sched_barrier(0);
     ldA(st, a1, 1, c1);
-    mma(a0, b1, 0);                                   // P2
+    __builtin_amdgcn_sched_barrier(0);
+    mma_half(a0, b1, 0, 1);
     __builtin_amdgcn_sched_barrier(0);
     if (t + 1 < nk) {
       asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
@@ -370,7 +382,8 @@ __global__ __launch_bounds__(NT2, 2) void conv_gemm256_kernel(Params p) {
       ldA(sn, a0, 0, c0);
     }
     __builtin_amdgcn_sched_barrier(0);
-    mma(a1, b1, 1);                                   // P3
+    mma_half(a1, b1, 1, 0);                           // P3
+    mma_half(a1, b1, 1, 1);
     __builtin_amdgcn_sched_barrier(0);
     if (!dma_early && t + 2 < nk) issue(t + 2, t & 1);
   }
