@@ -114,3 +114,17 @@ def test_pipeline_run_shard_single_rank(engine):
     assert np.array_equal(res.best_profile, oidx) and np.abs(res.best_score - osc).max() <= 1e-5
     olab, _ = ospec.spectral_cluster(oecapa.to_bf16_f32(Eg), 3, n_iter=20, n_kmeans=20)
     assert np.array_equal(res.cluster_labels, olab)
+
+
+def test_graph_replay_matches_eager(engine):
+    """The captured-HIP-graph form of the embedding path returns exactly what the eager launches return."""
+    for B in (1, 5):
+        pcm = torch.from_numpy(np.stack([_voice(200 + i, 2.0, 120.0 + 10 * i)[:32000] for i in range(B)])).cuda()
+        E0, Eb0, r0 = [t.clone() for t in engine.embed_pcm(pcm)]
+        E1, Eb1, r1 = engine.embed_pcm_graph(pcm)
+        torch.cuda.synchronize()
+        assert torch.equal(E0, E1) and torch.equal(Eb0.float(), Eb1.float()) and torch.equal(r0, r1)
+        pcm2 = torch.roll(pcm, 1234, dims=1)
+        E2, _, _ = engine.embed_pcm_graph(pcm2)          # replay with new input
+        torch.cuda.synchronize()
+        assert torch.equal(E2, engine.embed_pcm(pcm2)[0])
