@@ -432,6 +432,17 @@ __global__ __launch_bounds__(NT, 2) void asp_fused_kernel(const bf16_t* __restri
   for (int ks = 0; ks < 8; ++ks) bfrag[ks] = *reinterpret_cast<const bf16x8*>(w2 + (int64_t)ch * 128 + ks * 16 + hh * 8);
   __syncthreads();
 
+  // h slab [T x 128 channels]: its HBM loads are issued NOW and ride under the MFMA phase; they land in the
+  // same LDS buffer once every wave has finished reading the hidden tile
+  constexpr int HP = (ROWS * 16 + NT - 1) / NT;
+  u32x4 hpre[HP];
+#pragma unroll
+  for (int i = 0; i < HP; ++i) {
+    const int id = tid + NT * i, r = id >> 4, c = id & 15;
+    hpre[i] = u32x4{0u, 0u, 0u, 0u};
+    if (r < T) hpre[i] = *reinterpret_cast<const u32x4*>(h + (base + r) * ldh + cblk + c * 8);
+  }
+
   f32x16 acc[NTILES];
 #pragma unroll
   for (int rt = 0; rt < NTILES; ++rt) {
@@ -445,10 +456,10 @@ __global__ __launch_bounds__(NT, 2) void asp_fused_kernel(const bf16_t* __restri
     }
   }
   __syncthreads();
-  // ---- phase B: h slab [T x 128 channels] -> the same LDS
-  for (int id = tid; id < T * 16; id += NT) {
-    const int r = id >> 4, c = id & 15;
-    *reinterpret_cast<u32x4*>(lds + r * 256 + c * 16) = *reinterpret_cast<const u32x4*>(h + (base + r) * ldh + cblk + c * 8);
+#pragma unroll
+  for (int i = 0; i < HP; ++i) {
+    const int id = tid + NT * i, r = id >> 4, c = id & 15;
+    if (r < T) *reinterpret_cast<u32x4*>(lds + r * 256 + c * 16) = hpre[i];
   }
   // softmax max while the loads are in flight (registers only; branch-free: rows >= T count as -inf)
   float mx = -INFINITY;
