@@ -18,6 +18,8 @@
 //  exact rescan (affinity_rescan_kernel)  fp32 scan over all P with the same dot-product routine,
 //      one work item per (row, 1024-profile slice), merged by affinity_rescan_merge_kernel.
 // The reported (idx, score) therefore equal an fp32 full scan: ties -> lowest profile index.
+#include <stdlib.h>
+
 #include "common.hpp"
 
 namespace {
@@ -32,8 +34,8 @@ constexpr int PROWB = 384;             // LDS bytes per profile row (24 chunks o
 constexpr int NSTAGE = 3;              // LDS ring depth (2 tiles in flight); 36 KiB -> 4 workgroups per CU
 constexpr int CHUNK_TILES = 32;        // 1024 profiles share one 10-bit index space
 constexpr uint32_t IDX_MASK = 0x3ffu;
-constexpr int DEPTH = 3;               // per-lane sorted candidate list (one lane = one half of the profiles)
-constexpr int NCAND = 2 * DEPTH;
+constexpr int MAXDEPTH = 4;            // per-lane sorted candidate list (one lane = one half of the profiles): 3 or 4 deep
+constexpr int NCAND = 2 * MAXDEPTH;    // candidate slots per segment in the workspace (unused slots hold index -1)
 
 struct Workspace {        // layout inside the caller's scratch buffer
   float* cand_val;        // [N][8] coarse value (index bits stripped)
@@ -63,14 +65,18 @@ inline size_t ws_layout(int N, int P, char* base, Workspace* w) {
   return off;
 }
 
-// sorted insert of x into (m0 >= m1 >= m2): 1 v_max + 2 v_med3; values are packed floats
-__device__ __forceinline__ void insert3(float x, float& m0, float& m1, float& m2) {
-  const float n2 = __builtin_amdgcn_fmed3f(x, m1, m2);
-  const float n1 = __builtin_amdgcn_fmed3f(x, m0, m1);
-  m0 = fmaxf(x, m0);
-  m1 = n1; m2 = n2;
+// sorted insert of x into m[0] >= m[1] >= ... : 1 v_max + (DEPTH-1) v_med3; values are packed floats
+template <int DEPTH>
+__device__ __forceinline__ void insert_sorted(float x, float* m) {
+  float n[DEPTH];
+#pragma unroll
+  for (int q = DEPTH - 1; q >= 1; --q) n[q] = __builtin_amdgcn_fmed3f(x, m[q - 1], m[q]);
+  n[0] = fmaxf(x, m[0]);
+#pragma unroll
+  for (int q = 0; q < DEPTH; ++q) m[q] = n[q];
 }
 
+template <int DEPTH>
 __global__ __launch_bounds__(WAVES * 64, 2) void affinity_coarse_kernel(const bf16_t* __restrict__ Eb,
                                                                        const bf16_t* __restrict__ Pb, int N, int P,
                                                                        float* __restrict__ cand_val,
@@ -114,13 +120,13 @@ __global__ __launch_bounds__(WAVES * 64, 2) void affinity_coarse_kernel(const bf
   };
 
   // global candidate list of this lane (its half of the profiles): value + full index
-  float gv[DEPTH] = {-INFINITY, -INFINITY, -INFINITY};
-  int gi[DEPTH] = {-1, -1, -1};
-  // chunk-local packed list
-  float m0 = -INFINITY, m1 = -INFINITY, m2 = -INFINITY;
+  float gv[DEPTH];
+  int gi[DEPTH];
+  float mv[DEPTH];                                             // chunk-local packed list
+#pragma unroll
+  for (int q = 0; q < DEPTH; ++q) { gv[q] = -INFINITY; gi[q] = -1; mv[q] = -INFINITY; }
 
   auto merge_chunk = [&](int chunk) {
-    const float mv[DEPTH] = {m0, m1, m2};
 #pragma unroll
     for (int e = 0; e < DEPTH; ++e) {
       const uint32_t bits = __float_as_uint(mv[e]);
@@ -139,7 +145,8 @@ __global__ __launch_bounds__(WAVES * 64, 2) void affinity_coarse_kernel(const bf
       for (int q = 0; q < DEPTH; ++q)
         if (q == pos) { gv[q] = v; gi[q] = idx; }
     }
-    m0 = m1 = m2 = -INFINITY;
+#pragma unroll
+    for (int q = 0; q < DEPTH; ++q) mv[q] = -INFINITY;
   };
 
   issue(0);
@@ -166,7 +173,7 @@ __global__ __launch_bounds__(WAVES * 64, 2) void affinity_coarse_kernel(const bf
 #pragma unroll
       for (int r = 0; r < 16; ++r) {
         const uint32_t rc = (uint32_t)((r & 3) + 8 * (r >> 2));
-        insert3(__uint_as_float(((__float_as_uint(acc[r]) & ~IDX_MASK) | tb) | rc), m0, m1, m2);
+        insert_sorted<DEPTH>(__uint_as_float(((__float_as_uint(acc[r]) & ~IDX_MASK) | tb) | rc), mv);
       }
     } else {                                                     // last, partial tile: rows past the last profile never enter
 #pragma unroll
@@ -174,16 +181,16 @@ __global__ __launch_bounds__(WAVES * 64, 2) void affinity_coarse_kernel(const bf
         const uint32_t rc = (uint32_t)((r & 3) + 8 * (r >> 2));
         float x = __uint_as_float(((__float_as_uint(acc[r]) & ~IDX_MASK) | tb) | rc);
         if (t * PT + (int)rc + 4 * h >= P) x = -INFINITY;
-        insert3(x, m0, m1, m2);
+        insert_sorted<DEPTH>(x, mv);
       }
     }
     if (tl == CHUNK_TILES - 1 || t + 1 == ntiles) merge_chunk(t / CHUNK_TILES);
   }
   if (seg < N) {
 #pragma unroll
-    for (int e = 0; e < DEPTH; ++e) {
-      cand_val[(int64_t)seg * NCAND + h * DEPTH + e] = gv[e];
-      cand_idx[(int64_t)seg * NCAND + h * DEPTH + e] = gi[e];
+    for (int e = 0; e < MAXDEPTH; ++e) {
+      cand_val[(int64_t)seg * NCAND + h * MAXDEPTH + e] = e < DEPTH ? gv[e < DEPTH ? e : 0] : -INFINITY;
+      cand_idx[(int64_t)seg * NCAND + h * MAXDEPTH + e] = e < DEPTH ? gi[e < DEPTH ? e : 0] : -1;
     }
     // u = max over the two halves of their last list entry (a bound on every profile that is not a candidate)
     const float other = __shfl_xor(gv[DEPTH - 1], 32, 64);
@@ -449,8 +456,15 @@ extern "C" int sdk_affinity_topk(sdk_ctx* ctx, const float* E, const uint16_t* E
   SDK_HIP_OK(hipMemsetAsync(w.flag_count, 0, sizeof(int32_t), s));
   {
   ProfScope ps(ctx, stream, SDK_K_AFF_COARSE, 2.0 * N * (double)Pn * D, 2.0 * ((double)N + Pn) * D + 68.0 * N);
-  hipLaunchKernelGGL(affinity_coarse_kernel, dim3(ceil_div(N, SEG_PER_WG)), dim3(WAVES * 64), 0, s, (const bf16_t*)Eb,
-                     (const bf16_t*)Pb, N, Pn, w.cand_val, w.cand_idx, w.ubound);
+  static const int aff_depth3_max_p = getenv("SDK_AFF_DEPTH3_MAXP") ? atoi(getenv("SDK_AFF_DEPTH3_MAXP")) : 2048;
+  // list depth: 3 (5 VALU ops per score, ~1 % of rows re-scanned at P ~ 1k) up to 2048 profiles; 4 beyond, where
+  // the order statistics crowd together and every re-scanned row costs a full pass over P
+  if (Pn <= aff_depth3_max_p && k <= 2)
+    hipLaunchKernelGGL(affinity_coarse_kernel<3>, dim3(ceil_div(N, SEG_PER_WG)), dim3(WAVES * 64), 0, s, (const bf16_t*)Eb,
+                       (const bf16_t*)Pb, N, Pn, w.cand_val, w.cand_idx, w.ubound);
+  else
+    hipLaunchKernelGGL(affinity_coarse_kernel<4>, dim3(ceil_div(N, SEG_PER_WG)), dim3(WAVES * 64), 0, s, (const bf16_t*)Eb,
+                       (const bf16_t*)Pb, N, Pn, w.cand_val, w.cand_idx, w.ubound);
   }
   SDK_LAUNCH_CHECK();
   {
