@@ -229,17 +229,18 @@ __global__ __launch_bounds__(NT) void rows_fc_kernel(const float* __restrict__ i
 // result is still plain fp32 arithmetic in a fixed order).  Block = 32 rows x 32 outputs, the 4 waves
 // split K; lane half h of a wave takes k = 8g + 4h + u in MFMA step u, so every lane fetches its four
 // A values with ONE 16-byte load and the B values as four coalesced 128-byte weight-row segments.
-__global__ __launch_bounds__(NT) void rows_fc_mfma_kernel(const float* __restrict__ in, int64_t ldin,
+template <int KW>   // waves per block = K slices
+__global__ __launch_bounds__(KW * 64) void rows_fc_mfma_kernel(const float* __restrict__ in, int64_t ldin,
                                                          const float* __restrict__ isc, const float* __restrict__ ish,
                                                          const float* __restrict__ wt, const float* __restrict__ bias,
                                                          float* __restrict__ out, int64_t ldout, int B, int Cin, int Nout,
                                                          int act) {
-  __shared__ float red[4][32 * 33];
+  __shared__ float red[KW][32 * 33];
   const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
   const int i = lane & 31, hh = lane >> 5;
   const int b0 = blockIdx.x * 32, n0 = blockIdx.y * 32;
   const int row = min(b0 + i, B - 1), colw = min(n0 + i, Nout - 1);
-  const int kw = Cin / 4;                                  // K range of this wave (multiple of 8)
+  const int kw = Cin / KW;                                 // K range of this wave (multiple of 8)
   const float* ap = in + (int64_t)row * ldin + wid * kw + 4 * hh;
   const float* bp = wt + (int64_t)(wid * kw + 4 * hh) * Nout + colw;
   const float* sp = isc ? isc + wid * kw + 4 * hh : nullptr;
@@ -247,26 +248,39 @@ __global__ __launch_bounds__(NT) void rows_fc_mfma_kernel(const float* __restric
   f32x16 acc;
 #pragma unroll
   for (int r = 0; r < 16; ++r) acc[r] = 0.f;
-  for (int g = 0; g < kw; g += 8) {
-    f32x4 a = *reinterpret_cast<const f32x4*>(ap + g);
+  // software pipeline: the operands of group g+1 (8 k) are in flight while group g feeds the matrix pipe
+  auto fetch = [&](int g, f32x4& a, float* b) {
+    a = *reinterpret_cast<const f32x4*>(ap + g);
     if (sp) {
       const f32x4 s4 = *reinterpret_cast<const f32x4*>(sp + g), t4 = *reinterpret_cast<const f32x4*>(tp + g);
 #pragma unroll
       for (int u = 0; u < 4; ++u) a[u] = a[u] * s4[u] + t4[u];
     }
-    float b[4];
 #pragma unroll
     for (int u = 0; u < 4; ++u) b[u] = bp[(int64_t)(g + u) * Nout];
+  };
+  f32x4 fa0, fa1;
+  float fb0[4], fb1[4];
+  fetch(0, fa0, fb0);
+  for (int g = 0; g < kw; g += 16) {
+    if (g + 8 < kw) fetch(g + 8, fa1, fb1);
 #pragma unroll
-    for (int u = 0; u < 4; ++u) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a[u], b[u], acc, 0, 0, 0);
+    for (int u = 0; u < 4; ++u) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(fa0[u], fb0[u], acc, 0, 0, 0);
+    if (g + 8 < kw) {
+      if (g + 16 < kw) fetch(g + 16, fa0, fb0);
+#pragma unroll
+      for (int u = 0; u < 4; ++u) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(fa1[u], fb1[u], acc, 0, 0, 0);
+    }
   }
 #pragma unroll
   for (int r = 0; r < 16; ++r) red[wid][((r & 3) + 8 * (r >> 2) + 4 * hh) * 33 + i] = acc[r];
   __syncthreads();
-  for (int e = tid; e < 32 * 32; e += NT) {
+  for (int e = tid; e < 32 * 32; e += KW * 64) {
     const int r = e >> 5, c = e & 31;
     if (b0 + r < B && n0 + c < Nout) {
-      float v = ((red[0][r * 33 + c] + red[1][r * 33 + c]) + red[2][r * 33 + c]) + red[3][r * 33 + c];
+      float v = 0.f;
+#pragma unroll
+      for (int k2 = 0; k2 < KW; ++k2) v += red[k2][r * 33 + c];        // slice order: reproducible
       v += bias ? bias[n0 + c] : 0.f;
       if (act == 1) v = fmaxf(v, 0.f);
       else if (act == 2) v = 1.0f / (1.0f + __expf(-v));
@@ -592,8 +606,12 @@ extern "C" int sdk_rows_fc(sdk_ctx* ctx, const float* in, int64_t ldin, const fl
   SDK_REQUIRE((in_scale == nullptr) == (in_shift == nullptr), "sdk_rows_fc: in_scale and in_shift go together");
   SDK_REQUIRE(act >= 0 && act <= 2, "sdk_rows_fc: act=%d", act);
   ProfScope ps(ctx, stream, SDK_K_ROWS_FC, 2.0 * B * Cin * Nout, 4.0 * ((double)B * Cin + (double)Cin * Nout + (double)B * Nout));
-  if (Cin % 32 == 0 && ldin % 4 == 0 && ((uintptr_t)in % 16) == 0 && (!in_scale || (((uintptr_t)in_scale | (uintptr_t)in_shift) % 16) == 0))
-    hipLaunchKernelGGL(rows_fc_mfma_kernel, dim3(ceil_div(B, 32), ceil_div(Nout, 32)), dim3(NT), 0, (hipStream_t)stream,
+  const bool mfma_ok = ldin % 4 == 0 && ((uintptr_t)in % 16) == 0 && (!in_scale || (((uintptr_t)in_scale | (uintptr_t)in_shift) % 16) == 0);
+  if (mfma_ok && Cin % 128 == 0 && Cin >= 2048)      // long K (context bias, final FC): 16 K-slices keep every CU busy
+    hipLaunchKernelGGL(rows_fc_mfma_kernel<16>, dim3(ceil_div(B, 32), ceil_div(Nout, 32)), dim3(1024), 0, (hipStream_t)stream,
+                       in, ldin, in_scale, in_shift, wt, bias, out, ldout, B, Cin, Nout, act);
+  else if (mfma_ok && Cin % 32 == 0)
+    hipLaunchKernelGGL(rows_fc_mfma_kernel<4>, dim3(ceil_div(B, 32), ceil_div(Nout, 32)), dim3(NT), 0, (hipStream_t)stream,
                        in, ldin, in_scale, in_shift, wt, bias, out, ldout, B, Cin, Nout, act);
   else
     hipLaunchKernelGGL(rows_fc_kernel, dim3(ceil_div(B, FC_ROWS), ceil_div(Nout, FC_OUT)), dim3(NT), 0, (hipStream_t)stream,
