@@ -6,15 +6,15 @@
 // 80 dB floor under the utterance peak, per-utterance mean normalisation, bf16 output.
 //
 // Kernel A (fbank_tile_kernel): one workgroup = 32 frames of one segment, 7 waves.  The windowed
-// real DFT is a [32 x 400] x [400 x 2*224] product on the exact-fp32 matrix pipe
-// (v_mfma_f32_32x32x2_f32; K folded 400 -> 201 by the real-input/symmetric-window identity):
+// real DFT runs on the bf16 matrix pipe with hi+lo split operands (3 MFMAs per product, ~fp32
+// accuracy), K folded 400 -> 201 by the real-input/symmetric-window identity:
 // wave w owns frequency bins 32w..32w+31 and keeps the cos and sin
 // accumulators of those bins in the SAME lane/register positions, so |X|^2 is formed in registers.
-//   A operand: raw samples from an LDS image skewed by one word per hop (row stride 161 words:
-//              the 32 frames of a wave-instruction hit 32 different banks instead of one).
-//   B operand: the DFT matrix with the window folded in, pre-packed on the host in fragment order
-//              ([wave][cos|sin][k-group][lane][4]) so each lane fetches four k-steps with one
-//              16-byte L2-resident load, prefetched one group ahead.
+//   A operand: folded (x[n] +- x[400-n]) hi/lo bf16 sample images built once per tile in LDS, 432-byte
+//              rows (27 sixteen-byte slots: the 32 frames of a ds_read_b128 never share a slot).
+//   B operand: the DFT matrix with the window folded in, split hi/lo, pre-packed on the host in
+//              fragment order so each lane fetches a fragment with one 16-byte L2-resident load,
+//              prefetched one k-step ahead.
 // Mel projection is a sparse (triangular) VALU dot product over the LDS power tile.
 // Kernel B (fbank_norm_kernel): per segment floor / mean-normalise / bf16 store (HBM streaming).
 #include <math.h>
@@ -27,28 +27,41 @@ namespace {
 constexpr int NFFT = 400, HOP = 160, NMEL = 80, NBIN = 201;
 constexpr int FT = 32;                  // frames per tile
 constexpr int NW = 7;                   // waves per workgroup = bin blocks of 32 (224 >= 201)
-constexpr int NSYM = 208;                // folded sample index n = 0..200 (x[n] +- x[400-n]), padded to a multiple of 8
-constexpr int KG = NSYM / 2 / 4;        // 26 groups of 4 MFMA k-steps (2 folded samples each)
+constexpr int NSYM = 208;                // folded sample index n = 0..200 (x[n] +- x[400-n]), padded to 13 k-steps of 16
+constexpr int KSTEPS = NSYM / 16;        // 13 MFMA k-steps (v_mfma_f32_32x32x16_bf16)
 constexpr int TILE_SAMPLES = (FT - 1) * HOP + NFFT;   // 5360
-constexpr int XS_WORDS = TILE_SAMPLES + TILE_SAMPLES / HOP + 1;
+constexpr int AROW = NSYM + 8;           // bf16 elements per frame row of the folded images (432 B = 27 slots: conflict-free)
 constexpr int PW_STRIDE = NW * 32 + 1;  // 225
 constexpr int MELW_MAX = 512;
 
 struct FbankTables {
-  float dft[NW][2][KG][64][4];
+  // DFT matrix with the window folded in, split hi + lo bf16, in B-fragment order:
+  // [bin block][cos|sin][k-step][hi|lo][lane][8]   (lane l: bin 32w + (l & 31), k = 16 ks + 8 (l >> 5) + j)
+  uint16_t dft[NW][2][KSTEPS][2][64][8];
   int32_t mstart[NMEL];
   int32_t mlen[NMEL];
   int32_t moff[NMEL];
   float melw[MELW_MAX];
 };
 
-__device__ __forceinline__ int skew(int q) { return q + q / HOP; }
-
+// The windowed real DFT of 32 frames as a [32 x 208] x [208 x 2*224] product on the bf16 matrix pipe at
+// ~fp32 accuracy: both operands are split x = hi + lo (bf16 each; int16 samples split EXACTLY) and
+//     x . y  ~=  hi.hi + hi.lo + lo.hi          (relative error ~2^-16 per product, ~ -120 dB of the peak)
+// which is 3 v_mfma_f32_32x32x16_bf16 per 16 k - 5x fewer matrix-pipe cycles than v_mfma_f32_32x32x2_f32.
+// K is already folded 400 -> 201 by the real-input / symmetric-window identity:
+//   Re X[f] =  sum_{n=0..200} c_n w[n] (x[n] + x[400-n]) cos(2 pi f n / 400),  c_0 = c_200 = 1/2
+//   Im X[f] = -sum_{n=1..199}     w[n] (x[n] - x[400-n]) sin(2 pi f n / 400)         (400-n taken mod 400)
+// The folded, split sample images are built once per tile in LDS (rows of 432 B), so an A fragment is one
+// ds_read_b128; wave w owns bins 32w..32w+31 and keeps cos and sin accumulators in the same lane/register
+// positions, so |X|^2 forms in registers.
 __global__ __launch_bounds__(NW * 64) void fbank_tile_kernel(const int16_t* __restrict__ pcm, int S, int T,
                                                             int tiles_per_seg, const FbankTables* __restrict__ tab,
                                                             float* __restrict__ L) {
-  __shared__ float xs[XS_WORDS];
-  __shared__ float pw[FT * PW_STRIDE];
+  __shared__ __attribute__((aligned(16))) char lds[4 * FT * AROW * 2 + TILE_SAMPLES * 4];
+  bf16_t* img = reinterpret_cast<bf16_t*>(lds);                       // [cos hi | cos lo | sin hi | sin lo][32][AROW]
+  float* xs = reinterpret_cast<float*>(lds + 4 * FT * AROW * 2);      // raw samples of the tile
+  float* pw = reinterpret_cast<float*>(lds);                          // power tile, overlays the images after the MFMAs
+  static_assert(FT * PW_STRIDE * 4 <= 4 * FT * AROW * 2, "power tile must fit over the folded images");
   const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
   const int b = blockIdx.x / tiles_per_seg;
   const int t0 = (blockIdx.x - b * tiles_per_seg) * FT;
@@ -57,44 +70,58 @@ __global__ __launch_bounds__(NW * 64) void fbank_tile_kernel(const int16_t* __re
 
   for (int q = tid; q < TILE_SAMPLES; q += NW * 64) {
     const int64_t g = s0 + q;
-    const float v = (g >= 0 && g < S) ? (float)seg[g] * (1.0f / 32768.0f) : 0.f;
-    xs[skew(q)] = v;
+    xs[q] = (g >= 0 && g < S) ? (float)seg[g] * (1.0f / 32768.0f) : 0.f;
+  }
+  __syncthreads();
+  for (int e = tid; e < FT * NSYM; e += NW * 64) {
+    const int i = e / NSYM, n = e - i * NSYM;
+    float ec = 0.f, es = 0.f;
+    if (n <= NFFT / 2) {
+      const float xa = xs[i * HOP + n], xb = xs[i * HOP + (n == 0 ? 0 : NFFT - n)];
+      ec = xa + xb;
+      es = xa - xb;
+    }
+    const bf16_t ch = f32_to_bf16(ec), sh = f32_to_bf16(es);
+    img[(0 * FT + i) * AROW + n] = ch;
+    img[(1 * FT + i) * AROW + n] = f32_to_bf16(ec - bf16_to_f32(ch));
+    img[(2 * FT + i) * AROW + n] = sh;
+    img[(3 * FT + i) * AROW + n] = f32_to_bf16(es - bf16_to_f32(sh));
   }
   __syncthreads();
 
   f32x16 are, aim;
 #pragma unroll
   for (int r = 0; r < 16; ++r) { are[r] = 0.f; aim[r] = 0.f; }
-
-  // The frame is real and the periodic Hamming window is symmetric (w[n] = w[400-n]), so
-  //   Re X[f] =  sum_{n=0..200} c_n w[n] (x[n] + x[400-n]) cos(2 pi f n / 400),  c_0 = c_200 = 1/2
-  //   Im X[f] = -sum_{n=1..199}     w[n] (x[n] - x[400-n]) sin(2 pi f n / 400)
-  // (index 400-n taken mod 400): K shrinks from 400 to 201 - half the MFMAs - for one extra LDS read and
-  // one add/sub per A value.  The constants c_n and the window live in the packed tables.
   const int fi = lane & 31, kk = lane >> 5;
-  const int arow = fi * (HOP + 1);
-  const f32x4* bre = reinterpret_cast<const f32x4*>(&tab->dft[w][0][0][lane][0]);
-  const f32x4* bim = reinterpret_cast<const f32x4*>(&tab->dft[w][1][0][lane][0]);
-  f32x4 cre = bre[0], cim = bim[0];
-  for (int g = 0; g < KG; ++g) {
-    f32x4 nre = cre, nim = cim;
-    if (g + 1 < KG) {
-      nre = bre[(g + 1) * 64];
-      nim = bim[(g + 1) * 64];
-    }
+  const bf16_t* arow = img + fi * AROW + kk * 8;
+  const bf16x8* btab = reinterpret_cast<const bf16x8*>(&tab->dft[w][0][0][0][lane][0]);
+  // fragment (part p, step ks, hi/lo v) sits at btab[((p * KSTEPS + ks) * 2 + v) * 64]
+  bf16x8 bc[4], bn[4];                                  // cos hi, cos lo, sin hi, sin lo of the current / next k-step
 #pragma unroll
-    for (int u = 0; u < 4; ++u) {
-      int n = (g * 4 + u) * 2 + kk;
-      n = n <= NFFT / 2 ? n : NFFT / 2;                       // padded k (201..207): table rows are zero
-      const int m = n == 0 ? 0 : NFFT - n;                    // mirror sample, (400 - n) mod 400
-      const float xa = xs[arow + n + (n >= HOP)];             // n <= 200 < 2*HOP
-      const float xb = xs[arow + m + (m >= HOP) + (m >= 2 * HOP)];
-      are = __builtin_amdgcn_mfma_f32_32x32x2f32(xa + xb, cre[u], are, 0, 0, 0);
-      aim = __builtin_amdgcn_mfma_f32_32x32x2f32(xa - xb, cim[u], aim, 0, 0, 0);
+  for (int v = 0; v < 2; ++v) { bc[v] = btab[(0 * KSTEPS * 2 + v) * 64]; bc[2 + v] = btab[(1 * KSTEPS * 2 + v) * 64]; }
+#pragma unroll 1
+  for (int ks = 0; ks < KSTEPS; ++ks) {
+    if (ks + 1 < KSTEPS) {
+#pragma unroll
+      for (int v = 0; v < 2; ++v) {
+        bn[v] = btab[((0 * KSTEPS + ks + 1) * 2 + v) * 64];
+        bn[2 + v] = btab[((1 * KSTEPS + ks + 1) * 2 + v) * 64];
+      }
     }
-    cre = nre;
-    cim = nim;
+    const bf16x8 ach = *reinterpret_cast<const bf16x8*>(arow + (0 * FT) * AROW + ks * 16);
+    const bf16x8 acl = *reinterpret_cast<const bf16x8*>(arow + (1 * FT) * AROW + ks * 16);
+    const bf16x8 ash = *reinterpret_cast<const bf16x8*>(arow + (2 * FT) * AROW + ks * 16);
+    const bf16x8 asl = *reinterpret_cast<const bf16x8*>(arow + (3 * FT) * AROW + ks * 16);
+    are = __builtin_amdgcn_mfma_f32_32x32x16_bf16(acl, bc[0], are, 0, 0, 0);     // small terms first
+    are = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ach, bc[1], are, 0, 0, 0);
+    are = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ach, bc[0], are, 0, 0, 0);
+    aim = __builtin_amdgcn_mfma_f32_32x32x16_bf16(asl, bc[2], aim, 0, 0, 0);
+    aim = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ash, bc[3], aim, 0, 0, 0);
+    aim = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ash, bc[2], aim, 0, 0, 0);
+#pragma unroll
+    for (int v = 0; v < 4; ++v) bc[v] = bn[v];
   }
+  __syncthreads();                                       // every wave is done with the images: pw may overlay them
   // power tile -> LDS [frame][bin]
 #pragma unroll
   for (int r = 0; r < 16; ++r) {
@@ -163,18 +190,36 @@ extern "C" int sdk_fbank_tables_fill(void* host_dst, size_t bytes) {
   FbankTables* t = (FbankTables*)host_dst;
   memset(t, 0, sizeof(FbankTables));
   const double PI = 3.14159265358979323846;
+  auto bf16_bits = [](float v) -> uint16_t {               // round-to-nearest-even, finite inputs
+    uint32_t u;
+    memcpy(&u, &v, 4);
+    return (uint16_t)((u + 0x7FFFu + ((u >> 16) & 1u)) >> 16);
+  };
+  auto bf16_val = [](uint16_t b) -> float {
+    const uint32_t u = (uint32_t)b << 16;
+    float v;
+    memcpy(&v, &u, 4);
+    return v;
+  };
   for (int w = 0; w < NW; ++w)
-    for (int g = 0; g < KG; ++g)
+    for (int ks = 0; ks < KSTEPS; ++ks)
       for (int l = 0; l < 64; ++l)
-        for (int u = 0; u < 4; ++u) {
-          const int n = (g * 4 + u) * 2 + (l >> 5);
+        for (int j = 0; j < 8; ++j) {
+          const int n = ks * 16 + 8 * (l >> 5) + j;
           const int f = w * 32 + (l & 31);
-          if (f >= NBIN || n > NFFT / 2) continue;
-          const double win = 0.54 - 0.46 * cos(2.0 * PI * n / NFFT);
-          const double ang = 2.0 * PI * (double)((n * f) % NFFT) / NFFT;
-          const double half = (n == 0 || n == NFFT / 2) ? 0.5 : 1.0;   // these samples are their own mirror
-          t->dft[w][0][g][l][u] = (float)(half * win * cos(ang));
-          t->dft[w][1][g][l][u] = (float)(-win * sin(ang));
+          double vc = 0.0, vs = 0.0;
+          if (f < NBIN && n <= NFFT / 2) {
+            const double win = 0.54 - 0.46 * cos(2.0 * PI * n / NFFT);
+            const double ang = 2.0 * PI * (double)((n * f) % NFFT) / NFFT;
+            const double half = (n == 0 || n == NFFT / 2) ? 0.5 : 1.0;   // these samples are their own mirror
+            vc = half * win * cos(ang);
+            vs = -win * sin(ang);
+          }
+          const uint16_t ch = bf16_bits((float)vc), sh = bf16_bits((float)vs);
+          t->dft[w][0][ks][0][l][j] = ch;
+          t->dft[w][0][ks][1][l][j] = bf16_bits((float)(vc - (double)bf16_val(ch)));
+          t->dft[w][1][ks][0][l][j] = sh;
+          t->dft[w][1][ks][1][l][j] = bf16_bits((float)(vs - (double)bf16_val(sh)));
         }
   // HTK-mel triangular filters, 0..8000 Hz, unit peak (oracle/fbank.py: mel_matrix)
   auto hz2mel = [](double f) { return 2595.0 * log10(1.0 + f / 700.0); };
@@ -223,7 +268,7 @@ extern "C" int sdk_fbank(sdk_ctx* ctx, const int16_t* pcm, int B, int S, const v
   const int tps = ceil_div(T, FT);
   SDK_REQUIRE((int64_t)B * tps < (1ll << 31), "sdk_fbank: batch too large for one launch");
   {
-  ProfScope ps(ctx, stream, SDK_K_FBANK_TILE, 2.0 * B * T * (double)NSYM * 2 * (NW * 32) + 2.0 * B * T * NBIN * NMEL, 2.0 * B * S + 4.0 * B * T * NMEL);
+  ProfScope ps(ctx, stream, SDK_K_FBANK_TILE, 3 * 2.0 * B * T * (double)NSYM * 2 * (NW * 32) + 2.0 * B * T * NBIN * NMEL, 2.0 * B * S + 4.0 * B * T * NMEL);
   hipLaunchKernelGGL(fbank_tile_kernel, dim3(B * tps), dim3(NW * 64), 0, (hipStream_t)stream, pcm, S, T, tps,
                      (const FbankTables*)tabs, (float*)ws);
   }

@@ -40,12 +40,19 @@ def test_host_only_entry_points_work_without_gpu():
     n = lib.sdk_fbank_tables_bytes()
     buf = np.zeros(n, dtype=np.uint8)
     assert lib.sdk_fbank_tables_fill(buf.ctypes.data, n) == 0
-    tab = buf[:7 * 2 * 26 * 64 * 4 * 4].view(np.float32).reshape(7, 2, 26, 64, 4)
-    # folded DFT table (n = 0..200): entry (wave 0, cos, group 0, lane 0, step 0) is n = 0, f = 0 ->
-    # 1/2 * window(0) * cos(0) = 0.04 (samples 0 and 200 are their own mirror); sin rows of n = 0 are zero
-    assert abs(tab[0, 0, 0, 0, 0] - 0.04) < 1e-7 and tab[0, 1, 0, 0, 0] == 0
-    # lane 32 (k-half 1) of step 0 is n = 1: window(1) * cos(2 pi f / 400) at f = 0
-    assert abs(tab[0, 0, 0, 32, 0] - (0.54 - 0.46 * np.cos(2 * np.pi / 400))) < 1e-7
+    WP = sub("weights_pack")
+    raw = buf[:7 * 2 * 13 * 2 * 64 * 8 * 2].view(np.uint16).reshape(7, 2, 13, 2, 64, 8)
+    tab = WP.bf16_bits_to_f32(raw).reshape(raw.shape)
+    val = tab[:, :, :, 0] + tab[:, :, :, 1]                 # hi + lo
+    # folded DFT table (n = 0..200), B-fragment order: [bin block][cos|sin][k-step][hi|lo][lane][8];
+    # lane l, element j -> n = 16 ks + 8 (l >> 5) + j, bin 32 w + (l & 31)
+    assert abs(val[0, 0, 0, 0, 0] - 0.04) < 1e-6 and val[0, 1, 0, 0, 0] == 0          # n = 0: 1/2 w[0] cos 0; sin row zero
+    n, f = 16 * 3 + 8 + 5, 32 * 2 + 7
+    want_c = (0.54 - 0.46 * np.cos(2 * np.pi * n / 400)) * np.cos(2 * np.pi * n * f / 400)
+    want_s = -(0.54 - 0.46 * np.cos(2 * np.pi * n / 400)) * np.sin(2 * np.pi * n * f / 400)
+    assert abs(val[2, 0, 3, 32 + 7, 5] - want_c) < 2e-5 and abs(val[2, 1, 3, 32 + 7, 5] - want_s) < 2e-5   # hi+lo: ~16 bits
+    assert not val[:, :, 12, 32:, 1:].any()                  # n > 200 (padding) is zero
+    tab = raw                                                # byte size used below
     # mel table must equal the oracle's filterbank
     from oracle import fbank as ofb
     ints = buf[tab.nbytes:tab.nbytes + 3 * 80 * 4].view(np.int32).reshape(3, 80)
