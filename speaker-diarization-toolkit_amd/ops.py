@@ -57,9 +57,11 @@ class Engine:
         self._fbank_tabs = None
         self._scratch: Dict[str, torch.Tensor] = {}
         self._graphs: Dict[tuple, tuple] = {}
+        self._streams = []
 
     # ------------------------------------------------------------------ resident state
     def _scratch_bytes(self, key: str, nbytes: int) -> torch.Tensor:
+        key = f"{key}@{torch.cuda.current_stream().cuda_stream}"       # scratch is per stream: sub-batches overlap
         buf = self._scratch.get(key)
         if buf is None or buf.numel() < nbytes:
             self._scratch[key] = buf = torch.empty(max(nbytes, 256), dtype=torch.uint8, device=self.device)
@@ -175,6 +177,30 @@ class Engine:
         feats = self.fbank(pcm)
         emb = self.ecapa_forward(feats, B, num_frames(S))
         return self.l2norm(emb)
+
+    def embed_pcm_overlapped(self, pcm: torch.Tensor, nsplit: int = 2):
+        """embed_pcm with the batch cut into `nsplit` sub-batches, each on its own HIP stream.  Segments are
+        independent, so the sub-batches need no ordering between them; the dispatcher co-schedules the
+        HBM-bound sweeps (SE, pooling, fbank) of one sub-batch into the wave slots, registers and LDS the
+        MFMA-bound GEMMs of the other leave free on every CU, and one sub-batch's tail overlaps the other's head."""
+        B = pcm.shape[0]
+        if nsplit <= 1 or B < 2 * nsplit:
+            return self.embed_pcm(pcm)
+        if len(self._streams) < nsplit:
+            self._streams += [torch.cuda.Stream(device=self.device) for _ in range(nsplit - len(self._streams))]
+        cur = torch.cuda.current_stream()
+        parts = []
+        for i, chunk in enumerate(pcm.chunk(nsplit)):
+            st = self._streams[i]
+            st.wait_stream(cur)
+            with torch.cuda.stream(st):
+                parts.append(self.embed_pcm(chunk))
+        for i in range(len(parts)):
+            cur.wait_stream(self._streams[i])
+        E = torch.cat([p[0] for p in parts]); Eb = torch.cat([p[1] for p in parts]); r = torch.cat([p[2] for p in parts])
+        for t in (E, Eb, r):
+            t.record_stream(cur)
+        return E, Eb, r
 
     def embed_pcm_graph(self, pcm: torch.Tensor):
         """embed_pcm replayed from a captured HIP graph (one graph per input shape): ~45 launches become one

@@ -19,6 +19,16 @@ for B in (1, 8, 64, 256, 1000, 4000):
     for _ in range(n): step()
     torch.cuda.synchronize(); dt = (time.perf_counter() - t0) / n
     line = f"B={B:5d}  {dt*1e3:8.3f} ms/step  {B/dt:10.0f} segments/s"
+    if B >= 256:
+        for ns in (2, 3, 4):
+            def step2():
+                E, Eb, re = eng.embed_pcm_overlapped(pcm, ns)
+                return eng.affinity_topk(E, Eb, re, Pn, Pb, rpm, k=1)
+            for _ in range(3): step2()
+            torch.cuda.synchronize(); t0 = time.perf_counter()
+            for _ in range(n): step2()
+            torch.cuda.synchronize(); d2 = (time.perf_counter() - t0) / n
+            line += f"   | {ns} streams {d2*1e3:7.3f} ms {B/d2:8.0f}/s"
     if B <= 256:
         for _ in range(3): eng.embed_pcm_graph(pcm)
         torch.cuda.synchronize(); t0 = time.perf_counter()
