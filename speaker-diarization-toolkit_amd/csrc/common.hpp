@@ -113,6 +113,14 @@ __device__ __forceinline__ float wave_max(float v) {
   return v;
 }
 
+// Workgroup barrier that orders LDS traffic only.  __syncthreads() also waits for every outstanding GLOBAL
+// store of the wave (vmcnt(0): CDNA4 counts stores), i.e. a full HBM round trip per call in a store-heavy
+// epilogue; where no global data is handed between waves this is the barrier to use.
+__device__ __forceinline__ void lds_barrier() {
+  asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+  __builtin_amdgcn_s_barrier();
+}
+
 // reflect (no edge repeat) t into [0, T); valid for -T < t < 2T-1
 __device__ __forceinline__ int reflect_idx(int t, int T) {
   t = t < 0 ? -t : t;

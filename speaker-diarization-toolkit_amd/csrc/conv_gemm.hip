@@ -230,8 +230,8 @@ namespace {
 constexpr int BM2 = 256, BN2 = 256, NT2 = 512;
 constexpr int STAGE2 = (BM2 + BN2) * BK * 2;         // 65536
 constexpr int LDS2 = 2 * STAGE2;                     // 131072
-constexpr int CT2_F32 = BN2 + 4;                     // fp32 words per staged accumulator row (260: 2-way = free on ds_write_b32)
-static_assert(64 * CT2_F32 * 4 <= LDS2, "epilogue quarter-tile must fit in the stage memory");
+constexpr int LDS2_TOTAL = LDS2 + 3 * BN2 * 4;       // + the tile's bias / scale / shift columns
+static_assert(BM2 * BN2 * 2 <= LDS2, "the bf16 image of a finished tile must fit in the two pipeline stages");
 
 typedef const void __attribute__((address_space(1)))* gptr_t;
 typedef void __attribute__((address_space(3)))* lptr_t;
@@ -241,273 +241,257 @@ __global__ __launch_bounds__(NT2, 2) void conv_gemm256_kernel(Params p) {
   const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
   const int wm = wid >> 2, wn = wid & 3;
 
-  // Tile order: every XCD owns a contiguous run of tile ids (xcd_remap); inside the run, tiles are walked in
-  // groups of GM m-tiles with m fastest, so the ~32 workgroups an XCD runs at once form an 8 x 4 block of the
-  // output: 12 distinct operand slices per K-step instead of 16+ and a working set that stays in the 4 MiB L2.
   const int nbn = p.N / BN2;
   const int nbm = (p.M + BM2 - 1) / BM2;
-  const int tile = xcd_remap(blockIdx.x, nbn * nbm);
-  constexpr int GM = 8;
-  const int per_group = GM * nbn;
-  const int grp = tile / per_group, in_grp = tile - grp * per_group;
-  const int gm = min(nbm - grp * GM, GM);
-  const bool rowmajor = (p.tune & 4) != 0;            // A/B knob: plain n-fastest order
-  const int bm = rowmajor ? tile / nbn : grp * GM + in_grp % gm, bn = rowmajor ? tile % nbn : in_grp / gm;
-  const int m0 = bm * BM2, n0 = bn * BN2;
-
-  // ---- DMA assignment: wave wid fills rows [32 wid, 32 wid + 32) of A and of B, 8 rows per instruction
-  const int rin = lane >> 3, pos = lane & 7;
-  const int gch = (pos ^ rin) * 8;                   // source chunk (elements) for this lane's LDS position
-  int segbase[4], tloc[4];
-  const bf16_t* wrow[4];
+  const int ntiles = nbn * nbm;
   const int Ktot = p.taps * p.Cin;
-#pragma unroll
-  for (int i = 0; i < 4; ++i) {
-    const int row = 32 * wid + 8 * i + rin;
-    int m = m0 + row;
-    m = m < p.M ? m : p.M - 1;
-    if (p.taps > 1) {
-      const int b = m / p.T;
-      segbase[i] = b * p.T;
-      tloc[i] = m - b * p.T;
-    } else {
-      segbase[i] = m;
-      tloc[i] = 0;
-    }
-    wrow[i] = p.W + (int64_t)(n0 + row) * Ktot + gch;
-  }
   const int ksteps_per_tap = p.Cin / BK;
   const int nk = p.taps * ksteps_per_tap;
   const int half = p.taps >> 1;
 
+  // Tile order: every XCD owns a contiguous run of tile ids (xcd_remap); inside the run, tiles are walked in
+  // groups of GM m-tiles with m fastest, so the ~32 workgroups an XCD runs at once form an 8 x 4 block of the
+  // output: 12 distinct operand slices per K-step instead of 16+.
+  auto tile_coords = [&](int vt, int& tm0, int& tn0) {
+    const int tile = xcd_remap(vt, ntiles);
+    constexpr int GM = 8;
+    const int per_group = GM * nbn;
+    const int grp = tile / per_group, in_grp = tile - grp * per_group;
+    const int gm = min(nbm - grp * GM, GM);
+    const bool rowmajor = (p.tune & 4) != 0;            // A/B knob: plain n-fastest order
+    tm0 = (rowmajor ? tile / nbn : grp * GM + in_grp % gm) * BM2;
+    tn0 = (rowmajor ? tile % nbn : in_grp / gm) * BN2;
+  };
+
+  // ---- DMA assignment: wave wid fills rows [32 wid, 32 wid + 32) of A and of B, 8 rows per instruction.
+  // Only the first of a lane's 4 rows is kept (rows step by 8); the others are rebuilt at issue time.
+  const int rin = lane >> 3, pos = lane & 7;
+  const int gch = (pos ^ rin) * 8;                   // source chunk (elements) for this lane's LDS position
+  int arow0, aseg0, atl0, woff0;
+  auto setup_dma = [&](int tm0, int tn0) {
+    const int row = 32 * wid + rin;
+    arow0 = tm0 + row;
+    const int mm = min(arow0, p.M - 1);
+    aseg0 = (mm / p.T) * p.T;
+    atl0 = mm - aseg0;                               // rows past M fetch some valid row; their results are dropped
+    woff0 = (tn0 + row) * Ktot + gch;
+  };
   auto issue = [&](int t, int stage) {
     const int j = t / ksteps_per_tap;
     const int kc = (t - j * ksteps_per_tap) * BK;
     const int off = (j - half) * p.dil;
     char* sA = smem + stage * STAGE2 + (32 * wid) * 128;
     char* sB = sA + BM2 * BK * 2;
+    const bf16_t* abase = p.A + kc + gch;
+    if (p.taps > 1) {
 #pragma unroll
-    for (int i = 0; i < 4; ++i) {
-      const int src = p.taps > 1 ? segbase[i] + reflect_idx(tloc[i] + off, p.T) : segbase[i];
-      const bf16_t* ga = p.A + (int64_t)src * p.lda + kc + gch;
-      __builtin_amdgcn_global_load_lds((gptr_t)ga, (lptr_t)(sA + i * 1024), 16, 0, 0);
-    }
+      for (int i = 0; i < 4; ++i) {
+        int tl = atl0 + 8 * i, sb = aseg0;
+        if (tl >= p.T) { tl -= p.T; sb += p.T; }      // T >= 64 > 24: at most one segment boundary inside the 4 rows
+        const int src = min(sb + reflect_idx(tl + off, p.T), p.M - 1);
+        __builtin_amdgcn_global_load_lds((gptr_t)(abase + (int64_t)src * p.lda), (lptr_t)(sA + i * 1024), 16, 0, 0);
+      }
+    } else {
 #pragma unroll
-    for (int i = 0; i < 4; ++i) {
-      const bf16_t* gb = wrow[i] + j * p.Cin + kc;
-      __builtin_amdgcn_global_load_lds((gptr_t)gb, (lptr_t)(sB + i * 1024), 16, 0, 0);
+      for (int i = 0; i < 4; ++i) {
+        const int src = min(arow0 + 8 * i, p.M - 1);
+        __builtin_amdgcn_global_load_lds((gptr_t)(abase + (int64_t)src * p.lda), (lptr_t)(sA + i * 1024), 16, 0, 0);
+      }
     }
+    const bf16_t* wbase = p.W + (woff0 + j * p.Cin + kc);
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+      __builtin_amdgcn_global_load_lds((gptr_t)(wbase + i * 8 * Ktot), (lptr_t)(sB + i * 1024), 16, 0, 0);
   };
-
-  f32x4 acc[8][4];
-#pragma unroll
-  for (int mi = 0; mi < 8; ++mi)
-#pragma unroll
-    for (int ni = 0; ni < 4; ++ni) acc[mi][ni] = f32x4{0.f, 0.f, 0.f, 0.f};
 
   const int fr = lane & 15, fq = lane >> 4, sw = lane & 7;
   const uint32_t a_base = (wm * 128 + fr) * 128;
   const uint32_t b_base = BM2 * BK * 2 + (wn * 64 + fr) * 128;
   const uint32_t c0 = ((0 * 4 + fq) ^ sw) << 4, c1 = ((1 * 4 + fq) ^ sw) << 4;
-
-  // Software pipeline, one barrier per K-tile, placed BEFORE the last MFMA sub-phase of the tile:
-  //   P0 P1 P2 | own reads of tile t done, own DMA of tile t+1 landed, barrier |
-  //   issue DMA of tile t+2 into the stage just freed, prefetch tile t+1's first fragments | P3
-  // so the LDS latency of the next tile's first reads and the DMA issue hide under P3's MFMAs, and a
-  // DMA always has a whole iteration to land.  The two waves that share a SIMD issue their DMA at
-  // different points (before / after P3) so one of them always has MFMAs for the matrix pipe.
   const int pol = p.tune & 3;   // 0: waves 0-3 early / 4-7 late (default), 1: all early, 2: all late, 3: odd/even
   const int wu = __builtin_amdgcn_readfirstlane(wid);
   const bool dma_early = pol == 1 ? true : pol == 2 ? false : pol == 3 ? (wu & 1) == 0 : wu < 4;
-  bf16x8 b0[4], b1[4], a0[4], a1[4];
-  auto ldB = [&](const char* st, bf16x8* dst, uint32_t coff) {
-#pragma unroll
-    for (int ni = 0; ni < 4; ++ni) dst[ni] = *reinterpret_cast<const bf16x8*>(st + b_base + ni * 2048 + coff);
-  };
-  auto ldA = [&](const char* st, bf16x8* dst, int mh, uint32_t coff) {
-#pragma unroll
-    for (int mi = 0; mi < 4; ++mi) dst[mi] = *reinterpret_cast<const bf16x8*>(st + a_base + (mh * 4 + mi) * 2048 + coff);
-  };
-  // 16 MFMAs of one sub-phase in two halves: the fragment reads of the NEXT sub-phase are issued between
-  // the halves, so they complete under the second half instead of being waited for right after issue
-  // (hipcc waits lgkmcnt(0) before the first MFMA that follows a ds_read group).
-  auto mma_half = [&](const bf16x8* af, const bf16x8* bf, int mh, int part) {
-    __builtin_amdgcn_s_setprio(1);
-#pragma unroll
-    for (int mi = 2 * part; mi < 2 * part + 2; ++mi)
-#pragma unroll
-      for (int ni = 0; ni < 4; ++ni)
-        acc[mh * 4 + mi][ni] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[mi], bf[ni], acc[mh * 4 + mi][ni], 0, 0, 0);
-    __builtin_amdgcn_s_setprio(0);
-  };
-
-  issue(0, 0);
-  if (nk > 1) {
-    issue(1, 1);
-    asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
-  } else {
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-  }
-  __builtin_amdgcn_s_barrier();
-  ldB(smem, b0, c0);
-  ldA(smem, a0, 0, c0);
-  for (int t = 0; t < nk; ++t) {
-    const char* st = smem + (t & 1) * STAGE2;
-    __builtin_amdgcn_sched_barrier(0);
-    mma_half(a0, b0, 0, 0);                           // P0
-    __builtin_amdgcn_sched_barrier(0);
-    ldA(st, a1, 1, c0);
-    __builtin_amdgcn_sched_barrier(0);
-    mma_half(a0, b0, 0, 1);
-    __builtin_amdgcn_sched_barrier(0);
-    mma_half(a1, b0, 1, 0);                           // P1
-    __builtin_amdgcn_sched_barrier(0);
-    ldB(st, b1, c1);
-    ldA(st, a0, 0, c1);
-    __builtin_amdgcn_sched_barrier(0);
-    mma_half(a1, b0, 1, 1);
-    __builtin_amdgcn_sched_barrier(0);
-    mma_half(a0, b1, 0, 0);                           // P2
-    __builtin_amdgcn_sched_barrier(0);
-    ldA(st, a1, 1, c1);
-    __builtin_amdgcn_sched_barrier(0);
-    mma_half(a0, b1, 0, 1);
-    __builtin_amdgcn_sched_barrier(0);
-    if (t + 1 < nk) {
-      asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
-      __builtin_amdgcn_s_barrier();
-      if (dma_early && t + 2 < nk) issue(t + 2, t & 1);
-      const char* sn = smem + ((t + 1) & 1) * STAGE2;
-      ldB(sn, b0, c0);
-      ldA(sn, a0, 0, c0);
-    }
-    __builtin_amdgcn_sched_barrier(0);
-    mma_half(a1, b1, 1, 0);                           // P3
-    mma_half(a1, b1, 1, 1);
-    __builtin_amdgcn_sched_barrier(0);
-    if (!dma_early && t + 2 < nk) issue(t + 2, t & 1);
-  }
-  asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-  __builtin_amdgcn_s_barrier();                      // every wave is done reading the last stage
-
-  // ------------------------------------------------------------------ epilogue
-  // Raw fp32 accumulators go to LDS a 64-row quarter at a time (the accumulator registers die at
-  // once: no spills), then all 512 threads sweep the quarter row-major: 8 columns per thread,
-  // epilogue math in fp32, one 16-byte bf16 store (and two 16-byte fp32 stores for C32).
-  float* ct32 = reinterpret_cast<float*>(smem);
-  const bool relu = p.flags & SDK_GEMM_RELU, tnh = p.flags & SDK_GEMM_TANH;
-  // fused per-segment column statistics of the STORED (bf16-rounded) output: thread = (column, row half);
-  // a 256-row tile overlaps at most 3 segments (T >= 128), told apart by the tile-local row bounds b1, b2
+  const bool relu = p.flags & SDK_GEMM_RELU;
   const bool stats = p.stats_part != nullptr;
-  const int sb1 = (m0 / p.T + 1) * p.T - m0, sb2 = sb1 + p.T;
-  float ss0 = 0.f, ss1 = 0.f, ss2 = 0.f, sq0 = 0.f, sq1 = 0.f, sq2 = 0.f;
-#pragma unroll
-  for (int q = 0; q < 4; ++q) {
-    if (wm == (q >> 1)) {
-#pragma unroll
-      for (int mq = 0; mq < 4; ++mq) {
-        const int mi = (q & 1) * 4 + mq;
-#pragma unroll
-        for (int r = 0; r < 4; ++r) {
-          const int lrow = mq * 16 + fq * 4 + r;
-#pragma unroll
-          for (int ni = 0; ni < 4; ++ni) ct32[lrow * CT2_F32 + wn * 64 + ni * 16 + fr] = acc[mi][ni][r];
-        }
-      }
+  float* par = reinterpret_cast<float*>(smem + LDS2);            // [3][256]: bias, scale, shift of the tile's columns
+
+  // Persistent workgroups (one per CU; the grid is a multiple of 8 so a workgroup keeps its XCD class) walk
+  // their tiles back to back.
+  for (int vt = blockIdx.x; vt < ntiles; vt += gridDim.x) {
+    int m0, n0;
+    tile_coords(vt, m0, n0);
+    setup_dma(m0, n0);
+    // the tile's 256 columns of epilogue parameters travel through LDS: the loads ride under the K loop
+    float pb = 0.f, psc = 1.f, psh = 0.f;
+    if (tid < BN2) {
+      if (p.bias) pb = p.bias[n0 + tid];
+      if (p.scale) { psc = p.scale[n0 + tid]; psh = p.shift[n0 + tid]; }
     }
-    __syncthreads();
+
+    f32x4 acc[8][4];
 #pragma unroll
-    for (int i = 0; i < 4; ++i) {
-      const int id = tid + NT2 * i;                          // 64 rows x 32 column chunks of 8
-      const int lrow = id >> 5, cc = id & 31;
-      const int m = m0 + q * 64 + lrow;
-      if (m < p.M) {
-        const int col = n0 + cc * 8;
-        const f32x4 v0 = *reinterpret_cast<const f32x4*>(ct32 + lrow * CT2_F32 + cc * 8);
-        const f32x4 v1 = *reinterpret_cast<const f32x4*>(ct32 + lrow * CT2_F32 + cc * 8 + 4);
-        float v[8] = {v0[0], v0[1], v0[2], v0[3], v1[0], v1[1], v1[2], v1[3]};
-        if (p.bias) {
-          const f32x4 b0 = *reinterpret_cast<const f32x4*>(p.bias + col), b1 = *reinterpret_cast<const f32x4*>(p.bias + col + 4);
+    for (int mi = 0; mi < 8; ++mi)
 #pragma unroll
-          for (int e = 0; e < 4; ++e) { v[e] += b0[e]; v[4 + e] += b1[e]; }
-        }
-        if (p.ubias) {
-          const float* ub = p.ubias + (int64_t)(m / p.T) * p.ldub + col;
+      for (int ni = 0; ni < 4; ++ni) acc[mi][ni] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+    bf16x8 b0[4], b1[4], a0[4], a1[4];
+    auto ldB = [&](const char* st, bf16x8* dst, uint32_t coff) {
 #pragma unroll
-          for (int e = 0; e < 8; ++e) v[e] += ub[e];
-        }
+      for (int ni = 0; ni < 4; ++ni) dst[ni] = *reinterpret_cast<const bf16x8*>(st + b_base + ni * 2048 + coff);
+    };
+    auto ldA = [&](const char* st, bf16x8* dst, int mh, uint32_t coff) {
+#pragma unroll
+      for (int mi = 0; mi < 4; ++mi) dst[mi] = *reinterpret_cast<const bf16x8*>(st + a_base + (mh * 4 + mi) * 2048 + coff);
+    };
+    // 16 MFMAs of one sub-phase in two halves: the fragment reads of the NEXT sub-phase are issued between
+    // the halves, so they complete under the second half instead of being waited for right after issue.
+    // The WEIGHT fragment is the MFMA's row operand: a lane then holds 4 CONSECUTIVE output columns
+    // (fq*4 + r) of one output row (fr), which the epilogue packs into one 8-byte LDS write.
+    auto mma_half = [&](const bf16x8* af, const bf16x8* bf, int mh, int part) {
+      __builtin_amdgcn_s_setprio(1);
+#pragma unroll
+      for (int mi = 2 * part; mi < 2 * part + 2; ++mi)
+#pragma unroll
+        for (int ni = 0; ni < 4; ++ni)
+          acc[mh * 4 + mi][ni] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(bf[ni], af[mi], acc[mh * 4 + mi][ni], 0, 0, 0);
+      __builtin_amdgcn_s_setprio(0);
+    };
+
+    // Software pipeline over the K-tiles, one barrier per K-tile placed BEFORE the last MFMA sub-phase:
+    //   P0 P1 P2 | own reads of tile t done, own DMA of tile t+1 landed, barrier |
+    //   issue DMA of tile t+2 into the stage just freed, prefetch tile t+1's first fragments | P3
+    // The two waves that share a SIMD issue their DMA at different points (before / after P3).
+    issue(0, 0);
+    if (nk > 1) {
+      issue(1, 1);
+      asm volatile("s_waitcnt vmcnt(8)" ::: "memory");      // K-step 0 and the epilogue parameters have landed
+    } else {
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    }
+    if (tid < BN2) { par[tid] = pb; par[BN2 + tid] = psc; par[2 * BN2 + tid] = psh; }
+    __builtin_amdgcn_s_barrier();
+    ldB(smem, b0, c0);
+    ldA(smem, a0, 0, c0);
+    for (int t = 0; t < nk; ++t) {
+      const char* st = smem + (t & 1) * STAGE2;
+      __builtin_amdgcn_sched_barrier(0);
+      mma_half(a0, b0, 0, 0);                           // P0
+      __builtin_amdgcn_sched_barrier(0);
+      ldA(st, a1, 1, c0);
+      __builtin_amdgcn_sched_barrier(0);
+      mma_half(a0, b0, 0, 1);
+      __builtin_amdgcn_sched_barrier(0);
+      mma_half(a1, b0, 1, 0);                           // P1
+      __builtin_amdgcn_sched_barrier(0);
+      ldB(st, b1, c1);
+      ldA(st, a0, 0, c1);
+      __builtin_amdgcn_sched_barrier(0);
+      mma_half(a1, b0, 1, 1);
+      __builtin_amdgcn_sched_barrier(0);
+      mma_half(a0, b1, 0, 0);                           // P2
+      __builtin_amdgcn_sched_barrier(0);
+      ldA(st, a1, 1, c1);
+      __builtin_amdgcn_sched_barrier(0);
+      mma_half(a0, b1, 0, 1);
+      __builtin_amdgcn_sched_barrier(0);
+      if (t + 1 < nk) {
+        asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();
+        if (dma_early && t + 2 < nk) issue(t + 2, t & 1);
+        const char* sn = smem + ((t + 1) & 1) * STAGE2;
+        ldB(sn, b0, c0);
+        ldA(sn, a0, 0, c0);
+      }
+      __builtin_amdgcn_sched_barrier(0);
+      mma_half(a1, b1, 1, 0);                           // P3
+      mma_half(a1, b1, 1, 1);
+      __builtin_amdgcn_sched_barrier(0);
+      if (!dma_early && t + 2 < nk) issue(t + 2, t & 1);
+    }
+
+    // ------------------------------------------------------------------ epilogue
+    // bias / ReLU / BN affine run on the accumulators in registers (packed fp32 ops: a lane's 4 values are 4
+    // consecutive columns), the result is rounded to bf16 and written as 8-byte pieces into a [256][256] bf16
+    // image of the tile that takes over both (now idle) pipeline stages; one barrier later all 512 threads copy
+    // the image out, 16 bytes per lane and 512 contiguous bytes per row.  16-byte units of a row are XORed with
+    // (row & 15): conflict-free for the 8-byte writes (16 rows x 2 columns groups per pass) and the 16-byte reads.
+    f32x4 qb[4], qs[4], qt[4];
+#pragma unroll
+    for (int ni = 0; ni < 4; ++ni) {
+      const int c = wn * 64 + ni * 16 + fq * 4;
+      qb[ni] = *reinterpret_cast<const f32x4*>(par + c);
+      qs[ni] = *reinterpret_cast<const f32x4*>(par + BN2 + c);
+      qt[ni] = *reinterpret_cast<const f32x4*>(par + 2 * BN2 + c);
+    }
+    lds_barrier();                                      // every wave is done reading the last stage
+#pragma unroll
+    for (int mi = 0; mi < 8; ++mi) {
+      const int row = wm * 128 + mi * 16 + fr;
+      char* rowp = smem + row * (BN2 * 2);
+#pragma unroll
+      for (int ni = 0; ni < 4; ++ni) {
+        f32x4 v = acc[mi][ni] + qb[ni];
         if (relu) {
 #pragma unroll
-          for (int e = 0; e < 8; ++e) v[e] = fmaxf(v[e], 0.f);
+          for (int e = 0; e < 4; ++e) v[e] = fmaxf(v[e], 0.f);
         }
-        if (p.scale) {
-          const f32x4 s0 = *reinterpret_cast<const f32x4*>(p.scale + col), s1 = *reinterpret_cast<const f32x4*>(p.scale + col + 4);
-          const f32x4 t0 = *reinterpret_cast<const f32x4*>(p.shift + col), t1 = *reinterpret_cast<const f32x4*>(p.shift + col + 4);
+        v = v * qs[ni] + qt[ni];
+        uint2 pk;
+        pk.x = pack2(v[0], v[1]);
+        pk.y = pack2(v[2], v[3]);
+        const int u8 = (wn * 16 + ni * 4 + fq) ^ (fr << 1);            // 8-byte unit inside the 512-byte row
+        *reinterpret_cast<uint2*>(rowp + u8 * 8) = pk;
+      }
+    }
+    lds_barrier();
+    {
+      // 256 rows x 32 chunks of 8 columns; thread -> (row r0 + 16 i, chunk cc): the swizzle term (row & 15) does
+      // not depend on i, so every read is base + i * 8 KiB
+      const int r0 = tid >> 5, cc = tid & 31;
+      const char* src = smem + r0 * (BN2 * 2) + ((cc ^ (r0 & 15)) << 4);
+      bf16_t* dst = p.C + (int64_t)(m0 + r0) * p.ldc + n0 + cc * 8;
+      const int rows_left = p.M - m0 - r0;               // rows r0 + 16 i < rows_left are inside the matrix
 #pragma unroll
-          for (int e = 0; e < 4; ++e) { v[e] = v[e] * s0[e] + t0[e]; v[4 + e] = v[4 + e] * s1[e] + t1[e]; }
-        }
-        if (tnh) {
-#pragma unroll
-          for (int e = 0; e < 8; ++e) v[e] = tanhf(v[e]);
-        }
-        if (p.C32) {
-          float* o = p.C32 + (int64_t)m * p.ldc32 + col;
-          *reinterpret_cast<f32x4*>(o) = f32x4{v[0], v[1], v[2], v[3]};
-          *reinterpret_cast<f32x4*>(o + 4) = f32x4{v[4], v[5], v[6], v[7]};
-        }
-        const u32x4 packed = pack8(v);
-        if (p.C) *reinterpret_cast<u32x4*>(p.C + (int64_t)m * p.ldc + col) = packed;
-        if (stats) {                                           // leave the rounded values in LDS for the column pass
-          float fr8[8];
-          unpack8(packed, fr8);
-          *reinterpret_cast<f32x4*>(ct32 + lrow * CT2_F32 + cc * 8) = f32x4{fr8[0], fr8[1], fr8[2], fr8[3]};
-          *reinterpret_cast<f32x4*>(ct32 + lrow * CT2_F32 + cc * 8 + 4) = f32x4{fr8[4], fr8[5], fr8[6], fr8[7]};
-        }
-        if (p.S) {
-          const u32x4 x = *reinterpret_cast<const u32x4*>(p.X2 + (int64_t)m * p.ldx2 + col);
-          float fv[8], fx[8];
-          unpack8(packed, fv);
-          unpack8(x, fx);
-#pragma unroll
-          for (int e = 0; e < 8; ++e) fv[e] += fx[e];
-          *reinterpret_cast<u32x4*>(p.S + (int64_t)m * p.lds + col) = pack8(fv);
+      for (int i = 0; i < 16; ++i) {
+        if (16 * i < rows_left) {
+          const u32x4 v = *reinterpret_cast<const u32x4*>(src + i * 16 * (BN2 * 2));
+          *reinterpret_cast<u32x4*>(dst + (int64_t)(16 * i) * p.ldc) = v;
         }
       }
     }
-    __syncthreads();
     if (stats) {
-      const int c = tid & 255, hsel = tid >> 8;               // 4 waves per row half
-      const int rlim = min(64, p.M - m0 - q * 64);
-      const int lo = hsel * 32, hi = min(lo + 32, rlim);
-      const float* colp = ct32 + c;
-      // three branch-free runs (one per overlapped segment) so the LDS reads pipeline
-      auto run = [&](int a, int b, float& s1, float& s2) {
+      // fused per-segment column statistics of the STORED (bf16-rounded) output: thread = (column, row half);
+      // a 256-row tile overlaps at most 3 segments (T >= 128), told apart by the tile-local row bounds
+      const int c = tid & 255, hsel = tid >> 8;
+      const int sb1 = (m0 / p.T + 1) * p.T - m0, sb2 = sb1 + p.T;
+      const int lo = hsel * 128, hi = min(lo + 128, p.M - m0);
+      const char* colp = smem + (c & 7) * 2;
+      const int cu = c >> 3;
+      float ss[3], sq[3];
+      auto run = [&](int a, int b, float& s1, float& s2) {      // branch-free body so the LDS reads pipeline
         a = max(a, lo); b = min(b, hi);
         float t1 = 0.f, t2 = 0.f;
 #pragma unroll 8
-        for (int lr = a; lr < b; ++lr) {
-          const float v = colp[lr * CT2_F32];
+        for (int r = a; r < b; ++r) {
+          const uint16_t h = *reinterpret_cast<const uint16_t*>(colp + r * (BN2 * 2) + ((cu ^ (r & 15)) << 4));
+          const float v = __uint_as_float((uint32_t)h << 16);
           t1 += v;
           t2 = fmaf(v, v, t2);
         }
-        s1 += t1; s2 += t2;
+        s1 = t1; s2 = t2;
       };
-      run(0, sb1 - q * 64, ss0, sq0);
-      run(sb1 - q * 64, sb2 - q * 64, ss1, sq1);
-      run(sb2 - q * 64, 64, ss2, sq2);
-      __syncthreads();
+      run(0, sb1, ss[0], sq[0]);
+      run(sb1, sb2, ss[1], sq[1]);
+      run(sb2, BM2, ss[2], sq[2]);
+      float* dst = p.stats_part + ((int64_t)((m0 / BM2) * 2 + hsel) * 3) * p.N + n0 + c;
+      dst[0] = ss[0]; dst[p.N] = ss[1]; dst[2 * (int64_t)p.N] = ss[2];
+      if (p.stats_mode == 2) {
+        float* dq = dst + (int64_t)nbm * 6 * p.N;
+        dq[0] = sq[0]; dq[p.N] = sq[1]; dq[2 * (int64_t)p.N] = sq[2];
+      }
     }
-  }
-  if (stats) {
-    const int c = tid & 255, hsel = tid >> 8;
-    const int64_t nbm_ = (p.M + BM2 - 1) / BM2;
-    float* dst = p.stats_part + ((int64_t)(bm * 2 + hsel) * 3) * p.N + n0 + c;
-    dst[0] = ss0; dst[p.N] = ss1; dst[2 * (int64_t)p.N] = ss2;
-    if (p.stats_mode == 2) {
-      float* dq = dst + nbm_ * 6 * p.N;
-      dq[0] = sq0; dq[p.N] = sq1; dq[2 * (int64_t)p.N] = sq2;
-    }
-  }
+    lds_barrier();                                      // the image is free: the next tile's DMA may overwrite it
+  }   // persistent tile loop
 }
 
 // Combine the per-tile partials of a segment in tile order: mean (mode 1) or mean | std (mode 2).
@@ -562,7 +546,7 @@ extern "C" int sdk_colstats_finish(sdk_ctx* ctx, const float* stats_part, int M,
 
 extern "C" int sdk_set_gemm_variant(int v) {   // tuning knob: 1 = 128^2 register-staged, 2 = 256^2 LDS-DMA (default)
   if (g_gemm_variant < 0)
-    SDK_HIP_OK(hipFuncSetAttribute((const void*)conv_gemm256_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, LDS2));
+    SDK_HIP_OK(hipFuncSetAttribute((const void*)conv_gemm256_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, LDS2_TOTAL));
   g_gemm_variant = v;
   return 0;
 }
@@ -574,6 +558,7 @@ extern "C" int sdk_conv_gemm(sdk_ctx* ctx, const sdk_conv_gemm_args* a, void* st
   SDK_REQUIRE(a->Cin > 0 && a->Cin % BK == 0, "sdk_conv_gemm: Cin=%d must be a multiple of %d", a->Cin, BK);
   SDK_REQUIRE(a->taps >= 1 && (a->taps & 1), "sdk_conv_gemm: taps=%d must be odd", a->taps);
   SDK_REQUIRE(a->T > 0 && a->M % a->T == 0, "sdk_conv_gemm: M=%d must be a multiple of T=%d", a->M, a->T);
+  SDK_REQUIRE((int64_t)a->N * a->taps * a->Cin < (1ll << 31), "sdk_conv_gemm: weight matrix of %d x %d elements exceeds 2^31", a->N, a->taps * a->Cin);
   SDK_REQUIRE(a->taps == 1 || (a->taps / 2) * a->dil < a->T, "sdk_conv_gemm: segment of T=%d frames shorter than the conv halo %d", a->T, (a->taps / 2) * a->dil);
   SDK_REQUIRE(a->lda % 8 == 0 && a->lda >= a->Cin, "sdk_conv_gemm: lda=%lld must be >= Cin and a multiple of 8", (long long)a->lda);
   SDK_REQUIRE(((uintptr_t)a->A % 16) == 0 && ((uintptr_t)a->W % 16) == 0, "sdk_conv_gemm: A/W must be 16-byte aligned");
@@ -586,7 +571,7 @@ extern "C" int sdk_conv_gemm(sdk_ctx* ctx, const sdk_conv_gemm_args* a, void* st
   if (g_gemm_variant < 0) {
     const char* e = getenv("SDK_GEMM_VARIANT");
     g_gemm_variant = e ? atoi(e) : 2;
-    SDK_HIP_OK(hipFuncSetAttribute((const void*)conv_gemm256_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, LDS2));
+    SDK_HIP_OK(hipFuncSetAttribute((const void*)conv_gemm256_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, LDS2_TOTAL));
   }
   Params p;
   p.A = (const bf16_t*)a->A; p.lda = a->lda; p.W = (const bf16_t*)a->W;
@@ -600,7 +585,10 @@ extern "C" int sdk_conv_gemm(sdk_ctx* ctx, const sdk_conv_gemm_args* a, void* st
   if (a->A2) SDK_REQUIRE(a->lda2 % 8 == 0 && a->lda2 >= a->Cin && ((uintptr_t)a->A2 % 16) == 0, "sdk_conv_gemm: bad A2/lda2");
 
   const double kk = (double)a->taps * a->Cin;
-  const bool use256 = (g_gemm_variant & 15) != 1 && a->N % BN2 == 0 && a->M >= BM2 && !a->A2;
+  // the 256^2 kernel covers the plain layer shape (bias / ReLU / BN affine -> bf16, optional column statistics);
+  // fp32 output, residual sum, per-segment bias, tanh and the A2 addend stay with the 128^2 kernel
+  const bool use256 = (g_gemm_variant & 15) != 1 && a->N % BN2 == 0 && a->M >= BM2 && !a->A2 && a->C && !a->C32 && !a->S &&
+                      !a->ubias && !(a->flags & SDK_GEMM_TANH) && (a->taps == 1 || a->T >= 64);
   ProfScope ps(ctx, stream, use256 ? SDK_K_CONV_GEMM256 : SDK_K_CONV_GEMM, 2.0 * a->M * a->N * kk,
                2.0 * a->M * a->Cin + 2.0 * a->N * kk + (a->C ? 2.0 : 0.0) * a->M * a->N + (a->C32 ? 4.0 : 0.0) * a->M * a->N +
                    (a->S ? 4.0 : 0.0) * a->M * a->N);
@@ -610,7 +598,10 @@ extern "C" int sdk_conv_gemm(sdk_ctx* ctx, const sdk_conv_gemm_args* a, void* st
     p.stats_part = a->stats_part; p.stats_mode = a->stats_mode;
   }
   if (use256) {
-    hipLaunchKernelGGL(conv_gemm256_kernel, dim3((a->N / BN2) * ceil_div(a->M, BM2)), dim3(NT2), LDS2, (hipStream_t)stream, p);
+    const int ntiles = (a->N / BN2) * ceil_div(a->M, BM2);
+    const int cus = ctx->num_cu > 0 ? (ctx->num_cu / 8) * 8 : 256;
+    const int grid = (p.tune & 8) ? ntiles : (ntiles < cus ? ntiles : cus);       // tune bit 3: one workgroup per tile (A/B)
+    hipLaunchKernelGGL(conv_gemm256_kernel, dim3(grid), dim3(NT2), LDS2_TOTAL, (hipStream_t)stream, p);
   } else {
     hipLaunchKernelGGL(conv_gemm_kernel, dim3((a->N / BN) * ceil_div(a->M, BM)), dim3(NT), LDS_BYTES, (hipStream_t)stream, p);
   }
