@@ -9,9 +9,10 @@
 // fragment's row address.
 //   LDS: two [TP rows][128 ch] bf16 images (256-B rows, 16-B chunk index XOR (row & 15): the 16 rows of a
 //        ds_read_b128 lane group land on 16 distinct slots whatever the tap shift).
-//   MFMA: 8 waves split the 128 output channels (one 16-column tile each), every wave covers all MT row
-//        tiles: acc = MT x 4 VGPRs; B fragments (weights, L2-resident) are prefetched one whole tap (4
-//        k-steps) ahead; the next chunk of u is prefetched into registers across the conv.
+//   MFMA: 2 x 4 waves: half of the MT row tiles x 32 output channels each, so a frame fragment read from LDS
+//        feeds two MFMAs; weight fragments (L2-resident) are prefetched one whole tap (4 k-steps) ahead;
+//        the weight fragment is the row operand, so the epilogue packs 4 channels into one 8-byte LDS write;
+//        the next chunk of u is prefetched into registers across the conv.
 //   Arithmetic order is identical to seven conv_gemm launches (tap-major, 32-wide k-steps, fp32 epilogue,
 //   bf16 rounding points), so results are bit-identical to the unfused schedule.
 #include "common.hpp"
@@ -19,6 +20,7 @@
 namespace {
 
 constexpr int RS = 128;                  // sub-band width (channels per Res2Net chunk)
+constexpr int PAR_BYTES = 7 * 3 * RS * 4;   // LDS table of the convs' epilogue parameters
 constexpr int RNT = 512;                 // 8 waves: two per SIMD, each owns one 16-column output tile
 
 struct ChainParams {
@@ -41,6 +43,12 @@ __global__ __launch_bounds__(RNT, 2) void res2net_chain_kernel(ChainParams p) {
 
   auto lds_off = [](int row, int ch16) { return row * 256 + ((ch16 ^ (row & 15)) << 4); };
 
+  // bias / scale / shift of the (up to) seven convs: [7][3][128] fp32 behind the two images
+  float* par = reinterpret_cast<float*>(smem + 2 * TP * 256);
+  for (int i = tid; i < p.nconv * 3 * RS; i += RNT) {
+    const int cc = i / (3 * RS), w = (i / RS) % 3, ch = i % RS;
+    par[i] = (w == 0 ? p.bias[cc] : w == 1 ? p.scale[cc] : p.shift[cc])[ch];
+  }
   // ---- s_1 = u_1 -> buf 0
   {
     char* b0 = smem;
@@ -53,10 +61,19 @@ __global__ __launch_bounds__(RNT, 2) void res2net_chain_kernel(ChainParams p) {
     }
   }
 
-  const int64_t wofs = (int64_t)(wn * 16 + fr) * (3 * RS) + fq * 8;
-  bf16x8 bcur[4];
+  // 2 x 4 waves: wave (wm, wq) owns row tiles [wm*MH, wm*MH + MH) and the 32 output channels [32 wq, 32 wq + 32).
+  // The WEIGHT fragment is the MFMA's row operand, so a lane ends up with 4 consecutive channels of one frame.
+  const int wm = wn >> 2, wq = wn & 3;
+  constexpr int MH = (MT + 1) / 2;
+  const int mt0 = wm * MH;
+  const int64_t wofs0 = (int64_t)(wq * 32 + fr) * (3 * RS) + fq * 8;
+  const int64_t wofs1 = wofs0 + (int64_t)16 * (3 * RS);
+  bf16x8 bcur[2][4];
 #pragma unroll
-  for (int ks = 0; ks < 4; ++ks) bcur[ks] = *reinterpret_cast<const bf16x8*>(p.W[0] + wofs + ks * 32);
+  for (int ks = 0; ks < 4; ++ks) {
+    bcur[0][ks] = *reinterpret_cast<const bf16x8*>(p.W[0] + wofs0 + ks * 32);
+    bcur[1][ks] = *reinterpret_cast<const bf16x8*>(p.W[0] + wofs1 + ks * 32);
+  }
   for (int c = 1; c <= p.nconv; ++c) {
     const char* cur = smem + ((c - 1) & 1) * (TP * 256);
     char* nxt = smem + (c & 1) * (TP * 256);
@@ -72,47 +89,64 @@ __global__ __launch_bounds__(RNT, 2) void res2net_chain_kernel(ChainParams p) {
       }
     }
     // ---- conv c: [TP x 384] x [384 x 128]
-    f32x4 acc[MT];
+    f32x4 acc[MH][2];
 #pragma unroll
-    for (int mi = 0; mi < MT; ++mi) acc[mi] = f32x4{0.f, 0.f, 0.f, 0.f};
-    const bf16_t* Wc = p.W[c - 1] + wofs;
-    bf16x8 bnext[4];                                         // one tap (4 k-steps of 32) of weights ahead
+    for (int mi = 0; mi < MH; ++mi) acc[mi][0] = acc[mi][1] = f32x4{0.f, 0.f, 0.f, 0.f};
+    const bf16_t* Wc = p.W[c - 1];
+    bf16x8 bnext[2][4];                                      // one tap (4 k-steps of 32) of weights ahead
 #pragma unroll 1
     for (int j = 0; j < 3; ++j) {
       const int off = (j - 1) * p.dil;
       // next tap of this conv, or tap 0 of the next conv (its latency hides under the epilogue and the y pass)
-      const bf16_t* Wn = j < 2 ? Wc + (j + 1) * RS : (c < p.nconv ? p.W[c] + wofs : Wc);
+      const bf16_t* Wn = j < 2 ? Wc + (j + 1) * RS : (c < p.nconv ? p.W[c] : Wc);
 #pragma unroll
-      for (int ks = 0; ks < 4; ++ks) bnext[ks] = *reinterpret_cast<const bf16x8*>(Wn + ks * 32);
-      int rr[MT];
+      for (int ks = 0; ks < 4; ++ks) {
+        bnext[0][ks] = *reinterpret_cast<const bf16x8*>(Wn + wofs0 + ks * 32);
+        bnext[1][ks] = *reinterpret_cast<const bf16x8*>(Wn + wofs1 + ks * 32);
+      }
+      int rr[MH];
 #pragma unroll
-      for (int mi = 0; mi < MT; ++mi) rr[mi] = reflect_idx(mi * 16 + fr + off, T);
+      for (int mi = 0; mi < MH; ++mi) rr[mi] = reflect_idx(min((mt0 + mi) * 16 + fr, TP - 1) + off, T);
 #pragma unroll
       for (int ks = 0; ks < 4; ++ks) {
 #pragma unroll
-        for (int mi = 0; mi < MT; ++mi) {
-          const bf16x8 a = *reinterpret_cast<const bf16x8*>(cur + rr[mi] * 256 + (((ks * 4 + fq) ^ (rr[mi] & 15)) << 4));
-          acc[mi] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, bcur[ks], acc[mi], 0, 0, 0);
+        for (int mi = 0; mi < MH; ++mi) {
+          if (mt0 + mi < MT) {                               // wave-uniform: the second row half has MT - MH tiles
+            const bf16x8 a = *reinterpret_cast<const bf16x8*>(cur + rr[mi] * 256 + (((ks * 4 + fq) ^ (rr[mi] & 15)) << 4));
+            acc[mi][0] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(bcur[0][ks], a, acc[mi][0], 0, 0, 0);
+            acc[mi][1] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(bcur[1][ks], a, acc[mi][1], 0, 0, 0);
+          }
         }
       }
 #pragma unroll
-      for (int ks = 0; ks < 4; ++ks) bcur[ks] = bnext[ks];
+      for (int ks = 0; ks < 4; ++ks) { bcur[0][ks] = bnext[0][ks]; bcur[1][ks] = bnext[1][ks]; }
     }
-    // ---- epilogue: y_c = bf16(relu(acc + bias) * scale + shift) -> the free image
-    {
-      const int col = wn * 16 + fr;
-      const float cb = p.bias[c - 1][col], cs = p.scale[c - 1][col], ct = p.shift[c - 1][col];
-      const int ch16 = col >> 3, e = col & 7;
+    // ---- epilogue: y_c = bf16(relu(acc + bias) * scale + shift) -> the free image, 8 bytes (4 channels) per write
+    f32x4 cb[2], cs[2], ct[2];
 #pragma unroll
-      for (int mi = 0; mi < MT; ++mi)
+    for (int h = 0; h < 2; ++h) {
+      const float* q = par + (c - 1) * (3 * RS) + wq * 32 + h * 16 + fq * 4;
+      cb[h] = *reinterpret_cast<const f32x4*>(q);
+      cs[h] = *reinterpret_cast<const f32x4*>(q + RS);
+      ct[h] = *reinterpret_cast<const f32x4*>(q + 2 * RS);
+    }
 #pragma unroll
-        for (int r = 0; r < 4; ++r) {
-          const int row = mi * 16 + fq * 4 + r;
-          if (row < T) {
-            const float v = fmaxf(acc[mi][r] + cb, 0.f) * cs + ct;
-            *reinterpret_cast<bf16_t*>(nxt + lds_off(row, ch16) + e * 2) = f32_to_bf16(v);
-          }
+    for (int mi = 0; mi < MH; ++mi) {
+      const int row = (mt0 + mi) * 16 + fr;
+      if (mt0 + mi < MT && row < T) {
+#pragma unroll
+        for (int h = 0; h < 2; ++h) {
+          f32x4 v = acc[mi][h] + cb[h];
+#pragma unroll
+          for (int e = 0; e < 4; ++e) v[e] = fmaxf(v[e], 0.f);
+          v = v * cs[h] + ct[h];
+          uint2 pk;
+          pk.x = pack2(v[0], v[1]);
+          pk.y = pack2(v[2], v[3]);
+          const int ch16 = wq * 4 + h * 2 + (fq >> 1);
+          *reinterpret_cast<uint2*>(nxt + lds_off(row, ch16) + (fq & 1) * 8) = pk;
         }
+      }
     }
     __syncthreads();                                        // y_c complete in `nxt`; every read of `cur` is done
     // ---- y_c -> HBM; s_{c+1} = bf16(y_c + u_{c+1}) in place
@@ -157,12 +191,12 @@ extern "C" int sdk_res2net_chain(sdk_ctx* ctx, const uint16_t* U, int64_t ldu, u
   ProfScope ps(ctx, stream, SDK_K_RES2NET, 2.0 * B * T * (double)RS * 3 * RS * nconv, 2.0 * 2.0 * B * T * RS * nconv);
   static bool attr_set = false;
   if (!attr_set) {
-    SDK_HIP_OK(hipFuncSetAttribute((const void*)res2net_chain_kernel<13>, hipFuncAttributeMaxDynamicSharedMemorySize, 2 * 208 * 256));
-    SDK_HIP_OK(hipFuncSetAttribute((const void*)res2net_chain_kernel<7>, hipFuncAttributeMaxDynamicSharedMemorySize, 2 * 112 * 256));
+    SDK_HIP_OK(hipFuncSetAttribute((const void*)res2net_chain_kernel<13>, hipFuncAttributeMaxDynamicSharedMemorySize, 2 * 208 * 256 + PAR_BYTES));
+    SDK_HIP_OK(hipFuncSetAttribute((const void*)res2net_chain_kernel<7>, hipFuncAttributeMaxDynamicSharedMemorySize, 2 * 112 * 256 + PAR_BYTES));
     attr_set = true;
   }
-  if (T <= 112) hipLaunchKernelGGL(res2net_chain_kernel<7>, dim3(B), dim3(RNT), 2 * 112 * 256, (hipStream_t)stream, p);
-  else hipLaunchKernelGGL(res2net_chain_kernel<13>, dim3(B), dim3(RNT), 2 * 208 * 256, (hipStream_t)stream, p);
+  if (T <= 112) hipLaunchKernelGGL(res2net_chain_kernel<7>, dim3(B), dim3(RNT), 2 * 112 * 256 + PAR_BYTES, (hipStream_t)stream, p);
+  else hipLaunchKernelGGL(res2net_chain_kernel<13>, dim3(B), dim3(RNT), 2 * 208 * 256 + PAR_BYTES, (hipStream_t)stream, p);
   SDK_LAUNCH_CHECK();
   return 0;
 }
