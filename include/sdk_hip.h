@@ -57,13 +57,13 @@ int sdk_set_option(sdk_ctx* ctx, const char* name, int value);
 enum {
   SDK_K_CONV_GEMM = 0, SDK_K_SE_GATE, SDK_K_ASP_STATS, SDK_K_ROWS_FC, SDK_K_ASP_POOL, SDK_K_FBANK_TILE,
   SDK_K_FBANK_NORM, SDK_K_L2NORM, SDK_K_AFF_COARSE, SDK_K_AFF_RESCORE, SDK_K_AFF_RESCAN, SDK_K_COPY,
-  SDK_K_AFF_MATVEC, SDK_K_CONV_GEMM256, SDK_K_ASP_FUSED, SDK_K_RES2NET, SDK_K_COUNT
+  SDK_K_AFF_MATVEC, SDK_K_CONV_GEMM256, SDK_K_ASP_FUSED, SDK_K_RES2NET, SDK_K_RESAMPLE, SDK_K_COUNT
 };
 typedef struct sdk_profile_report {
-  int32_t launches[16];
-  double ms[16];          /* summed device time of the family's launches */
-  double flops[16];       /* executed flops as launched (2*M*N*K for GEMMs) */
-  double bytes[16];       /* compulsory bytes as launched (inputs once + outputs once) */
+  int32_t launches[24];
+  double ms[24];          /* summed device time of the family's launches */
+  double flops[24];       /* executed flops as launched (2*M*N*K for GEMMs) */
+  double bytes[24];       /* compulsory bytes as launched (inputs once + outputs once) */
 } sdk_profile_report;
 int sdk_profile_begin(sdk_ctx* ctx);
 int sdk_profile_end(sdk_ctx* ctx, sdk_profile_report* out);   /* synchronises the device */
@@ -177,6 +177,16 @@ size_t sdk_ecapa_workspace_bytes(const sdk_ecapa_desc* d, int B, int T);
 int sdk_ecapa_forward(sdk_ctx* ctx, const void* wblob, const sdk_ecapa_desc* wdesc,
                       const uint16_t* feats, int ldf, int B, int T,
                       void* ws, size_t ws_bytes, float* emb, void* stream);
+
+/* ---- audio conversion to the AudioProfile: replaces the ffmpeg subprocess the reference's backends
+ *      run before upload (audio_profiles.py:70-100 `format_ffmpeg_args`; speechmatics_backend.py:231-281).
+ *      x [n_in, channels] s16 interleaved -> y [n_out] s16 mono at rate_in * L / M, n_out = ceil(n_in * L / M).
+ *      Channel down-mix (rounded mean) + polyphase FIR, integer arithmetic: taps [L][K] int32 Q30 (device memory,
+ *      designed by the host layer, every phase summing to 2^30), int64 accumulation, round-half-up, s16 saturation;
+ *      samples outside the input are zero.  Bit-exact against oracle/resample.py. -- */
+int64_t sdk_resample_out_len(int64_t n_in, int L, int M);
+int sdk_resample_s16(sdk_ctx* ctx, const int16_t* x, int64_t n_in, int channels, const int32_t* taps, int L, int M, int K,
+                     int16_t* y, int64_t n_out, void* stream);
 
 /* ---- k3: L2-normalise rows.  X [N, d] fp32 -> E fp32 unit rows, Eb bf16 copy,
  *      resid[n] = || E[n] - float(Eb[n]) ||_2 (rigorous per-row bf16 rounding residual). -- */

@@ -46,11 +46,11 @@ class EcapaDesc(C.Structure):
 
 
 class ProfileReport(C.Structure):
-    _fields_ = [("launches", C.c_int32 * 16), ("ms", C.c_double * 16), ("flops", C.c_double * 16), ("bytes", C.c_double * 16)]
+    _fields_ = [("launches", C.c_int32 * 24), ("ms", C.c_double * 24), ("flops", C.c_double * 24), ("bytes", C.c_double * 24)]
 
 
 KERNEL_FAMILIES = ["conv_gemm", "se_gate", "asp_stats", "rows_fc", "asp_pool", "fbank_tile", "fbank_norm", "l2norm",
-                   "affinity_coarse", "affinity_rescore", "affinity_rescan", "copy", "affinity_matvec", "conv_gemm256", "asp_fused", "res2net_chain"]
+                   "affinity_coarse", "affinity_rescore", "affinity_rescan", "copy", "affinity_matvec", "conv_gemm256", "asp_fused", "res2net_chain", "resample"]
 
 GEMM_RELU = 1
 GEMM_TANH = 2
@@ -87,6 +87,8 @@ SIGNATURES = {
     "sdk_asp_fused": (_i, [_vp, _vp, _i64, _vp, _vp, _vp, _i64, _i, _i, _i, _i, _vp, _vp]),
     "sdk_ecapa_workspace_bytes": (_sz, [C.POINTER(EcapaDesc), _i, _i]),
     "sdk_ecapa_forward": (_i, [_vp, _vp, C.POINTER(EcapaDesc), _vp, _i, _i, _i, _vp, _sz, _vp, _vp]),
+    "sdk_resample_out_len": (_i64, [_i64, _i, _i]),
+    "sdk_resample_s16": (_i, [_vp, _vp, _i64, _i, _vp, _i, _i, _i, _vp, _i64, _vp]),
     "sdk_l2norm": (_i, [_vp, _vp, _i, _i, _vp, _vp, _vp, _vp]),
     "sdk_affinity_workspace_bytes": (_sz, [_i, _i]),
     "sdk_affinity_matvec_workspace_bytes": (_sz, [_i]),

@@ -25,7 +25,7 @@ import numpy as np
 from . import BACKEND_NAME
 from .plugin_api import EmbeddingBackend
 from .store import load_profile_batch, save_vector, vector_path
-from .wav import cut_windows, read_wav_s16
+from .wav import cut_windows, decode_to_profile
 from .weights import DEFAULT_CONFIG, load_weights, synthetic_weights, weights_digest
 
 
@@ -90,7 +90,7 @@ class Backend(EmbeddingBackend):
         return eng.embed_pcm(torch.from_numpy(np.ascontiguousarray(pcm)).to(eng.device))
 
     def _windows(self, audio_path: Path, segments):
-        samples = read_wav_s16(Path(audio_path), self.get_audio_profile())
+        samples = decode_to_profile(Path(audio_path), self.engine(), self.get_audio_profile())   # other rates / layouts: GPU resampler
         pcm, spans = cut_windows(samples, segments, window_s=self.window_s, hop_s=self.hop_s)
         if len(spans) == 0:
             raise ValueError(f"{audio_path}: no analysable audio (every segment shorter than 0.5 s)")

@@ -91,7 +91,7 @@ extern "C" int sdk_profile_end(sdk_ctx* ctx, sdk_profile_report* out) {
   for (auto& r : ctx->prof) {
     float ms = 0.f;
     SDK_HIP_OK(hipEventElapsedTime(&ms, r.a, r.b));
-    if (r.family >= 0 && r.family < 16) {
+    if (r.family >= 0 && r.family < SDK_K_COUNT) {
       out->launches[r.family] += 1;
       out->ms[r.family] += ms;
       out->flops[r.family] += r.flops;

@@ -14,7 +14,7 @@ from typing import Dict, Optional, Tuple
 import numpy as np
 import torch
 
-from . import _lib
+from . import _lib, resample
 from ._lib import ConvGemmArgs, EcapaDesc, SdkError, check
 from .weights import DEFAULT_CONFIG, EcapaConfig, synthetic_weights
 from .weights_pack import N_MELS_PADDED, pack_weights
@@ -58,6 +58,7 @@ class Engine:
         self._scratch: Dict[str, torch.Tensor] = {}
         self._graphs: Dict[tuple, tuple] = {}
         self._streams = []
+        self._taps: Dict[tuple, torch.Tensor] = {}
 
     # ------------------------------------------------------------------ resident state
     def _scratch_bytes(self, key: str, nbytes: int) -> torch.Tensor:
@@ -111,6 +112,24 @@ class Engine:
         check(self.lib.sdk_profile_end(self.ctx, C.byref(rep)), "sdk_profile_end")
         return {name: {"launches": rep.launches[i], "ms": rep.ms[i], "flops": rep.flops[i], "bytes": rep.bytes[i]}
                 for i, name in enumerate(_lib.KERNEL_FAMILIES) if rep.launches[i]}
+
+    # ------------------------------------------------------------------ audio conversion
+    def resample_s16(self, x: torch.Tensor, rate_in: int, rate_out: int = 16000) -> torch.Tensor:
+        """x int16 [n] or [n, C] interleaved (device) at rate_in -> mono int16 [ceil(n*L/M)] at rate_out."""
+        _need(x, torch.int16, "x")
+        x = x.contiguous()
+        n_in = x.shape[0]
+        ch = 1 if x.dim() == 1 else x.shape[1]
+        taps, L, M, K = resample.design_taps(int(rate_in), int(rate_out))
+        key = (int(rate_in), int(rate_out))
+        tdev = self._taps.get(key)
+        if tdev is None:
+            tdev = self._taps[key] = torch.from_numpy(np.array(taps)).to(self.device)
+        n_out = resample.out_len(n_in, L, M)
+        y = torch.empty((n_out,), dtype=torch.int16, device=self.device)
+        check(self.lib.sdk_resample_s16(self.ctx, x.data_ptr(), n_in, ch, tdev.data_ptr(), L, M, K, y.data_ptr(), n_out, _stream()),
+              "sdk_resample_s16")
+        return y
 
     # ------------------------------------------------------------------ k1
     def fbank(self, pcm: torch.Tensor, ldf: int = N_MELS_PADDED) -> torch.Tensor:

@@ -1,8 +1,10 @@
-"""Minimal RIFF/WAVE reader for the backend's input contract (16 kHz mono s16le PCM,
-speaker_detection_backends/audio_profiles.py:25-29).  The reference cuts segments with an ffmpeg
-subprocess (speechmatics_backend.py:231-281); here the file is read once and segments are sliced
-from the sample array.  Anything that is not already in the contract format is rejected with the
-ffmpeg command line that produces it (the toolkit's own conversion step)."""
+"""RIFF/WAVE reader for the backend's input contract (16 kHz mono s16le PCM,
+speaker_detection_backends/audio_profiles.py:25-29).  The reference converts and cuts audio with ffmpeg
+subprocesses (speechmatics_backend.py:231-281; speaker_samples:280-326); here the file is read once, segments are
+sliced from the sample array, and a WAVE file in another PCM layout (8/16/24/32-bit integer, 32/64-bit float, any
+channel count, any sample rate) is converted on the GPU (`Engine.resample_s16`).  `read_wav_s16` is the strict
+reader (contract format only); anything that is not RIFF/WAVE PCM is rejected with the ffmpeg command line that
+produces the contract format (the toolkit's own conversion step)."""
 from __future__ import annotations
 
 import struct
@@ -41,6 +43,82 @@ def read_wav_s16(path: Path, profile: Optional[AudioProfile] = None) -> np.ndarr
             f"{path}: {rate} Hz / {ch} ch / {bits} bit (tag {tag}) does not match the backend's audio profile; "
             f"convert with: ffmpeg -i IN {' '.join(format_ffmpeg_args(profile))} OUT.wav")
     return np.frombuffer(pcm[:len(pcm) // 2 * 2], dtype="<i2").astype(np.int16, copy=False)
+
+
+def _chunks(path: Path, profile: AudioProfile):
+    data = Path(path).read_bytes()
+    if len(data) < 12 or data[:4] != b"RIFF" or data[8:12] != b"WAVE":
+        raise AudioFormatError(f"{path}: not a RIFF/WAVE file; convert with: ffmpeg -i IN {' '.join(format_ffmpeg_args(profile))} OUT.wav")
+    pos, fmt, pcm = 12, None, None
+    while pos + 8 <= len(data):
+        cid, size = data[pos:pos + 4], struct.unpack("<I", data[pos + 4:pos + 8])[0]
+        body = data[pos + 8:pos + 8 + size]
+        if cid == b"fmt ":
+            fmt = body
+        elif cid == b"data":
+            pcm = body
+        pos += 8 + size + (size & 1)
+    if fmt is None or pcm is None or len(fmt) < 16:
+        raise AudioFormatError(f"{path}: missing fmt/data chunk")
+    return fmt, pcm
+
+
+def samples_to_s16(raw: np.ndarray, kind: str) -> np.ndarray:
+    """Integer / float sample formats -> s16: keep the top 16 bits, round half up on the dropped ones, saturate."""
+    if kind == "u8":
+        return ((raw.astype(np.int32) - 128) << 8).astype(np.int16)
+    if kind == "s16":
+        return raw.astype(np.int16, copy=False)
+    if kind == "s24":
+        return np.clip((raw.astype(np.int64) + 128) >> 8, -32768, 32767).astype(np.int16)
+    if kind == "s32":
+        return np.clip((raw.astype(np.int64) + 32768) >> 16, -32768, 32767).astype(np.int16)
+    if kind in ("f32", "f64"):
+        return np.clip(np.floor(raw.astype(np.float64) * 32768.0 + 0.5), -32768, 32767).astype(np.int16)
+    raise AudioFormatError(f"unsupported sample format {kind}")
+
+
+def read_wav(path: Path, profile: Optional[AudioProfile] = None) -> Tuple[np.ndarray, int]:
+    """Any PCM RIFF/WAVE -> (int16 [n, channels], sample_rate)."""
+    profile = profile or AudioProfile()
+    fmt, pcm = _chunks(Path(path), profile)
+    tag, ch, rate, _, align, bits = struct.unpack("<HHIIHH", fmt[:16])
+    if tag == 0xFFFE and len(fmt) >= 26:                      # WAVE_FORMAT_EXTENSIBLE: the sub-format GUID starts with the real tag
+        tag = struct.unpack("<H", fmt[24:26])[0]
+    if ch < 1 or rate < 1:
+        raise AudioFormatError(f"{path}: {ch} channels at {rate} Hz")
+    if tag == 1 and bits in (8, 16, 24, 32):
+        if bits == 8:
+            raw, kind = np.frombuffer(pcm, dtype=np.uint8), "u8"
+        elif bits == 16:
+            raw, kind = np.frombuffer(pcm[:len(pcm) // 2 * 2], dtype="<i2"), "s16"
+        elif bits == 24:
+            b = np.frombuffer(pcm[:len(pcm) // 3 * 3], dtype=np.uint8).reshape(-1, 3).astype(np.int32)
+            raw, kind = ((b[:, 0] | (b[:, 1] << 8) | (b[:, 2] << 16)) ^ 0x800000) - 0x800000, "s24"
+        else:
+            raw, kind = np.frombuffer(pcm[:len(pcm) // 4 * 4], dtype="<i4"), "s32"
+    elif tag == 3 and bits in (32, 64):
+        raw, kind = np.frombuffer(pcm[:len(pcm) // (bits // 8) * (bits // 8)], dtype="<f4" if bits == 32 else "<f8"), f"f{bits}"
+    else:
+        raise AudioFormatError(
+            f"{path}: WAVE format tag {tag} / {bits} bit is not linear PCM; convert with: ffmpeg -i IN {' '.join(format_ffmpeg_args(profile))} OUT.wav")
+    s16 = samples_to_s16(raw, kind)
+    n = len(s16) // ch
+    return s16[:n * ch].reshape(n, ch), int(rate)
+
+
+def decode_to_profile(path: Path, engine, profile: Optional[AudioProfile] = None) -> np.ndarray:
+    """WAVE file -> mono int16 samples at the profile's rate.  Files already in the contract format are returned as
+    read; anything else is down-mixed and resampled on the GPU (`sdk_resample_s16`, integer polyphase FIR)."""
+    import torch
+    profile = profile or AudioProfile()
+    x, rate = read_wav(path, profile)
+    if rate == profile.sample_rate and x.shape[1] == profile.channels == 1:
+        return np.ascontiguousarray(x[:, 0])
+    if x.shape[0] == 0:
+        return np.zeros((0,), dtype=np.int16)
+    y = engine.resample_s16(torch.from_numpy(np.ascontiguousarray(x)).to(engine.device), rate, profile.sample_rate)
+    return y.cpu().numpy()
 
 
 def write_wav_s16(path: Path, samples: np.ndarray, rate: int = 16000) -> None:

@@ -31,7 +31,7 @@ def test_library_exports_every_declared_symbol():
 
 def test_struct_layouts_match_header():
     assert C.sizeof(LIB.EcapaDesc) == 14 * 4 + 256 * 8
-    assert C.sizeof(LIB.ProfileReport) == 16 * 4 + 3 * 16 * 8
+    assert C.sizeof(LIB.ProfileReport) == 24 * 4 + 3 * 24 * 8
     assert C.sizeof(LIB.ConvGemmArgs) == 16 * 8 + 8 * 4 + 8 + 16  # 16 pointer/int64 slots, 6 ints + flags + stats_mode, stats_part, A2 + lda2
 
 
