@@ -49,7 +49,8 @@ int sdk_init(int device, sdk_ctx** out);
 int sdk_shutdown(sdk_ctx* ctx);
 const char* sdk_last_error(void);
 int sdk_get_device_info(sdk_ctx* ctx, sdk_device_info* out);
-/* A/B and test knobs: "res2net_chain_fusion" (1 default / 0 = seven conv_gemm launches), "gemm_variant" (see
+/* A/B and test knobs: "res2net_chain_fusion" (1 default / 0 = seven conv_gemm launches), "asp_per_segment" (1 default /
+ * 0 = one workgroup per (segment, 128 channels)), "gemm_variant" (see
  * sdk_set_gemm_variant).  Results do not depend on them. */
 int sdk_set_option(sdk_ctx* ctx, const char* name, int value);
 

@@ -29,6 +29,7 @@ struct sdk_ctx {
   hipDeviceProp_t prop;
   bool prof_on = false;
   bool no_chain_fusion = false;   // A/B + test knob: run the Res2Net chain as separate conv_gemm launches
+  bool no_asp_seg = false;        // A/B + test knob: ASP by (segment, 128-channel) workgroups instead of one per segment
   std::vector<sdk_prof_rec> prof;
 };
 

@@ -514,6 +514,232 @@ __global__ __launch_bounds__(NT, 2) void asp_fused_kernel(const bf16_t* __restri
 }
 
 // ------------------------------------------------------------------------------------------
+// The same computation, one workgroup (8 waves) per SEGMENT: the attention-hidden tile is loaded into LDS once
+// per segment instead of once per 128 channels (24 reads of the same 51 KB per segment otherwise), and every
+// wave walks its own share of the 32-channel blocks without any workgroup barrier: MFMA logits -> softmax over
+// frames in registers -> weighted moments against the wave's PRIVATE [208 x 32] slab of h in LDS.  The next
+// block's slab and W2 rows are in flight (registers) while the current block is reduced, and the matrix phase of
+// one wave overlaps the vector phase of the other wave on its SIMD.
+//   LDS: hidden tile 224 x 256 B (16-B chunk index XOR (row & 15)) + 8 x (208 x 64 B) slabs (chunk XOR
+//        ((row >> 2) & 3): the two half-waves read rows 4 apart) = 163 840 B, all of a CU's LDS.
+// Arithmetic and its order are those of asp_fused_kernel<7>: results are bit-identical.
+constexpr int SEG_ROWS = 208;                 // frames a private h slab holds (T <= 208)
+constexpr int SEG_NT = 512;
+constexpr int SEG_HID_ROWS = 224;               // 7 MFMA row tiles of 32; rows >= T are zero
+constexpr int SEG_HID_BYTES = SEG_HID_ROWS * 256;
+constexpr int SEG_SLAB_BYTES = SEG_ROWS * 64;
+constexpr int SEG_LDS = SEG_HID_BYTES + 8 * SEG_SLAB_BYTES;
+
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+typedef const void __attribute__((address_space(1)))* seg_gptr_t;
+typedef void __attribute__((address_space(3)))* seg_lptr_t;
+
+__global__ __launch_bounds__(SEG_NT, 2) void asp_seg_kernel(const bf16_t* __restrict__ ah, int64_t ldah,
+                                                           const bf16_t* __restrict__ w2, const bf16_t* __restrict__ h,
+                                                           int64_t ldh, int T, int C, float* __restrict__ pooled, int dbg) {
+  extern __shared__ __attribute__((aligned(16))) char lds[];
+  constexpr int NTILES = 7;
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wid = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int col = lane & 31, hh = lane >> 5;
+  const int seg = blockIdx.x;
+  const int64_t base = (int64_t)seg * T;
+
+  // ---- attention-hidden tile -> LDS, once per segment (rows >= T are zero)
+  for (int id = tid; id < SEG_HID_ROWS * 16; id += SEG_NT) {
+    const int r = id >> 4, c = id & 15;
+    u32x4 v = {0u, 0u, 0u, 0u};
+    if (r < T) v = *reinterpret_cast<const u32x4*>(ah + (base + r) * ldah + c * 8);
+    *reinterpret_cast<u32x4*>(lds + r * 256 + ((c ^ (r & 15)) << 4)) = v;
+  }
+  char* slab = lds + SEG_HID_BYTES + wid * SEG_SLAB_BYTES;
+  const int nblk = C / 32;                                   // 32-channel blocks; wave w takes blocks w, w + 8, ...
+  constexpr int HP = SEG_ROWS / 16;                          // 13 slab pieces: 16 rows x 4 chunks of 16 B per wave instruction
+  const int lrow = lane >> 2, lch = lane & 3;
+  // rows T..207 of the private slab are never written by the DMA below: make them finite (their weight is 0)
+#pragma unroll
+  for (int i = 0; i < HP; ++i) {
+    const int r = i * 16 + lrow;
+    if (r >= T) *reinterpret_cast<u32x4*>(slab + r * 64 + lch * 16) = u32x4{0u, 0u, 0u, 0u};
+  }
+
+  // slab of h [T x 32 channels] by LDS-DMA straight into the wave's region: LDS position (row, lch) receives the
+  // SOURCE chunk lch ^ ((row >> 2) & 3), so the two half-waves (rows 4 apart) later read different banks
+  // ((row >> 2) & 3) == ((lrow >> 2) & 3) for every piece (16 i does not reach those bits): one per-lane offset,
+  // the piece index only moves the wave-uniform base
+  const uint32_t voff = (uint32_t)(lrow * ldh + ((lch ^ ((lrow >> 2) & 3)) << 3)) * 2u;
+  auto fetch_slab = [&](int blk) {
+    const char* hb = reinterpret_cast<const char*>(h + base * ldh + blk * 32);     // wave-uniform
+#pragma unroll
+    for (int i = 0; i < HP; ++i) {
+      if (i * 16 + lrow < T)
+        __builtin_amdgcn_global_load_lds((seg_gptr_t)(hb + (int64_t)i * 32 * ldh + voff), (seg_lptr_t)(slab + i * 1024), 16, 0, 0);
+    }
+  };
+  // hidden-tile fragment addresses: chunk (2 ks + hh) ^ (row & 15) with row & 15 == col & 15 for every row tile
+  uint32_t aoff[8];                                          // dynamic LDS starts at offset 0 (the kernel has no static LDS)
+#pragma unroll
+  for (int ks = 0; ks < 8; ++ks) aoff[ks] = col * 256 + (((ks * 2 + hh) ^ (col & 15)) << 4);
+  bf16x8 bfrag[8];
+  auto fetch_w2 = [&](int blk) {                              // W2 rows of this lane's channel
+#pragma unroll
+    for (int ks = 0; ks < 8; ++ks)
+      bfrag[ks] = *reinterpret_cast<const bf16x8*>(w2 + (int64_t)(blk * 32 + col) * 128 + ks * 16 + hh * 8);
+  };
+  const uint32_t slab_off = (uint32_t)(SEG_HID_BYTES + wid * SEG_SLAB_BYTES);       // dynamic LDS starts at offset 0
+  const uint32_t hoff0 = slab_off + hh * 4 * 64 + ((((col >> 3) ^ hh) ^ 0) << 4) + (col & 7) * 2;
+  const uint32_t hoff2 = slab_off + hh * 4 * 64 + ((((col >> 3) ^ hh) ^ 2) << 4) + (col & 7) * 2;
+  asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");          // the zero fill precedes the DMA into the same region
+  if (wid < nblk) { if (!(dbg & 1)) fetch_slab(wid); fetch_w2(wid); }
+  __syncthreads();                                           // the only workgroup barrier: the hidden tile is complete
+
+  const f32x16 zero16 = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+  // slab values arrive in the HIGH half of these registers (ds_read_u16_d16_hi keeps the low half): zeroed once
+  uint32_t hv[16];
+#pragma unroll
+  for (int r = 0; r < 16; ++r) hv[r] = 0u;
+  int tlim = T - 4 * hh;                                       // frame (const + 4 hh) exists  <=>  const < tlim
+  for (int blk = wid; blk < nblk; blk += 8) {
+    const int ch = blk * 32 + col;
+    asm volatile("" : "+v"(tlim));                             // keeps the 112 frame predicates out of (spilled) scalar registers
+    // logits of one 32-frame row tile; evaluated TWICE per tile (max pass, then moment pass) instead of holding all
+    // seven tiles in 112 registers: the matrix pipe has the room (56 MFMAs against ~900 vector instructions per
+    // block), the register file does not, and the recomputed values are the same bits
+    auto tile_logits = [&](int rt) {
+      // inline-asm reads: a tile's 8 fragments are fetched when the tile is evaluated, not 56 at once at the top
+      bf16x8 a[8];
+#pragma unroll
+      for (int ks = 0; ks < 8; ++ks) asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(a[ks]) : "v"(aoff[ks]), "n"(rt * 32 * 256));
+      asm volatile("s_waitcnt lgkmcnt(0)"
+                   : "+v"(a[0]), "+v"(a[1]), "+v"(a[2]), "+v"(a[3]), "+v"(a[4]), "+v"(a[5]), "+v"(a[6]), "+v"(a[7]) :: "memory");
+      f32x16 acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[0], bfrag[0], zero16, 0, 0, 0);
+#pragma unroll
+      for (int ks = 1; ks < 8; ++ks) acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[ks], bfrag[ks], acc, 0, 0, 0);
+      return acc;
+    };
+    // ---- pass 1: softmax max over frames (registers only; rows >= T count as -inf).  The next tile's fragment reads
+    // and MFMAs are issued before the current tile is reduced, so LDS latency and the matrix pipe overlap the VALU work.
+    float mx = -INFINITY;
+    {
+      f32x16 cur = tile_logits(0);
+#pragma unroll
+      for (int rt = 0; rt < NTILES; ++rt) {
+        if (dbg & 4) break;
+        f32x16 nxt = cur;
+        if (rt + 1 < NTILES) nxt = tile_logits(rt + 1);
+        if ((rt + 1) * 32 <= T) {                              // wave-uniform: every frame of the tile exists
+#pragma unroll
+          for (int r = 0; r < 16; ++r) mx = fmaxf(mx, cur[r]);
+        } else {
+#pragma unroll
+          for (int r = 0; r < 16; ++r) mx = fmaxf(mx, rt * 32 + (r & 3) + 8 * (r >> 2) < tlim ? cur[r] : -INFINITY);
+        }
+        asm volatile("" : "+v"(mx));                           // pins this tile's reduction before the next tile's reads
+        cur = nxt;
+      }
+    }
+    mx = fmaxf(mx, __shfl_xor(mx, 32, 64));                  // the logit bias is constant over frames: it cancels
+    const bool more = blk + 8 < nblk;
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");           // this block's slab has landed
+    // ---- pass 2: weighted moments about K = h[t = 0] (shifted single pass, fp32); the slab belongs to this wave only.
+    // Frame t = 32 rt + 8 (r >> 2) + (r & 3) + 4 hh sits at chunk (col >> 3) ^ ((t >> 2) & 3) = (col >> 3) ^ hh ^ (2 (r >> 2) & 3):
+    // two per-lane bases (compile-time part 0 or 2) + an immediate.  The bf16 lands in the HIGH half of a zeroed
+    // register (ds_read_u16_d16_hi): that register is the fp32 value.
+    const float Kf = bf16_to_f32(*reinterpret_cast<const bf16_t*>(slab + ((col >> 3) << 4) + (col & 7) * 2));     // h[t = 0]
+    float l = 0.f, s1 = 0.f, s2 = 0.f;
+    const f32x2 mx2 = {mx, mx}, K2 = {Kf, Kf}, log2e2 = {1.44269502162933349609375f, 1.44269502162933349609375f};
+    auto moments = [&](int rt, const f32x16& lg, const bool masked) {
+      // elementwise steps on frame PAIRS with packed fp32 instructions (same IEEE results as the scalar forms);
+      // the three running sums stay sequential in frame order
+#pragma unroll
+      for (int r = 0; r < 16; r += 2) {
+        f32x2 x = {lg[r], lg[r + 1]};
+        x = (x - mx2) * log2e2;                                  // __expf(v - mx) = exp2((v - mx) * log2(e))
+        f32x2 e = {__builtin_amdgcn_exp2f(x[0]), __builtin_amdgcn_exp2f(x[1])};
+        if (masked) {
+          const int t0 = rt * 32 + (r & 3) + 8 * (r >> 2);
+          e[0] = t0 < tlim ? e[0] : 0.f;
+          e[1] = t0 + 1 < tlim ? e[1] : 0.f;
+        }
+        f32x2 d = {__uint_as_float(hv[r]), __uint_as_float(hv[r + 1])};
+        d = d - K2;
+        const f32x2 ed = e * d;
+        l += e[0];
+        s1 = fmaf(e[0], d[0], s1);
+        s2 = fmaf(ed[0], d[0], s2);
+        l += e[1];
+        s1 = fmaf(e[1], d[1], s1);
+        s2 = fmaf(ed[1], d[1], s2);
+      }
+    };
+    {
+      f32x16 cur = tile_logits(0);
+#pragma unroll
+      for (int rt = 0; rt < NTILES; ++rt) {
+        if (dbg & 2) break;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          if (rt * 32 + 8 * (r >> 2) + (r & 3) + 4 < SEG_ROWS)                         // compile-time: frames 208..223 do not exist (weight 0, stale h)
+            asm volatile("ds_read_u16_d16_hi %0, %1 offset:%2" : "+v"(hv[r]) : "v"(((2 * (r >> 2)) & 3) ? hoff2 : hoff0),
+                         "n"((rt * 32 + 8 * (r >> 2) + (r & 3)) * 64));
+        }
+        // the next tile's fragments are read now; ONE wait covers both kinds of reads, so the next tile's MFMAs and this
+        // tile's arithmetic sit in the same scheduling region
+        bf16x8 a[8];
+        if (rt + 1 < NTILES) {
+#pragma unroll
+          for (int ks = 0; ks < 8; ++ks)
+            asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(a[ks]) : "v"(aoff[ks]), "n"((rt + 1 < NTILES ? rt + 1 : 0) * 32 * 256));
+          asm volatile("s_waitcnt lgkmcnt(0)"
+                       : "+v"(hv[0]), "+v"(hv[1]), "+v"(hv[2]), "+v"(hv[3]), "+v"(hv[4]), "+v"(hv[5]), "+v"(hv[6]), "+v"(hv[7]),
+                         "+v"(hv[8]), "+v"(hv[9]), "+v"(hv[10]), "+v"(hv[11]), "+v"(hv[12]), "+v"(hv[13]), "+v"(hv[14]), "+v"(hv[15]),
+                         "+v"(a[0]), "+v"(a[1]), "+v"(a[2]), "+v"(a[3]), "+v"(a[4]), "+v"(a[5]), "+v"(a[6]), "+v"(a[7])
+                       :: "memory");
+        } else {
+          asm volatile("s_waitcnt lgkmcnt(0)"
+                       : "+v"(hv[0]), "+v"(hv[1]), "+v"(hv[2]), "+v"(hv[3]), "+v"(hv[4]), "+v"(hv[5]), "+v"(hv[6]), "+v"(hv[7]),
+                         "+v"(hv[8]), "+v"(hv[9]), "+v"(hv[10]), "+v"(hv[11]), "+v"(hv[12]), "+v"(hv[13]), "+v"(hv[14]), "+v"(hv[15])
+                       :: "memory");
+        }
+        f32x16 nxt = cur;
+        // Issue order inside the tile: one MFMA of the NEXT tile's chain, then a slice of THIS tile's vector work.  A wave
+        // issues in order, so a bare chain of 8 dependent MFMAs would block its own vector instructions for 256 cycles.
+        // (Both live in one basic block per arm of the wave-uniform branch, or the scheduler could not mix them.)
+        auto step = [&](const bool masked) {
+          if (rt + 1 < NTILES) {
+            nxt = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[0], bfrag[0], zero16, 0, 0, 0);
+#pragma unroll
+            for (int ks = 1; ks < 8; ++ks) nxt = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[ks], bfrag[ks], nxt, 0, 0, 0);
+          }
+          moments(rt, cur, masked);
+          if (rt + 1 < NTILES) {
+#pragma unroll
+            for (int i = 0; i < 8; ++i) {
+              __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);     // MFMA
+              __builtin_amdgcn_sched_group_barrier(0x002, 13, 0);    // VALU
+            }
+          }
+        };
+        if ((rt + 1) * 32 <= T) step(false);                     // wave-uniform: no frame of this tile needs masking
+        else step(true);
+        asm volatile("" : "+v"(l), "+v"(s1), "+v"(s2));          // pins this tile's arithmetic before the next tile's reads
+        cur = nxt;
+      }
+    }
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");        // every read of the slab is done: the next DMA may overwrite it
+    if (more) { if (!(dbg & 1)) fetch_slab(blk + 8); fetch_w2(blk + 8); }     // both ride under the other wave's work and the store below
+    l += __shfl_xor(l, 32, 64);
+    s1 += __shfl_xor(s1, 32, 64);
+    s2 += __shfl_xor(s2, 32, 64);
+    if (hh == 0) {
+      const float a = s1 / l;
+      pooled[(int64_t)seg * 2 * C + ch] = Kf + a;
+      pooled[(int64_t)seg * 2 * C + C + ch] = sqrtf(fmaxf(s2 / l - a * a, 1e-12f));
+    }
+  }
+}
+
+// ------------------------------------------------------------------------------------------
 // k3: L2-normalise rows; one wave per row.
 __global__ __launch_bounds__(NT) void l2norm_kernel(const float* __restrict__ X, int N, int d, float* __restrict__ E,
                                                    bf16_t* __restrict__ Eb, float* __restrict__ resid) {
@@ -640,6 +866,17 @@ extern "C" int sdk_asp_fused(sdk_ctx* ctx, const uint16_t* ah, int64_t ldah, con
   SDK_REQUIRE(B > 0 && T > 0 && T <= 224, "sdk_asp_fused: T=%d frames unsupported (1..224); use sdk_conv_gemm + sdk_asp_pool", T);
   SDK_REQUIRE(C % 128 == 0 && ldah % 8 == 0 && ldh % 8 == 0, "sdk_asp_fused: C=%d must be a multiple of 128", C);
   ProfScope ps(ctx, stream, SDK_K_ASP_FUSED, 2.0 * B * T * (double)A * C, 2.0 * B * T * ((double)C + A) + 8.0 * B * C);
+  if (T > 96 && T <= SEG_ROWS && C % 256 == 0 && !ctx->no_asp_seg) {     // one workgroup per segment (hidden tile read once)
+    static bool attr_set = false;
+    if (!attr_set) {
+      SDK_HIP_OK(hipFuncSetAttribute((const void*)asp_seg_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, SEG_LDS));
+      attr_set = true;
+    }
+    hipLaunchKernelGGL(asp_seg_kernel, dim3(B), dim3(SEG_NT), SEG_LDS, (hipStream_t)stream, (const bf16_t*)ah, ldah, (const bf16_t*)w2,
+                       (const bf16_t*)h, ldh, T, C, pooled, getenv("SDK_ASP_DBG") ? atoi(getenv("SDK_ASP_DBG")) : 0);
+    SDK_LAUNCH_CHECK();
+    return 0;
+  }
   const dim3 grid(C / 128, B);
   if (T <= 96) hipLaunchKernelGGL(asp_fused_kernel<3>, grid, dim3(NT), 0, (hipStream_t)stream, (const bf16_t*)ah, ldah, (const bf16_t*)w2, b2, (const bf16_t*)h, ldh, T, C, pooled);
   else hipLaunchKernelGGL(asp_fused_kernel<7>, grid, dim3(NT), 0, (hipStream_t)stream, (const bf16_t*)ah, ldah, (const bf16_t*)w2, b2, (const bf16_t*)h, ldh, T, C, pooled);
