@@ -514,15 +514,26 @@ __global__ __launch_bounds__(NT, 2) void asp_fused_kernel(const bf16_t* __restri
 }
 
 // ------------------------------------------------------------------------------------------
-// The same computation, one workgroup (8 waves) per SEGMENT: the attention-hidden tile is loaded into LDS once
-// per segment instead of once per 128 channels (24 reads of the same 51 KB per segment otherwise), and every
-// wave walks its own share of the 32-channel blocks without any workgroup barrier: MFMA logits -> softmax over
-// frames in registers -> weighted moments against the wave's PRIVATE [208 x 32] slab of h in LDS.  The next
-// block's slab and W2 rows are in flight (registers) while the current block is reduced, and the matrix phase of
-// one wave overlaps the vector phase of the other wave on its SIMD.
+// The same computation, one workgroup (8 waves) per SEGMENT.  The attention-hidden tile is loaded into LDS once
+// per segment instead of once per 128 channels, and every wave walks its own share of the 32-channel blocks with
+// no workgroup barrier: per 32-frame row tile  MFMA logits -> ONLINE softmax (running max, the three running sums
+// are rescaled when it grows) -> weighted moments against the wave's PRIVATE [208 x 32] slab of h in LDS.
+//   * logits are evaluated once and a tile's 16 accumulator registers die with the tile (the two-pass form
+//     needs all 112, or the MFMAs twice);
+//   * a wave issues in order, so the NEXT tile's chain of 8 dependent MFMAs is interleaved, one MFMA per ~13
+//     vector instructions, with THIS tile's arithmetic (sched_group_barrier), both in one basic block;
+//   * the slab is refilled by LDS-DMA a row tile at a time: as soon as a tile's rows have been read, the same
+//     rows of the wave's next block are requested, so every piece has a whole block (~4 us) to arrive.  vmcnt
+//     retires in order and every block issues the same 13 DMA + 8 weight loads, so the wait before tile rt is the
+//     constant "all but the 19 (20 for the last tile) youngest"; W2 fragments are double-buffered in registers and
+//     requested a block ahead so that they are OLDER than the pieces they would otherwise force to land;
+//   * elementwise steps run on frame pairs with packed fp32 instructions; slab values are read with
+//     ds_read_u16_d16_hi into registers whose low half stays zero (the register IS the fp32 value);
+//   * all LDS reads of the hot loop are inline asm: the compiler otherwise hoists the block's 112 + 56 reads to the
+//     top and spills them.
 //   LDS: hidden tile 224 x 256 B (16-B chunk index XOR (row & 15)) + 8 x (208 x 64 B) slabs (chunk XOR
 //        ((row >> 2) & 3): the two half-waves read rows 4 apart) = 163 840 B, all of a CU's LDS.
-// Arithmetic and its order are those of asp_fused_kernel<7>: results are bit-identical.
+// Results differ from asp_fused_kernel by fp32 rounding only (rescaling of the running sums).
 constexpr int SEG_ROWS = 208;                 // frames a private h slab holds (T <= 208)
 constexpr int SEG_NT = 512;
 constexpr int SEG_HID_ROWS = 224;               // 7 MFMA row tiles of 32; rows >= T are zero
@@ -534,9 +545,11 @@ typedef float f32x2 __attribute__((ext_vector_type(2)));
 typedef const void __attribute__((address_space(1)))* seg_gptr_t;
 typedef void __attribute__((address_space(3)))* seg_lptr_t;
 
+#define SEG_WAIT_VM(n) asm volatile("s_waitcnt vmcnt(" #n ")" ::: "memory")
+
 __global__ __launch_bounds__(SEG_NT, 2) void asp_seg_kernel(const bf16_t* __restrict__ ah, int64_t ldah,
                                                            const bf16_t* __restrict__ w2, const bf16_t* __restrict__ h,
-                                                           int64_t ldh, int T, int C, float* __restrict__ pooled, int dbg) {
+                                                           int64_t ldh, int T, int C, float* __restrict__ pooled) {
   extern __shared__ __attribute__((aligned(16))) char lds[];
   constexpr int NTILES = 7;
   const int tid = threadIdx.x, lane = tid & 63;
@@ -554,180 +567,165 @@ __global__ __launch_bounds__(SEG_NT, 2) void asp_seg_kernel(const bf16_t* __rest
   }
   char* slab = lds + SEG_HID_BYTES + wid * SEG_SLAB_BYTES;
   const int nblk = C / 32;                                   // 32-channel blocks; wave w takes blocks w, w + 8, ...
-  constexpr int HP = SEG_ROWS / 16;                          // 13 slab pieces: 16 rows x 4 chunks of 16 B per wave instruction
   const int lrow = lane >> 2, lch = lane & 3;
-  // rows T..207 of the private slab are never written by the DMA below: make them finite (their weight is 0)
-#pragma unroll
-  for (int i = 0; i < HP; ++i) {
-    const int r = i * 16 + lrow;
-    if (r >= T) *reinterpret_cast<u32x4*>(slab + r * 64 + lch * 16) = u32x4{0u, 0u, 0u, 0u};
-  }
 
-  // slab of h [T x 32 channels] by LDS-DMA straight into the wave's region: LDS position (row, lch) receives the
-  // SOURCE chunk lch ^ ((row >> 2) & 3), so the two half-waves (rows 4 apart) later read different banks
-  // ((row >> 2) & 3) == ((lrow >> 2) & 3) for every piece (16 i does not reach those bits): one per-lane offset,
-  // the piece index only moves the wave-uniform base
-  const uint32_t voff = (uint32_t)(lrow * ldh + ((lch ^ ((lrow >> 2) & 3)) << 3)) * 2u;
-  auto fetch_slab = [&](int blk) {
+  // Slab pieces: DMA instruction i fills rows [16 i, 16 i + 16) x 4 chunks of 16 B; row tile rt = instructions 2 rt and
+  // 2 rt + 1 (the last tile has one: rows 192..207).  LDS position (row, lch) receives the SOURCE chunk
+  // lch ^ ((row >> 2) & 3) (== ((lrow >> 2) & 3): 16 i does not reach those bits).  Rows past the segment re-read its
+  // last frame instead of being skipped, so EVERY block issues exactly 13 instructions (the vmcnt arithmetic below
+  // depends on it) and the slab never holds non-finite stale bytes.
+  const uint32_t chunk_off = (uint32_t)((lch ^ ((lrow >> 2) & 3)) << 4);
+  uint32_t voff0 = (uint32_t)lrow * (uint32_t)ldh * 2u + chunk_off;       // the per-lane part of every FULL piece's address
+  auto fetch_piece = [&](int blk, int rt) {
     const char* hb = reinterpret_cast<const char*>(h + base * ldh + blk * 32);     // wave-uniform
 #pragma unroll
-    for (int i = 0; i < HP; ++i) {
-      if (i * 16 + lrow < T)
-        __builtin_amdgcn_global_load_lds((seg_gptr_t)(hb + (int64_t)i * 32 * ldh + voff), (seg_lptr_t)(slab + i * 1024), 16, 0, 0);
+    for (int i = 2 * rt; i < 2 * rt + 2 && i < SEG_ROWS / 16; ++i) {
+      // address = scalar base + 32-bit lane offset; the row part of a full piece moves into the scalar base
+      const bool full = (i + 1) * 16 <= T;                        // wave-uniform
+      const char* sb = full ? hb + (int64_t)i * 32 * ldh : hb;
+      const uint32_t vo = full ? voff0 : (uint32_t)min(i * 16 + lrow, T - 1) * (uint32_t)ldh * 2u + chunk_off;
+      __builtin_amdgcn_global_load_lds((seg_gptr_t)(sb + vo), (seg_lptr_t)(slab + i * 1024), 16, 0, 0);
     }
   };
   // hidden-tile fragment addresses: chunk (2 ks + hh) ^ (row & 15) with row & 15 == col & 15 for every row tile
   uint32_t aoff[8];                                          // dynamic LDS starts at offset 0 (the kernel has no static LDS)
 #pragma unroll
   for (int ks = 0; ks < 8; ++ks) aoff[ks] = col * 256 + (((ks * 2 + hh) ^ (col & 15)) << 4);
-  bf16x8 bfrag[8];
-  auto fetch_w2 = [&](int blk) {                              // W2 rows of this lane's channel
+  bf16x8 bA[8], bB[8];                                       // W2 rows of this lane's channel, this block / next block
+  auto fetch_w2 = [&](int blk, bf16x8* dst) {
 #pragma unroll
     for (int ks = 0; ks < 8; ++ks)
-      bfrag[ks] = *reinterpret_cast<const bf16x8*>(w2 + (int64_t)(blk * 32 + col) * 128 + ks * 16 + hh * 8);
+      dst[ks] = *reinterpret_cast<const bf16x8*>(w2 + (int64_t)(blk * 32 + col) * 128 + ks * 16 + hh * 8);
   };
-  const uint32_t slab_off = (uint32_t)(SEG_HID_BYTES + wid * SEG_SLAB_BYTES);       // dynamic LDS starts at offset 0
+  const uint32_t slab_off = (uint32_t)(SEG_HID_BYTES + wid * SEG_SLAB_BYTES);
+  // frame t = 32 rt + 8 (r >> 2) + (r & 3) + 4 hh sits at chunk (col >> 3) ^ ((t >> 2) & 3) = (col >> 3) ^ hh ^ (2 (r >> 2) & 3):
+  // two per-lane bases (compile-time part 0 or 2) + an immediate
   const uint32_t hoff0 = slab_off + hh * 4 * 64 + ((((col >> 3) ^ hh) ^ 0) << 4) + (col & 7) * 2;
   const uint32_t hoff2 = slab_off + hh * 4 * 64 + ((((col >> 3) ^ hh) ^ 2) << 4) + (col & 7) * 2;
-  asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");          // the zero fill precedes the DMA into the same region
-  if (wid < nblk) { if (!(dbg & 1)) fetch_slab(wid); fetch_w2(wid); }
+  const uint32_t koff = slab_off + ((col >> 3) << 4) + (col & 7) * 2;               // h[t = 0]
+  if (wid < nblk) {
+    fetch_w2(wid, bA);                                        // oldest: older than every piece
+#pragma unroll
+    for (int rt = 0; rt < NTILES; ++rt) fetch_piece(wid, rt);
+  }
   __syncthreads();                                           // the only workgroup barrier: the hidden tile is complete
 
   const f32x16 zero16 = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
-  // slab values arrive in the HIGH half of these registers (ds_read_u16_d16_hi keeps the low half): zeroed once
-  uint32_t hv[16];
+  const float LOG2E = 1.44269502162933349609375f;
+  uint32_t hv[16];                                           // low halves stay zero: ds_read_u16_d16_hi writes the high half only
 #pragma unroll
   for (int r = 0; r < 16; ++r) hv[r] = 0u;
+  uint32_t kv = 0u;
   int tlim = T - 4 * hh;                                       // frame (const + 4 hh) exists  <=>  const < tlim
-  for (int blk = wid; blk < nblk; blk += 8) {
+
+  auto process = [&](int blk, const bf16x8* bcur, bf16x8* bnext) {
     const int ch = blk * 32 + col;
-    asm volatile("" : "+v"(tlim));                             // keeps the 112 frame predicates out of (spilled) scalar registers
-    // logits of one 32-frame row tile; evaluated TWICE per tile (max pass, then moment pass) instead of holding all
-    // seven tiles in 112 registers: the matrix pipe has the room (56 MFMAs against ~900 vector instructions per
-    // block), the register file does not, and the recomputed values are the same bits
-    auto tile_logits = [&](int rt) {
-      // inline-asm reads: a tile's 8 fragments are fetched when the tile is evaluated, not 56 at once at the top
-      bf16x8 a[8];
+    const bool more = blk + 8 < nblk;
+    asm volatile("" : "+v"(tlim), "+v"(voff0));                // keeps frame predicates / piece addresses from being hoisted and spilled
+    SEG_WAIT_VM(13);                                           // this block's W2 rows (requested a block ago) are older than its 13 pieces
+    if (more) fetch_w2(blk + 8, bnext);
+    auto read_frags = [&](int rt, bf16x8* a) {
 #pragma unroll
       for (int ks = 0; ks < 8; ++ks) asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(a[ks]) : "v"(aoff[ks]), "n"(rt * 32 * 256));
-      asm volatile("s_waitcnt lgkmcnt(0)"
-                   : "+v"(a[0]), "+v"(a[1]), "+v"(a[2]), "+v"(a[3]), "+v"(a[4]), "+v"(a[5]), "+v"(a[6]), "+v"(a[7]) :: "memory");
-      f32x16 acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[0], bfrag[0], zero16, 0, 0, 0);
+    };
+    auto chain = [&](const bf16x8* a) {
+      f32x16 acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[0], bcur[0], zero16, 0, 0, 0);
 #pragma unroll
-      for (int ks = 1; ks < 8; ++ks) acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[ks], bfrag[ks], acc, 0, 0, 0);
+      for (int ks = 1; ks < 8; ++ks) acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[ks], bcur[ks], acc, 0, 0, 0);
       return acc;
     };
-    // ---- pass 1: softmax max over frames (registers only; rows >= T count as -inf).  The next tile's fragment reads
-    // and MFMAs are issued before the current tile is reduced, so LDS latency and the matrix pipe overlap the VALU work.
-    float mx = -INFINITY;
+    f32x16 cur;
     {
-      f32x16 cur = tile_logits(0);
-#pragma unroll
-      for (int rt = 0; rt < NTILES; ++rt) {
-        if (dbg & 4) break;
-        f32x16 nxt = cur;
-        if (rt + 1 < NTILES) nxt = tile_logits(rt + 1);
-        if ((rt + 1) * 32 <= T) {                              // wave-uniform: every frame of the tile exists
-#pragma unroll
-          for (int r = 0; r < 16; ++r) mx = fmaxf(mx, cur[r]);
-        } else {
-#pragma unroll
-          for (int r = 0; r < 16; ++r) mx = fmaxf(mx, rt * 32 + (r & 3) + 8 * (r >> 2) < tlim ? cur[r] : -INFINITY);
-        }
-        asm volatile("" : "+v"(mx));                           // pins this tile's reduction before the next tile's reads
-        cur = nxt;
-      }
+      bf16x8 a[8];
+      read_frags(0, a);
+      asm volatile("s_waitcnt lgkmcnt(0)"
+                   : "+v"(a[0]), "+v"(a[1]), "+v"(a[2]), "+v"(a[3]), "+v"(a[4]), "+v"(a[5]), "+v"(a[6]), "+v"(a[7]) :: "memory");
+      cur = chain(a);
     }
-    mx = fmaxf(mx, __shfl_xor(mx, 32, 64));                  // the logit bias is constant over frames: it cancels
-    const bool more = blk + 8 < nblk;
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");           // this block's slab has landed
-    // ---- pass 2: weighted moments about K = h[t = 0] (shifted single pass, fp32); the slab belongs to this wave only.
-    // Frame t = 32 rt + 8 (r >> 2) + (r & 3) + 4 hh sits at chunk (col >> 3) ^ ((t >> 2) & 3) = (col >> 3) ^ hh ^ (2 (r >> 2) & 3):
-    // two per-lane bases (compile-time part 0 or 2) + an immediate.  The bf16 lands in the HIGH half of a zeroed
-    // register (ds_read_u16_d16_hi): that register is the fp32 value.
-    const float Kf = bf16_to_f32(*reinterpret_cast<const bf16_t*>(slab + ((col >> 3) << 4) + (col & 7) * 2));     // h[t = 0]
-    float l = 0.f, s1 = 0.f, s2 = 0.f;
-    const f32x2 mx2 = {mx, mx}, K2 = {Kf, Kf}, log2e2 = {1.44269502162933349609375f, 1.44269502162933349609375f};
-    auto moments = [&](int rt, const f32x16& lg, const bool masked) {
-      // elementwise steps on frame PAIRS with packed fp32 instructions (same IEEE results as the scalar forms);
-      // the three running sums stay sequential in frame order
+    float m = -INFINITY, Kf = 0.f;
+    f32x2 l2 = {0.f, 0.f}, s12 = {0.f, 0.f}, s22 = {0.f, 0.f};   // softmax denominator and the two shifted moments, (even, odd) frames
 #pragma unroll
-      for (int r = 0; r < 16; r += 2) {
-        f32x2 x = {lg[r], lg[r + 1]};
-        x = (x - mx2) * log2e2;                                  // __expf(v - mx) = exp2((v - mx) * log2(e))
-        f32x2 e = {__builtin_amdgcn_exp2f(x[0]), __builtin_amdgcn_exp2f(x[1])};
-        if (masked) {
-          const int t0 = rt * 32 + (r & 3) + 8 * (r >> 2);
-          e[0] = t0 < tlim ? e[0] : 0.f;
-          e[1] = t0 + 1 < tlim ? e[1] : 0.f;
-        }
-        f32x2 d = {__uint_as_float(hv[r]), __uint_as_float(hv[r + 1])};
-        d = d - K2;
-        const f32x2 ed = e * d;
-        l += e[0];
-        s1 = fmaf(e[0], d[0], s1);
-        s2 = fmaf(ed[0], d[0], s2);
-        l += e[1];
-        s1 = fmaf(e[1], d[1], s1);
-        s2 = fmaf(ed[1], d[1], s2);
+    for (int rt = 0; rt < NTILES; ++rt) {
+      // piece rt of this block has landed once all but the ops issued after it are done (see the header comment)
+      if (more) { if (rt < NTILES - 1) SEG_WAIT_VM(19); else SEG_WAIT_VM(20); }
+      else if (rt == 0) SEG_WAIT_VM(11); else if (rt == 1) SEG_WAIT_VM(9); else if (rt == 2) SEG_WAIT_VM(7);
+      else if (rt == 3) SEG_WAIT_VM(5); else if (rt == 4) SEG_WAIT_VM(3); else if (rt == 5) SEG_WAIT_VM(1); else SEG_WAIT_VM(0);
+      if (rt == 0) asm volatile("ds_read_u16_d16_hi %0, %1" : "+v"(kv) : "v"(koff));
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        if (rt * 32 + 8 * (r >> 2) + (r & 3) + 4 < SEG_ROWS)                         // compile-time: frames 208..223 do not exist (weight 0, stale h)
+          asm volatile("ds_read_u16_d16_hi %0, %1 offset:%2" : "+v"(hv[r]) : "v"(((2 * (r >> 2)) & 3) ? hoff2 : hoff0),
+                       "n"((rt * 32 + 8 * (r >> 2) + (r & 3)) * 64));
       }
-    };
-    {
-      f32x16 cur = tile_logits(0);
+      // the next tile's fragments are read now; ONE wait covers both kinds of reads, so the next tile's MFMAs and this
+      // tile's arithmetic sit in the same scheduling region
+      bf16x8 a[8];
+      if (rt + 1 < NTILES) {
+        read_frags(rt + 1, a);
+        asm volatile("s_waitcnt lgkmcnt(0)"
+                     : "+v"(hv[0]), "+v"(hv[1]), "+v"(hv[2]), "+v"(hv[3]), "+v"(hv[4]), "+v"(hv[5]), "+v"(hv[6]), "+v"(hv[7]),
+                       "+v"(hv[8]), "+v"(hv[9]), "+v"(hv[10]), "+v"(hv[11]), "+v"(hv[12]), "+v"(hv[13]), "+v"(hv[14]), "+v"(hv[15]),
+                       "+v"(a[0]), "+v"(a[1]), "+v"(a[2]), "+v"(a[3]), "+v"(a[4]), "+v"(a[5]), "+v"(a[6]), "+v"(a[7]), "+v"(kv)
+                     :: "memory");
+      } else {
+        asm volatile("s_waitcnt lgkmcnt(0)"
+                     : "+v"(hv[0]), "+v"(hv[1]), "+v"(hv[2]), "+v"(hv[3]), "+v"(hv[4]), "+v"(hv[5]), "+v"(hv[6]), "+v"(hv[7]),
+                       "+v"(hv[8]), "+v"(hv[9]), "+v"(hv[10]), "+v"(hv[11]), "+v"(hv[12]), "+v"(hv[13]), "+v"(hv[14]), "+v"(hv[15]), "+v"(kv)
+                     :: "memory");
+      }
+      // this tile's slab rows have been read: request the same rows of the wave's next block
+      if (more) fetch_piece(blk + 8, rt);
+      if (rt == 0) Kf = __uint_as_float(kv);
+      f32x16 nxt = cur;
+      auto step = [&](const bool masked) {
+        if (rt + 1 < NTILES) nxt = chain(a);
+        // online softmax: the running maximum may grow with this tile; the sums so far are rescaled to it
+        float tm = -INFINITY;
 #pragma unroll
-      for (int rt = 0; rt < NTILES; ++rt) {
-        if (dbg & 2) break;
+        for (int r = 0; r < 16; ++r) tm = fmaxf(tm, (!masked || rt * 32 + (r & 3) + 8 * (r >> 2) < tlim) ? cur[r] : -INFINITY);
+        const float mn = fmaxf(m, tm);
+        const float sc = __builtin_amdgcn_exp2f((m - mn) * LOG2E);   // first tile: exp2(-inf) = 0 (tile 0 always has frames)
+        const f32x2 sc2 = {sc, sc};
+        l2 *= sc2; s12 *= sc2; s22 *= sc2;
+        m = mn;
+        const float mc = -m * LOG2E;
+        const f32x2 mc2 = {mc, mc}, K2 = {Kf, Kf}, log2e2 = {LOG2E, LOG2E};
+        // frame PAIRS on packed fp32 instructions: even and odd frames of the lane accumulate side by side (merged at the
+        // end of the block); 5 vector-issue slots per frame instead of 9
 #pragma unroll
-        for (int r = 0; r < 16; ++r) {
-          if (rt * 32 + 8 * (r >> 2) + (r & 3) + 4 < SEG_ROWS)                         // compile-time: frames 208..223 do not exist (weight 0, stale h)
-            asm volatile("ds_read_u16_d16_hi %0, %1 offset:%2" : "+v"(hv[r]) : "v"(((2 * (r >> 2)) & 3) ? hoff2 : hoff0),
-                         "n"((rt * 32 + 8 * (r >> 2) + (r & 3)) * 64));
+        for (int r = 0; r < 16; r += 2) {
+          const f32x2 x = {cur[r], cur[r + 1]};
+          const f32x2 y = x * log2e2 + mc2;                        // exp(v - m) = exp2(v log2(e) - m log2(e)): one packed FMA
+          f32x2 e = {__builtin_amdgcn_exp2f(y[0]), __builtin_amdgcn_exp2f(y[1])};
+          if (masked) {
+            const int t0 = rt * 32 + (r & 3) + 8 * (r >> 2);
+            e[0] = t0 < tlim ? e[0] : 0.f;
+            e[1] = t0 + 1 < tlim ? e[1] : 0.f;
+          }
+          f32x2 d = {__uint_as_float(hv[r]), __uint_as_float(hv[r + 1])};
+          d = d - K2;
+          const f32x2 ed = e * d;
+          l2 += e;
+          s12 = e * d + s12;
+          s22 = ed * d + s22;
         }
-        // the next tile's fragments are read now; ONE wait covers both kinds of reads, so the next tile's MFMAs and this
-        // tile's arithmetic sit in the same scheduling region
-        bf16x8 a[8];
         if (rt + 1 < NTILES) {
 #pragma unroll
-          for (int ks = 0; ks < 8; ++ks)
-            asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(a[ks]) : "v"(aoff[ks]), "n"((rt + 1 < NTILES ? rt + 1 : 0) * 32 * 256));
-          asm volatile("s_waitcnt lgkmcnt(0)"
-                       : "+v"(hv[0]), "+v"(hv[1]), "+v"(hv[2]), "+v"(hv[3]), "+v"(hv[4]), "+v"(hv[5]), "+v"(hv[6]), "+v"(hv[7]),
-                         "+v"(hv[8]), "+v"(hv[9]), "+v"(hv[10]), "+v"(hv[11]), "+v"(hv[12]), "+v"(hv[13]), "+v"(hv[14]), "+v"(hv[15]),
-                         "+v"(a[0]), "+v"(a[1]), "+v"(a[2]), "+v"(a[3]), "+v"(a[4]), "+v"(a[5]), "+v"(a[6]), "+v"(a[7])
-                       :: "memory");
-        } else {
-          asm volatile("s_waitcnt lgkmcnt(0)"
-                       : "+v"(hv[0]), "+v"(hv[1]), "+v"(hv[2]), "+v"(hv[3]), "+v"(hv[4]), "+v"(hv[5]), "+v"(hv[6]), "+v"(hv[7]),
-                         "+v"(hv[8]), "+v"(hv[9]), "+v"(hv[10]), "+v"(hv[11]), "+v"(hv[12]), "+v"(hv[13]), "+v"(hv[14]), "+v"(hv[15])
-                       :: "memory");
+          for (int i = 0; i < 8; ++i) {
+            __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);     // one MFMA of the next tile's chain
+            __builtin_amdgcn_sched_group_barrier(0x002, 11, 0);    // a slice of this tile's vector work
+          }
         }
-        f32x16 nxt = cur;
-        // Issue order inside the tile: one MFMA of the NEXT tile's chain, then a slice of THIS tile's vector work.  A wave
-        // issues in order, so a bare chain of 8 dependent MFMAs would block its own vector instructions for 256 cycles.
-        // (Both live in one basic block per arm of the wave-uniform branch, or the scheduler could not mix them.)
-        auto step = [&](const bool masked) {
-          if (rt + 1 < NTILES) {
-            nxt = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[0], bfrag[0], zero16, 0, 0, 0);
-#pragma unroll
-            for (int ks = 1; ks < 8; ++ks) nxt = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[ks], bfrag[ks], nxt, 0, 0, 0);
-          }
-          moments(rt, cur, masked);
-          if (rt + 1 < NTILES) {
-#pragma unroll
-            for (int i = 0; i < 8; ++i) {
-              __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);     // MFMA
-              __builtin_amdgcn_sched_group_barrier(0x002, 13, 0);    // VALU
-            }
-          }
-        };
-        if ((rt + 1) * 32 <= T) step(false);                     // wave-uniform: no frame of this tile needs masking
-        else step(true);
-        asm volatile("" : "+v"(l), "+v"(s1), "+v"(s2));          // pins this tile's arithmetic before the next tile's reads
-        cur = nxt;
-      }
+      };
+      if ((rt + 1) * 32 <= T) step(false);                     // wave-uniform: no frame of this tile needs masking
+      else step(true);
+      asm volatile("" : "+v"(l2), "+v"(s12), "+v"(s22), "+v"(m));   // pins this tile's arithmetic before the next tile's reads
+      cur = nxt;
     }
-    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");        // every read of the slab is done: the next DMA may overwrite it
-    if (more) { if (!(dbg & 1)) fetch_slab(blk + 8); fetch_w2(blk + 8); }     // both ride under the other wave's work and the store below
+    // the two lanes of a channel (frame halves hh = 0 / 1) merge their running states
+    const float M = fmaxf(m, __shfl_xor(m, 32, 64));
+    const float f = __builtin_amdgcn_exp2f((m - M) * LOG2E);
+    float l = (l2[0] + l2[1]) * f, s1 = (s12[0] + s12[1]) * f, s2 = (s22[0] + s22[1]) * f;
     l += __shfl_xor(l, 32, 64);
     s1 += __shfl_xor(s1, 32, 64);
     s2 += __shfl_xor(s2, 32, 64);
@@ -736,8 +734,13 @@ __global__ __launch_bounds__(SEG_NT, 2) void asp_seg_kernel(const bf16_t* __rest
       pooled[(int64_t)seg * 2 * C + ch] = Kf + a;
       pooled[(int64_t)seg * 2 * C + C + ch] = sqrtf(fmaxf(s2 / l - a * a, 1e-12f));
     }
+  };
+  for (int blk = wid; blk < nblk; blk += 16) {
+    process(blk, bA, bB);
+    if (blk + 8 < nblk) process(blk + 8, bB, bA);
   }
 }
+#undef SEG_WAIT_VM
 
 // ------------------------------------------------------------------------------------------
 // k3: L2-normalise rows; one wave per row.
@@ -873,7 +876,7 @@ extern "C" int sdk_asp_fused(sdk_ctx* ctx, const uint16_t* ah, int64_t ldah, con
       attr_set = true;
     }
     hipLaunchKernelGGL(asp_seg_kernel, dim3(B), dim3(SEG_NT), SEG_LDS, (hipStream_t)stream, (const bf16_t*)ah, ldah, (const bf16_t*)w2,
-                       (const bf16_t*)h, ldh, T, C, pooled, getenv("SDK_ASP_DBG") ? atoi(getenv("SDK_ASP_DBG")) : 0);
+                       (const bf16_t*)h, ldh, T, C, pooled);
     SDK_LAUNCH_CHECK();
     return 0;
   }
