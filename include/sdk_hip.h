@@ -134,7 +134,8 @@ int sdk_set_gemm_variant(int variant);
 /* Res2Net chain of one block fused per segment (T <= sdk_res2net_chain_max_frames(), 128-channel sub-bands):
  *   R[:, 128c : 128(c+1)] = y_c,  y_1 = TDNN_0(U chunk 1),  y_c = TDNN_{c-1}(bf16(U chunk c + y_{c-1})),  c = 2..nconv
  * W/bias/scale/shift: HOST arrays of nconv device pointers (W[i]: bf16 [128][3*128]).  Bit-identical to the
- * same chain expressed as nconv sdk_conv_gemm launches. */
+ * same chain expressed as nconv sdk_conv_gemm launches.  R may be U itself (in place: a segment's chunk c has been
+ * read before y_c is written over it), which also leaves chunk 0 where the next layer expects it. */
 int sdk_res2net_chain_max_frames(void);
 int sdk_res2net_chain(sdk_ctx* ctx, const uint16_t* U, int64_t ldu, uint16_t* R, int64_t ldr, const uint16_t* const* W,
                       const float* const* bias, const float* const* scale, const float* const* shift, int nconv,

@@ -211,22 +211,27 @@ extern "C" int sdk_ecapa_forward(sdk_ctx* ctx, const void* wblob, const sdk_ecap
   for (int i = 1; i <= d->n_blocks; ++i) {
     const int base = EL_BLOCK_BASE(i), dil = d->dilation[i - 1];
     if (int rc = tdnn(xin, ldx, C, 1, 1, base + EL_TDNN1, C, w.U, C, nullptr, 0, nullptr, 0)) return rc;
-    // Res2Net: chunk 0 passes through, chunk c>=1 = TDNN(chunk c + y_{c-1}); the running sum is
-    // produced by the previous conv's epilogue (S output), ping-ponging between two [M, S] buffers.
-    {
-      ProfScope ps(ctx, stream, SDK_K_COPY, 0.0, 2.0 * M * S * 2);
-      SDK_HIP_OK(hipMemcpy2DAsync(w.R, (size_t)C * 2, w.U, (size_t)C * 2, (size_t)S * 2, (size_t)M, hipMemcpyDeviceToDevice, st));
-    }
+    // Res2Net: chunk 0 passes through, chunk c>=1 = TDNN(chunk c + y_{c-1})
+    const uint16_t* r2out = w.R;
     if (S == 128 && d->scale - 1 <= 7 && T <= sdk_res2net_chain_max_frames() && !ctx->no_chain_fusion) {
-      // the seven dependent convolutions in ONE launch, the running tile resident in LDS per segment
+      // the seven dependent convolutions in ONE launch, the running tile resident in LDS per segment.  The chain runs
+      // IN PLACE on the tdnn1 output: a workgroup has read u_c (into LDS / registers) before it writes y_c over it, and
+      // segments do not overlap - so chunk 0 needs no copy
       const uint16_t* Wp[7]; const float* bp[7]; const float* sp[7]; const float* tp[7];
       for (int j = 0; j < d->scale - 1; ++j) {
         const int slot = base + EL_RES2NET(j);
         Wp[j] = P16(slot + EL_W); bp[j] = P32(slot + EL_B); sp[j] = P32(slot + EL_SCALE); tp[j] = P32(slot + EL_SHIFT);
       }
-      if (int rc = sdk_res2net_chain(ctx, w.U, C, w.R, C, Wp, bp, sp, tp, d->scale - 1, B, T, dil, stream)) return rc;
+      if (int rc = sdk_res2net_chain(ctx, w.U, C, w.U, C, Wp, bp, sp, tp, d->scale - 1, B, T, dil, stream)) return rc;
+      r2out = w.U;
     } else {
-    for (int j = 0; j < d->scale - 1; ++j) {
+      // separate launches: the running sum is produced by the previous conv's epilogue (S output), ping-ponging
+      // between two [M, S] buffers
+      {
+        ProfScope ps(ctx, stream, SDK_K_COPY, 0.0, 2.0 * M * S * 2);
+        SDK_HIP_OK(hipMemcpy2DAsync(w.R, (size_t)C * 2, w.U, (size_t)C * 2, (size_t)S * 2, (size_t)M, hipMemcpyDeviceToDevice, st));
+      }
+      for (int j = 0; j < d->scale - 1; ++j) {
         const uint16_t* Ain = j == 0 ? w.U + S : ((j & 1) ? w.Sa : w.Sb);
         const int64_t lda = j == 0 ? C : S;
         const bool more = j + 1 < d->scale - 1;
@@ -237,7 +242,7 @@ extern "C" int sdk_ecapa_forward(sdk_ctx* ctx, const void* wblob, const sdk_ecap
     }
     // the SE squeeze (per-segment channel means of z) comes out of the tdnn2 epilogue where the shape allows it
     const bool fuse_se = sdk_conv_gemm_stats_fusable(M, C, T) != 0;
-    if (int rc = tdnn(w.R, C, C, 1, 1, base + EL_TDNN2, C, w.Z, C, nullptr, 0, nullptr, 0, fuse_se ? 1 : 0)) return rc;
+    if (int rc = tdnn(r2out, C, C, 1, 1, base + EL_TDNN2, C, w.Z, C, nullptr, 0, nullptr, 0, fuse_se ? 1 : 0)) return rc;
     if (fuse_se)
       if (int rc = sdk_colstats_finish(ctx, w.stats, M, C, T, 1, w.mean, stream)) return rc;
     uint16_t* slab = w.CAT + (int64_t)C * (i - 1);
