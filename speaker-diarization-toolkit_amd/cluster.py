@@ -57,7 +57,7 @@ class _Comm:
         import torch.distributed as d
         t = torch.tensor([value, float(row)], dtype=torch.float64, device=dev)
         out = torch.zeros((self.world * 2,), dtype=torch.float64, device=dev)
-        d.all_gather_into_tensor(out, t, group=self.group)
+        sdist._gather_into(out, t, self.group)
         pairs = out.reshape(self.world, 2).cpu().tolist()
         return int(max(pairs, key=lambda p: (p[0], -p[1]))[1])
 

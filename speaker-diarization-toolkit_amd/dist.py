@@ -31,6 +31,17 @@ def shard_range(n: int, rank: Optional[int] = None, world: Optional[int] = None)
     return shard_bounds(n, world)[rank]
 
 
+def _gather_into(out: torch.Tensor, send: torch.Tensor, group=None) -> None:
+    """all_gather_into_tensor; the gloo transport cannot move device tensors for this collective, so a gloo group with
+    tensors on a GPU (rehearsals of the N > 1 path on a single-GPU box) is staged through host memory."""
+    if send.is_cuda and dist.get_backend(group) == "gloo":
+        host = torch.empty(out.shape, dtype=out.dtype)
+        dist.all_gather_into_tensor(host, send.cpu().contiguous(), group=group)
+        out.copy_(host)
+    else:
+        dist.all_gather_into_tensor(out, send.contiguous(), group=group)
+
+
 def all_gather_rows(local: torch.Tensor, n_total: int, group=None) -> torch.Tensor:
     """Gather row shards produced under shard_bounds(n_total, world) into the full [n_total, d]
     tensor on every rank.  Shards are padded to the largest block so a single collective moves
@@ -46,7 +57,7 @@ def all_gather_rows(local: torch.Tensor, n_total: int, group=None) -> torch.Tens
         return local.new_zeros((0,) + tuple(local.shape[1:]))
     send = local if local.shape[0] == width else torch.cat([local, local.new_zeros((width - local.shape[0],) + tuple(local.shape[1:]))])
     out = local.new_empty((world * width,) + tuple(local.shape[1:]))
-    dist.all_gather_into_tensor(out, send.contiguous(), group=group)
+    _gather_into(out, send, group)
     if all(h - l == width for l, h in bounds):
         return out
     return torch.cat([out[k * width: k * width + (h - l)] for k, (l, h) in enumerate(bounds)])

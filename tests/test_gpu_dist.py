@@ -1,0 +1,76 @@
+"""The N > 1 path on real kernels: two processes share the one GPU of the test box (process-per-rank exactly as
+bench.py / pipeline.run_shard run over RCCL on a node; here the transport is gloo because RCCL refuses two ranks on
+one device) - segments sharded by dist.shard_bounds, embeddings all-gathered, global spectral clustering with
+row-sharded affinity, every rank ending with the labels a single process computes."""
+import os
+import socket
+
+import numpy as np
+import pytest
+import torch
+import torch.multiprocessing as mp
+
+from conftest import PKG, ROOT
+
+pytestmark = pytest.mark.gpu
+
+
+def _free_port():
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        return s.getsockname()[1]
+
+
+def _voices(n_per, seeds=(0, 1, 2)):
+    t = np.arange(32000) / 16000.0
+    out = []
+    for s, f0 in zip(seeds, (95.0, 150.0, 220.0)):
+        for i in range(n_per):
+            rng = np.random.default_rng(1000 * s + i)
+            x = sum((0.5 / h ** (1.0 + 0.2 * s)) * np.sin(2 * np.pi * f0 * h * t + rng.uniform(0, 6.28)) for h in range(1, 12))
+            x = x * (0.6 + 0.4 * np.sin(2 * np.pi * 3.1 * t)) + rng.normal(0, 0.02, t.shape)
+            out.append(np.clip(np.round(x / np.abs(x).max() * 0.5 * 32767), -32768, 32767).astype(np.int16))
+    return np.stack(out)
+
+
+def _worker(rank, world, port, out_dir):
+    import importlib
+    import sys
+    sys.path.insert(0, str(ROOT))
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), HSA_ENABLE_IPC_MODE_LEGACY="0")
+    import torch.distributed as dist
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    D = importlib.import_module(f"{PKG}.dist")
+    P = importlib.import_module(f"{PKG}.pipeline")
+    eng = importlib.import_module(f"{PKG}.ops").get_engine(0)
+    pcm = _voices(7)                                         # 21 segments: ragged shards (11 + 10)
+    n = len(pcm)
+    lo, hi = D.shard_range(n)
+    prof = torch.from_numpy(np.random.default_rng(5).standard_normal((5, 192)).astype(np.float32)).cuda()
+    res = P.run_shard(eng, torch.from_numpy(pcm[lo:hi]).cuda(), prof, n_total=n, k=1, n_clusters=3, cluster_iters=20)
+    gathered = D.all_gather_rows(res.embeddings, n)          # k5 on device tensors
+    np.save(os.path.join(out_dir, f"labels{rank}.npy"), res.cluster_labels)
+    np.save(os.path.join(out_dir, f"emb{rank}.npy"), gathered.cpu().numpy())
+    np.save(os.path.join(out_dir, f"best{rank}.npy"), res.best_profile)
+    dist.destroy_process_group()
+
+
+def test_two_ranks_one_gpu_match_single_process(engine, tmp_path):
+    world = 2
+    mp.spawn(_worker, args=(world, _free_port(), str(tmp_path)), nprocs=world, join=True)
+    import importlib
+    P = importlib.import_module(f"{PKG}.pipeline")
+    pcm = _voices(7)
+    prof = torch.from_numpy(np.random.default_rng(5).standard_normal((5, 192)).astype(np.float32)).cuda()
+    one = P.run_shard(engine, torch.from_numpy(pcm).cuda(), prof, k=1, n_clusters=3, cluster_iters=20)
+    lab = [np.load(tmp_path / f"labels{r}.npy") for r in range(world)]
+    emb = [np.load(tmp_path / f"emb{r}.npy") for r in range(world)]
+    assert np.array_equal(lab[0], lab[1]) and np.array_equal(emb[0], emb[1])          # every rank ends with the same answer
+    # embeddings: the shard's rows travel in a different batch than in the single process (bf16-level tolerance,
+    # see test_config2_full_batch_properties); clustering of three well separated voices must agree exactly
+    E1 = one.embeddings.cpu().numpy()
+    assert ((E1.astype(np.float64) * emb[0]).sum(1) > 1 - 1e-5).all()
+    assert np.array_equal(lab[0], one.cluster_labels)
+    assert np.array_equal(lab[0], np.repeat(np.arange(3), 7))
+    best = np.concatenate([np.load(tmp_path / f"best{r}.npy") for r in range(world)])
+    assert np.array_equal(best, one.best_profile)
