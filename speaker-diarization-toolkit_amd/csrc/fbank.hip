@@ -62,6 +62,7 @@ __global__ __launch_bounds__(NW * 64) void fbank_tile_kernel(const int16_t* __re
   float* xs = reinterpret_cast<float*>(lds + 4 * FT * AROW * 2);      // raw samples of the tile
   float* pw = reinterpret_cast<float*>(lds);                          // power tile, overlays the images after the MFMAs
   static_assert(FT * PW_STRIDE * 4 <= 4 * FT * AROW * 2, "power tile must fit over the folded images");
+  static_assert((MELW_MAX + 3 * NMEL) * 4 <= TILE_SAMPLES * 4, "mel tables must fit over the raw samples");
   const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
   const int b = blockIdx.x / tiles_per_seg;
   const int t0 = (blockIdx.x - b * tiles_per_seg) * FT;
@@ -97,29 +98,30 @@ __global__ __launch_bounds__(NW * 64) void fbank_tile_kernel(const int16_t* __re
   const bf16x8* btab = reinterpret_cast<const bf16x8*>(&tab->dft[w][0][0][0][lane][0]);
   // fragment (part p, step ks, hi/lo v) sits at btab[((p * KSTEPS + ks) * 2 + v) * 64]
   bf16x8 bc[4], bn[4];                                  // cos hi, cos lo, sin hi, sin lo of the current / next k-step
+  bf16x8 ac[4], an[4];                                  // sample fragments (cos hi, cos lo, sin hi, sin lo images), likewise
 #pragma unroll
   for (int v = 0; v < 2; ++v) { bc[v] = btab[(0 * KSTEPS * 2 + v) * 64]; bc[2 + v] = btab[(1 * KSTEPS * 2 + v) * 64]; }
+#pragma unroll
+  for (int q = 0; q < 4; ++q) ac[q] = *reinterpret_cast<const bf16x8*>(arow + (q * FT) * AROW);
 #pragma unroll 1
   for (int ks = 0; ks < KSTEPS; ++ks) {
-    if (ks + 1 < KSTEPS) {
+    if (ks + 1 < KSTEPS) {                               // both operands of the NEXT k-step are requested before this step's MFMAs
 #pragma unroll
       for (int v = 0; v < 2; ++v) {
         bn[v] = btab[((0 * KSTEPS + ks + 1) * 2 + v) * 64];
         bn[2 + v] = btab[((1 * KSTEPS + ks + 1) * 2 + v) * 64];
       }
-    }
-    const bf16x8 ach = *reinterpret_cast<const bf16x8*>(arow + (0 * FT) * AROW + ks * 16);
-    const bf16x8 acl = *reinterpret_cast<const bf16x8*>(arow + (1 * FT) * AROW + ks * 16);
-    const bf16x8 ash = *reinterpret_cast<const bf16x8*>(arow + (2 * FT) * AROW + ks * 16);
-    const bf16x8 asl = *reinterpret_cast<const bf16x8*>(arow + (3 * FT) * AROW + ks * 16);
-    are = __builtin_amdgcn_mfma_f32_32x32x16_bf16(acl, bc[0], are, 0, 0, 0);     // small terms first
-    are = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ach, bc[1], are, 0, 0, 0);
-    are = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ach, bc[0], are, 0, 0, 0);
-    aim = __builtin_amdgcn_mfma_f32_32x32x16_bf16(asl, bc[2], aim, 0, 0, 0);
-    aim = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ash, bc[3], aim, 0, 0, 0);
-    aim = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ash, bc[2], aim, 0, 0, 0);
 #pragma unroll
-    for (int v = 0; v < 4; ++v) bc[v] = bn[v];
+      for (int q = 0; q < 4; ++q) an[q] = *reinterpret_cast<const bf16x8*>(arow + (q * FT) * AROW + (ks + 1) * 16);
+    }
+    are = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ac[1], bc[0], are, 0, 0, 0);     // small terms first
+    are = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ac[0], bc[1], are, 0, 0, 0);
+    are = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ac[0], bc[0], are, 0, 0, 0);
+    aim = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ac[3], bc[2], aim, 0, 0, 0);
+    aim = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ac[2], bc[3], aim, 0, 0, 0);
+    aim = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ac[2], bc[2], aim, 0, 0, 0);
+#pragma unroll
+    for (int v = 0; v < 4; ++v) { bc[v] = bn[v]; ac[v] = an[v]; }
   }
   __syncthreads();                                       // every wave is done with the images: pw may overlay them
   // power tile -> LDS [frame][bin]
@@ -128,14 +130,20 @@ __global__ __launch_bounds__(NW * 64) void fbank_tile_kernel(const int16_t* __re
     const int frame = (r & 3) + 8 * (r >> 2) + 4 * kk;
     pw[frame * PW_STRIDE + w * 32 + fi] = are[r] * are[r] + aim[r] * aim[r];
   }
+  // the triangular mel filters (start / length / offset per filter + 512 weights) move into the LDS the raw samples
+  // no longer need: the dot products below then read only LDS instead of walking global memory per term
+  float* melw = xs;
+  int* mtab = reinterpret_cast<int*>(xs + MELW_MAX);
+  for (int i = tid; i < MELW_MAX; i += NW * 64) melw[i] = tab->melw[i];
+  for (int i = tid; i < NMEL; i += NW * 64) { mtab[i] = tab->mstart[i]; mtab[NMEL + i] = tab->mlen[i]; mtab[2 * NMEL + i] = tab->moff[i]; }
   __syncthreads();
   for (int o = tid; o < FT * NMEL; o += NW * 64) {
     const int frame = o / NMEL, m = o - frame * NMEL;
     const int t = t0 + frame;
     if (t < T) {
-      const int st = tab->mstart[m], ln = tab->mlen[m], of = tab->moff[m];
+      const int st = mtab[m], ln = mtab[NMEL + m], of = mtab[2 * NMEL + m];
       float acc = 0.f;
-      for (int i = 0; i < ln; ++i) acc += pw[frame * PW_STRIDE + st + i] * tab->melw[of + i];
+      for (int i = 0; i < ln; ++i) acc += pw[frame * PW_STRIDE + st + i] * melw[of + i];
       L[((int64_t)b * T + t) * NMEL + m] = 10.0f * log10f(fmaxf(acc, 1e-10f));
     }
   }
