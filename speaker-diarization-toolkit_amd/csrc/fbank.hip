@@ -74,19 +74,25 @@ __global__ __launch_bounds__(NW * 64) void fbank_tile_kernel(const int16_t* __re
     xs[q] = (g >= 0 && g < S) ? (float)seg[g] * (1.0f / 32768.0f) : 0.f;
   }
   __syncthreads();
-  for (int e = tid; e < FT * NSYM; e += NW * 64) {
-    const int i = e / NSYM, n = e - i * NSYM;
-    float ec = 0.f, es = 0.f;
-    if (n <= NFFT / 2) {
-      const float xa = xs[i * HOP + n], xb = xs[i * HOP + (n == 0 ? 0 : NFFT - n)];
-      ec = xa + xb;
-      es = xa - xb;
+  // folded, split sample images: two consecutive n per thread-iteration -> 4-byte LDS writes
+  for (int e = tid; e < FT * (NSYM / 2); e += NW * 64) {
+    const int i = e / (NSYM / 2), n = (e - i * (NSYM / 2)) * 2;
+    float ec[2] = {0.f, 0.f}, es[2] = {0.f, 0.f};
+#pragma unroll
+    for (int q = 0; q < 2; ++q) {
+      const int nn = n + q;
+      if (nn <= NFFT / 2) {
+        const float xa = xs[i * HOP + nn], xb = xs[i * HOP + (nn == 0 ? 0 : NFFT - nn)];
+        ec[q] = xa + xb;
+        es[q] = xa - xb;
+      }
     }
-    const bf16_t ch = f32_to_bf16(ec), sh = f32_to_bf16(es);
-    img[(0 * FT + i) * AROW + n] = ch;
-    img[(1 * FT + i) * AROW + n] = f32_to_bf16(ec - bf16_to_f32(ch));
-    img[(2 * FT + i) * AROW + n] = sh;
-    img[(3 * FT + i) * AROW + n] = f32_to_bf16(es - bf16_to_f32(sh));
+    const bf16_t ch0 = f32_to_bf16(ec[0]), ch1 = f32_to_bf16(ec[1]), sh0 = f32_to_bf16(es[0]), sh1 = f32_to_bf16(es[1]);
+    uint32_t* dst = reinterpret_cast<uint32_t*>(img + i * AROW + n);
+    dst[(0 * FT * AROW) / 2] = pack2(bf16_to_f32(ch0), bf16_to_f32(ch1));
+    dst[(1 * FT * AROW) / 2] = pack2(ec[0] - bf16_to_f32(ch0), ec[1] - bf16_to_f32(ch1));
+    dst[(2 * FT * AROW) / 2] = pack2(bf16_to_f32(sh0), bf16_to_f32(sh1));
+    dst[(3 * FT * AROW) / 2] = pack2(es[0] - bf16_to_f32(sh0), es[1] - bf16_to_f32(sh1));
   }
   __syncthreads();
 
