@@ -161,6 +161,32 @@ def main() -> int:
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         elapsed = float(tt.item())
 
+    # ---- k5 measured on its own: the all-gather of the embedding shards, every rank taking part.
+    # Two sizes: this run's [B, 192] shard, and config #4's 125 000-row shard (96 MB fp32 per rank, 768 MB gathered at 8).
+    exchange = None
+    if world > 1:
+        exchange = {}
+        for label, rows in (("bench_shard", B), ("config4_shard", 125_000)):
+            src = torch.empty((rows, 192), dtype=torch.float32, device=dev).normal_()
+            dst = torch.empty((world * rows, 192), dtype=torch.float32, device=dev)
+            for _ in range(2):
+                sdist._gather_into(dst, src)
+            fence()
+            t1 = time.perf_counter()
+            reps = 10
+            for _ in range(reps):
+                sdist._gather_into(dst, src)
+            fence()
+            dt = torch.tensor([(time.perf_counter() - t1) / reps], dtype=torch.float64, device=dev)
+            dist.all_reduce(dt, op=dist.ReduceOp.MAX)
+            ms = float(dt.item()) * 1e3
+            recv = (world - 1) * rows * 192 * 4
+            exchange[label] = {"rows_per_rank": rows, "ms": round(ms, 4), "bytes_received_per_rank": recv,
+                               "recv_GBps_per_rank": round(recv / (ms * 1e-3) / 1e9, 1)}
+            del src, dst
+        exchange["note"] = ("torch.distributed all_gather_into_tensor (backend nccl = RCCL over xGMI); xGMI is point to point, 7 links x ~153 GB/s "
+                            "per GPU: direct-exchange floor for the config #4 shard at 8 GPUs = 672 MB / 1071 GB/s = 0.63 ms")
+
     out = None
     if rank == 0:
         ms_step = elapsed / args.steps * 1e3
@@ -255,7 +281,7 @@ def main() -> int:
                        + (", RCCL all-gather of embeddings per step" if use_dist else "")},
             "affinity_pairs_per_sec": aff["pairs_per_sec"] if aff else None,
             "roofline": roofline, "roofline_forward_mfma": fwd_mfma, "roofline_forward_hbm_model": fwd_hbm, "affinity": aff,
-            "affinity_cluster": clus,
+            "affinity_cluster": clus, "embedding_exchange": exchange,
             "kernels": kernels, "step_device_ms": round(step_dev_ms, 3),
             "device": {"name": info["name"], "arch": info["arch"], "cus": info["compute_units"], "clock_mhz": info["clock_khz"] / 1000.0},
             "peaks_used": {"bf16_mfma_tflops": PEAK_BF16_MFMA / 1e12, "hbm_gbps": PEAK_HBM / 1e9},
