@@ -350,7 +350,8 @@ __global__ __launch_bounds__(NT) void se_apply_kernel(const bf16_t* __restrict__
   bf16_t* op = out + base * ldo + c8 * 8;
   for (int t = t0 + grp; t < t1; t += ngrp) {
     float fz[8], fx[8];
-    unpack8(*reinterpret_cast<const u32x4*>(zp + (int64_t)t * ldz), fz);
+    // z is read exactly once, here: non-temporal (5.0 -> 5.3 TB/s; nt on x and on the store as well measured no better)
+    unpack8(__builtin_nontemporal_load(reinterpret_cast<const u32x4*>(zp + (int64_t)t * ldz)), fz);
     unpack8(*reinterpret_cast<const u32x4*>(xp + (int64_t)t * ldx), fx);
 #pragma unroll
     for (int e = 0; e < 8; ++e) fz[e] = g[e] * fz[e] + fx[e];
