@@ -455,7 +455,7 @@ __global__ __launch_bounds__(NT2, 2) void conv_gemm256_kernel(Params p) {
       for (int i = 0; i < 16; ++i) {
         if (16 * i < rows_left) {
           const u32x4 v = *reinterpret_cast<const u32x4*>(src + i * 16 * (BN2 * 2));
-          *reinterpret_cast<u32x4*>(dst + (int64_t)(16 * i) * p.ldc) = v;
+          __builtin_nontemporal_store(v, reinterpret_cast<u32x4*>(dst + (int64_t)(16 * i) * p.ldc));
         }
       }
     }
