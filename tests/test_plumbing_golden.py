@@ -34,6 +34,20 @@ def test_audio_profiles_variants(golden):
         assert ac.format_ffmpeg_args(ac.AudioProfile(sample_rate=sr, channels=ch, format=fmt, bit_depth=bd)) == v["ffmpeg"]
 
 
+def test_get_profile_unknown_and_register(golden):
+    """test_audio_profiles.py:83-137 - an unknown backend gets the default profile; a registered one is returned as is."""
+    d, u = ac.get_profile("default"), ac.get_profile("nonexistent_backend")
+    assert (u.sample_rate, u.channels, u.format, u.bit_depth) == (d.sample_rate, d.channels, d.format, d.bit_depth)
+    custom = ac.AudioProfile(sample_rate=44100, channels=2, format="mp3", bit_depth=24, max_duration_sec=300.0)
+    ac.register_profile("custom_test", custom)
+    try:
+        got = ac.get_profile("custom_test")
+        assert (got.sample_rate, got.channels, got.format, got.bit_depth, got.max_duration_sec) == (44100, 2, "mp3", 24, 300.0)
+        assert ac.format_ffmpeg_args(got) == ["-ar", "44100", "-ac", "2", "-f", "mp3"]        # no -acodec outside wav
+    finally:
+        ac.PROFILES.pop("custom_test", None)
+
+
 def _transcripts(golden, fixture_transcript_path):
     cases = dict(golden["transcript"]["inputs"])
     cases["fixture"] = json.loads(Path(fixture_transcript_path).read_text())
