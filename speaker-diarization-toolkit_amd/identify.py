@@ -44,9 +44,21 @@ def make_rows_fn(audio_path: Path, tags: Optional[List[str]] = None, per_label: 
     from .backend import Backend, aggregate_matches
     from .store import load_profile_batch
     be = backend or Backend()
-    cands = candidates_for(be.name, tags)
+    # the three rc-1 exits of cmd_identify before the backend is called (speaker_detection:1033-1057); speaker-assign
+    # treats them as "no signals" (speaker-assign:296), so they become an empty row list with the same message
+    if not Path(audio_path).exists():
+        print(f"Error: Audio file not found: {audio_path}", file=sys.stderr)
+        return lambda label, segs: []
+    speakers = list_all_speakers()
+    if tags:
+        speakers = [s for s in speakers if set(tags) <= set(s.get("tags", []))]
+    if not speakers:
+        print("No speakers to match against.", file=sys.stderr)
+        return lambda label, segs: []
+    cands = [s for s in speakers if s.get("embeddings", {}).get(be.name)]
     by_id = {c["id"]: c for c in cands}
     if not cands:
+        print(f"No speakers with {be.name} embeddings.", file=sys.stderr)
         return lambda label, segs: []
     if not per_label:
         rows = rows_with_trust(be.identify_speaker(audio_path, cands, threshold), by_id, be.name)

@@ -122,3 +122,23 @@ def test_backend_plugs_into_the_reference_registry(monkeypatch):
     r = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, env=env)
     assert r.returncode == 0, r.stderr
     assert r.stdout.startswith("mi355x 192 16000 mi355x-ecapa1024-")
+
+
+def test_identify_rows_early_exits_mirror_cmd_identify(tmp_path, monkeypatch, capsys):
+    """speaker_detection:1033-1057 / test_cli.py:594-634: missing audio, empty database, no embeddings for the backend -
+    the in-process row provider reports the toolkit's messages and yields no signals (no GPU is touched)."""
+    import json
+    ident = sub("identify")
+    monkeypatch.setenv("SPEAKERS_EMBEDDINGS_DIR", str(tmp_path))
+    audio = tmp_path / "a.wav"
+    wav.write_wav_s16(audio, np.zeros(16000, dtype=np.int16))
+    assert ident.make_rows_fn(tmp_path / "nonexistent.wav")("S1", []) == []
+    assert "Audio file not found" in capsys.readouterr().err
+    assert ident.make_rows_fn(audio)("S1", []) == []
+    assert "No speakers to match against." in capsys.readouterr().err
+    (tmp_path / "db").mkdir()
+    (tmp_path / "db" / "alice.json").write_text(json.dumps({"id": "alice", "tags": ["team"], "embeddings": {"speechmatics": [{"id": "e1", "external_id": "spk"}]}}))
+    assert ident.make_rows_fn(audio)("S1", []) == []
+    assert "No speakers with mi355x embeddings." in capsys.readouterr().err
+    assert ident.make_rows_fn(audio, tags=["other"])("S1", []) == []
+    assert "No speakers to match against." in capsys.readouterr().err
