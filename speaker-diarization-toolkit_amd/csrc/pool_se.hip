@@ -229,13 +229,14 @@ __global__ __launch_bounds__(NT) void rows_fc_kernel(const float* __restrict__ i
 // result is still plain fp32 arithmetic in a fixed order).  Block = 32 rows x 32 outputs, the 4 waves
 // split K; lane half h of a wave takes k = 8g + 4h + u in MFMA step u, so every lane fetches its four
 // A values with ONE 16-byte load and the B values as four coalesced 128-byte weight-row segments.
-template <int KW>   // waves per block = K slices
+template <int KW, bool WLDS = false>   // waves per block = K slices; WLDS: weight groups fetched as 16-byte rows through a wave-private LDS tile
 __global__ __launch_bounds__(KW * 64) void rows_fc_mfma_kernel(const float* __restrict__ in, int64_t ldin,
                                                          const float* __restrict__ isc, const float* __restrict__ ish,
                                                          const float* __restrict__ wt, const float* __restrict__ bias,
                                                          float* __restrict__ out, int64_t ldout, int B, int Cin, int Nout,
                                                          int act) {
   __shared__ float red[KW][32 * 33];
+  __shared__ __attribute__((aligned(16))) float wtile[WLDS ? KW : 1][8 * 32];   // one group of weights [8 k][32 outputs] per wave
   const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
   const int i = lane & 31, hh = lane >> 5;
   const int b0 = blockIdx.x * 32, n0 = blockIdx.y * 32;
@@ -256,11 +257,34 @@ __global__ __launch_bounds__(KW * 64) void rows_fc_mfma_kernel(const float* __re
 #pragma unroll
       for (int u = 0; u < 4; ++u) a[u] = a[u] * s4[u] + t4[u];
     }
+    if (!WLDS) {
 #pragma unroll
-    for (int u = 0; u < 4; ++u) b[u] = bp[(int64_t)(g + u) * Nout];
+      for (int u = 0; u < 4; ++u) b[u] = bp[(int64_t)(g + u) * Nout];
+    }
   };
   f32x4 fa0, fa1;
   float fb0[4], fb1[4];
+  if (WLDS) {
+    // A group's weights [8 k][32 outputs] = 1 KiB = ONE 16-byte load per lane (lane -> k = lane >> 3, 4 outputs) instead of
+    // four 4-byte column loads per lane: the long-K FCs are bound by L2 request rate.  The tile is private to the wave
+    // (same-wave LDS operations execute in order), so no barrier is involved.
+    const float* wq = wt + (int64_t)(wid * kw + (lane >> 3)) * Nout + n0 + (lane & 7) * 4;
+    float* tw = &wtile[wid][(lane >> 3) * 32 + (lane & 7) * 4];
+    const float* tr = &wtile[wid][(4 * hh) * 32 + i];
+    f32x4 wcur = *reinterpret_cast<const f32x4*>(wq), wnxt = wcur;
+    fetch(0, fa0, fb0);
+    for (int g = 0; g < kw; g += 8) {
+      if (g + 8 < kw) {
+        wnxt = *reinterpret_cast<const f32x4*>(wq + (int64_t)(g + 8) * Nout);
+        fetch(g + 8, fa1, fb1);
+      }
+      *reinterpret_cast<f32x4*>(tw) = wcur;
+#pragma unroll
+      for (int u = 0; u < 4; ++u) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(fa0[u], tr[u * 32], acc, 0, 0, 0);
+      wcur = wnxt;
+      fa0 = fa1;
+    }
+  } else {
   fetch(0, fa0, fb0);
   for (int g = 0; g < kw; g += 16) {
     if (g + 8 < kw) fetch(g + 8, fa1, fb1);
@@ -271,6 +295,7 @@ __global__ __launch_bounds__(KW * 64) void rows_fc_mfma_kernel(const float* __re
 #pragma unroll
       for (int u = 0; u < 4; ++u) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(fa1[u], fb1[u], acc, 0, 0, 0);
     }
+  }
   }
 #pragma unroll
   for (int r = 0; r < 16; ++r) red[wid][((r & 3) + 8 * (r >> 2) + 4 * hh) * 33 + i] = acc[r];
@@ -837,7 +862,11 @@ extern "C" int sdk_rows_fc(sdk_ctx* ctx, const float* in, int64_t ldin, const fl
   SDK_REQUIRE(act >= 0 && act <= 2, "sdk_rows_fc: act=%d", act);
   ProfScope ps(ctx, stream, SDK_K_ROWS_FC, 2.0 * B * Cin * Nout, 4.0 * ((double)B * Cin + (double)Cin * Nout + (double)B * Nout));
   const bool mfma_ok = ldin % 4 == 0 && ((uintptr_t)in % 16) == 0 && (!in_scale || (((uintptr_t)in_scale | (uintptr_t)in_shift) % 16) == 0);
-  if (mfma_ok && Cin % 128 == 0 && Cin >= 2048)      // long K (context bias, final FC): 16 K-slices keep every CU busy
+  const bool wlds_ok = Nout % 32 == 0 && ((uintptr_t)wt % 16) == 0;
+  if (mfma_ok && Cin % 128 == 0 && Cin >= 2048 && wlds_ok)   // long K (context bias, final FC): 16 K-slices, weights as 16-byte rows via LDS
+    hipLaunchKernelGGL((rows_fc_mfma_kernel<16, true>), dim3(ceil_div(B, 32), ceil_div(Nout, 32)), dim3(1024), 0, (hipStream_t)stream,
+                       in, ldin, in_scale, in_shift, wt, bias, out, ldout, B, Cin, Nout, act);
+  else if (mfma_ok && Cin % 128 == 0 && Cin >= 2048)
     hipLaunchKernelGGL(rows_fc_mfma_kernel<16>, dim3(ceil_div(B, 32), ceil_div(Nout, 32)), dim3(1024), 0, (hipStream_t)stream,
                        in, ldin, in_scale, in_shift, wt, bias, out, ldout, B, Cin, Nout, act);
   else if (mfma_ok && Cin % 32 == 0)
