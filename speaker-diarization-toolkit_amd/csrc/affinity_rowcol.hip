@@ -1,0 +1,570 @@
+// k4, k = 1 (argmax) fast path: segments x profiles cosine affinity without per-score bookkeeping.
+//
+// Rows consumed at speaker_detection:1085-1127 are "best enrolled profile + score" per segment.  The general kernel
+// (scoring.hip) keeps a sorted candidate list per lane and pays 5 vector ops per score, which - not the matrix
+// pipe - bounds it.  Here a lane (one segment, one half of a 32-profile tile = 16 accumulator registers) keeps
+//     ROW maxima     T_t  = max over the 16 registers of tile t      (v_max3 tree, 8 ops per 16 scores)
+//     COLUMN maxima  C_r  = max over all tiles of register r         (16 v_max per 16 scores)
+// and a sorted top-4 of the tagged T_t (tile index in the low 10 mantissa bits; 5 ops per tile): 29 vector ops per
+// 16 scores instead of 80+.  Every score x[t][r] sits in exactly one row and one column, hence
+//     x[t][r] <= min(T_t, C_r),   and any score outside (top-3 rows) x (top-3 columns) is <= max(T_(4), C_(4)) =: u.
+// The exact pass therefore re-scores, in fp32 with the one shared dot routine (scoring_exact.hpp), the intersections
+// (t_i, r_j), i, j < 3, whose bound min(T_i, C_j) can still reach the best coarse score minus the rounding margin, and
+// certifies the winner against max(u, cut) + eps exactly as the general path does; rows it cannot certify (~1 %) take the
+// exact rescan, batched four rows per profile sweep.  Results equal an fp32 full scan: ties -> lowest profile index.
+//
+// Decomposition: ONE workgroup per CU, a contiguous range of (segment group, profile stage) units, so every CU gets
+// the same amount of matrix work whatever N and P are (a group's sweep may be split over up to 3 workgroups = "parts";
+// each part writes its own row/column record).  Profile stages of TPS tiles stream through a 3-deep LDS ring filled by
+// LDS-DMA; the ring runs ahead across group boundaries.
+#include <stdlib.h>
+
+#include "common.hpp"
+#include "scoring_exact.hpp"
+
+using namespace sdk_exact;
+
+namespace {
+
+constexpr int KS = D / 16;             // 12 MFMA k-steps (32x32x16)
+constexpr int PT = 32;                 // profiles per MFMA tile
+constexpr int PROWB = 384;             // LDS bytes per profile row (24 chunks of 16 B, XOR-swizzled)
+constexpr int TILE_BYTES = PT * PROWB; // 12 KiB
+constexpr int MAXP = 3;                // record slots per segment = parts of a group's sweep (the geometry gives <= 3: tests/test_cabi_cpu.py)
+constexpr uint32_t TMASK = 0x3ffu;     // tile tag: 10 bits (<= 1024 tiles = 32768 profiles per part)
+constexpr uint32_t CMASK = 0xfu;       // column tag: the accumulator register
+constexpr float MASKED = -4.0f;        // stands for "no such profile" (cosines are >= -1 - eps); finite so tags never make a NaN
+constexpr float EMPTY = -8.0f;
+
+struct Geom {            // host-computed, identical on both sides
+  int ngroups, nst, G, segs;   // segment groups, stages per group, workgroups, segments per group
+  long long U;                 // units = ngroups * nst
+};
+
+template <int DEPTH>
+__device__ __forceinline__ void insert_sorted(float x, float* m) {
+  float n[DEPTH];
+#pragma unroll
+  for (int q = DEPTH - 1; q >= 1; --q) n[q] = __builtin_amdgcn_fmed3f(x, m[q - 1], m[q]);
+  n[0] = fmaxf(x, m[0]);
+#pragma unroll
+  for (int q = 0; q < DEPTH; ++q) m[q] = n[q];
+}
+
+__device__ __forceinline__ float max3(float a, float b, float c) { return fmaxf(fmaxf(a, b), c); }
+
+// WAVES waves x SEGB blocks of 32 segments; TPS tiles per LDS stage; NSTAGE stages.
+template <int WAVES, int SEGB, int TPS, int NSTAGE>
+__global__ __launch_bounds__(WAVES * 64) void aff_rowcol_kernel(const bf16_t* __restrict__ Eb, const bf16_t* __restrict__ Pb,
+                                                               int N, int P, Geom gm, float* __restrict__ stats,
+                                                               int32_t* __restrict__ part_base, int32_t* __restrict__ part_cnt,
+                                                               int32_t* __restrict__ err) {
+  constexpr int STAGE_BYTES = TPS * TILE_BYTES;
+  constexpr int DMA_PER_STAGE = STAGE_BYTES / 1024;
+  static_assert(DMA_PER_STAGE % WAVES == 0, "stage must split evenly over the waves");
+  constexpr int DPW = DMA_PER_STAGE / WAVES;
+  constexpr int SEGS = WAVES * SEGB * 32;
+  extern __shared__ __attribute__((aligned(16))) char sP[];
+  const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
+  const int col = lane & 31, h = lane >> 5;
+  const long long u0 = ((long long)blockIdx.x * gm.U) / gm.G, u1 = ((long long)(blockIdx.x + 1) * gm.U) / gm.G;
+  const int nst = gm.nst;
+  const int ntiles = (P + PT - 1) / PT;
+
+  // DMA assignment: a stage is DMA_PER_STAGE wave-instructions of 1 KiB; wave w issues instructions w*DPW .. w*DPW+DPW-1
+  int drow[DPW], dsrc[DPW];
+#pragma unroll
+  for (int i = 0; i < DPW; ++i) {
+    const int id = (wid * DPW + i) * 64 + lane;
+    const int row = id / 24, pos = id - row * 24;
+    drow[i] = row;
+    dsrc[i] = ((pos & ~7) | ((pos & 7) ^ ((row >> 1) & 7))) * 8;    // source chunk (elements)
+  }
+  int s_issue = (int)(u0 % nst), k_issue = 0;
+  auto issue = [&]() {                                               // next stage of the running sequence
+    char* st = sP + (k_issue % NSTAGE) * STAGE_BYTES;
+#pragma unroll
+    for (int i = 0; i < DPW; ++i) {
+      int pr = s_issue * (TPS * PT) + drow[i];
+      pr = pr < P ? pr : P - 1;
+      __builtin_amdgcn_global_load_lds((const void __attribute__((address_space(1)))*)(Pb + (int64_t)pr * D + dsrc[i]),
+                                       (void __attribute__((address_space(3)))*)(st + (wid * DPW + i) * 1024), 16, 0, 0);
+    }
+    ++k_issue;
+    if (++s_issue == nst) s_issue = 0;
+  };
+
+  int b = (int)(u0 / nst), s = (int)(u0 % nst);
+  // slot of the first portion = number of earlier workgroups that share its group
+  int slot;
+  {
+    const long long x = (long long)b * nst;
+    const long long ifirst = ((x + 1) * gm.G + gm.U - 1) / gm.U - 1;
+    slot = (int)(blockIdx.x - ifirst);
+  }
+
+  bf16x8 bfrag[SEGB][KS];
+  float C[SEGB][16], tl[SEGB][4];
+  int ltile = 0;
+  auto begin_portion = [&]() {
+#pragma unroll
+    for (int sb = 0; sb < SEGB; ++sb) {
+      const int seg = b * SEGS + (wid * SEGB + sb) * 32 + col;
+      const int seg_c = seg < N ? seg : N - 1;
+#pragma unroll
+      for (int ks = 0; ks < KS; ++ks)
+        bfrag[sb][ks] = *reinterpret_cast<const bf16x8*>(Eb + (int64_t)seg_c * D + ks * 16 + h * 8);
+#pragma unroll
+      for (int r = 0; r < 16; ++r) C[sb][r] = EMPTY;
+#pragma unroll
+      for (int q = 0; q < 4; ++q) tl[sb][q] = EMPTY;
+    }
+    ltile = 0;
+    if (tid == 0) {
+      if (slot < MAXP) part_base[b * MAXP + slot] = s * TPS;
+      else atomicAdd(err, 1);
+    }
+  };
+  auto end_portion = [&](bool group_done) {
+#pragma unroll
+    for (int sb = 0; sb < SEGB; ++sb) {
+      float cl[4] = {EMPTY, EMPTY, EMPTY, EMPTY};
+#pragma unroll
+      for (int r = 0; r < 16; ++r)
+        insert_sorted<4>(__uint_as_float((__float_as_uint(C[sb][r]) & ~CMASK) | (uint32_t)r), cl);
+      const int seg = b * SEGS + (wid * SEGB + sb) * 32 + col;
+      if (seg < N && slot < MAXP) {
+        float* dst = stats + (((int64_t)seg * MAXP + slot) * 2 + h) * 8;
+        f32x4 tv, cv;
+#pragma unroll
+        for (int q = 0; q < 4; ++q) { tv[q] = tl[sb][q]; cv[q] = cl[q]; }
+        *reinterpret_cast<f32x4*>(dst) = tv;
+        *reinterpret_cast<f32x4*>(dst + 4) = cv;
+      }
+    }
+    if (group_done && tid == 0) part_cnt[b] = slot + 1;
+  };
+
+  if (u0 >= u1) return;
+  constexpr int AHEAD = NSTAGE - 1;                // stages in flight
+#pragma unroll
+  for (int a = 0; a < AHEAD; ++a)
+    if (u0 + a < u1) issue();
+  const int rsw = (col >> 1) & 7;
+  int k = 0;
+  long long u = u0;
+  while (u < u1) {                                 // one portion = this workgroup's share of one group's sweep
+    const long long gend = (long long)(b + 1) * nst;
+    const long long uend = gend < u1 ? gend : u1;
+    // The segment fragments are ordinary loads issued OUTSIDE the stage loop, so the compiler drains them once here and
+    // the stage loop keeps its counted waits (a load inside the loop makes it wait vmcnt(0) before every tile).
+    begin_portion();
+    for (; u < uend; ++u, ++k) {
+      // stage u must have landed; the stages issued after it (at most AHEAD - 1) may stay in flight
+      const long long after = u1 - 1 - u < AHEAD - 1 ? u1 - 1 - u : AHEAD - 1;
+      if (after >= 2) {
+        if constexpr (DPW == 3) asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
+        else if constexpr (DPW == 6) asm volatile("s_waitcnt vmcnt(12)" ::: "memory");
+        else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      } else if (after == 1) {
+        if constexpr (DPW == 3) asm volatile("s_waitcnt vmcnt(3)" ::: "memory");
+        else if constexpr (DPW == 6) asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
+        else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      } else {
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      }
+      __builtin_amdgcn_s_barrier();                 // stage k landed for everyone; the buffer of stage k-1 is free
+      if (u + AHEAD < u1) issue();
+      const char* stg = sP + (k % NSTAGE) * STAGE_BYTES + col * PROWB;
+#pragma unroll
+      for (int tt = 0; tt < TPS; ++tt) {
+        const int tile = s * TPS + tt;
+        if (tile < ntiles) {                         // wave-uniform
+          const char* st = stg + tt * TILE_BYTES;
+          f32x16 acc[SEGB];
+#pragma unroll
+          for (int sb = 0; sb < SEGB; ++sb)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[sb][r] = 0.f;
+#pragma unroll
+          for (int ks = 0; ks < KS; ++ks) {
+            const int c = ks * 2 + h;
+            const bf16x8 a = *reinterpret_cast<const bf16x8*>(st + (((c & ~7) | ((c & 7) ^ rsw)) << 4));
+#pragma unroll
+            for (int sb = 0; sb < SEGB; ++sb) acc[sb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, bfrag[sb][ks], acc[sb], 0, 0, 0);
+          }
+          if ((tile + 1) * PT > P) {                 // last, partial tile: rows past the last profile never count
+#pragma unroll
+            for (int sb = 0; sb < SEGB; ++sb)
+#pragma unroll
+              for (int r = 0; r < 16; ++r)
+                if (tile * PT + (r & 3) + 8 * (r >> 2) + 4 * h >= P) acc[sb][r] = MASKED;
+          }
+#pragma unroll
+          for (int sb = 0; sb < SEGB; ++sb) {
+            const f32x16& a = acc[sb];
+            const float m0 = max3(a[0], a[1], a[2]), m1 = max3(a[3], a[4], a[5]), m2 = max3(a[6], a[7], a[8]);
+            const float m3 = max3(a[9], a[10], a[11]), m4 = max3(a[12], a[13], a[14]);
+            const float T = fmaxf(max3(m0, m1, m2), max3(m3, m4, a[15]));
+#pragma unroll
+            for (int r = 0; r < 16; ++r) C[sb][r] = fmaxf(C[sb][r], a[r]);
+            insert_sorted<4>(__uint_as_float((__float_as_uint(T) & ~TMASK) | (uint32_t)ltile), tl[sb]);
+          }
+          ++ltile;
+        }
+      }
+      ++s;
+    }
+    end_portion(s == nst);
+    if (s == nst) { ++b; s = 0; slot = 0; }         // the next portion starts a new group
+  }
+}
+
+// ---- exact pass ------------------------------------------------------------------------------------------------------
+// 8 lanes per segment row.  Lane j looks after half (j >> 2) of every part and, of that half's 3 x 3 intersections
+// (i, j) = (c / 3, c % 3), the combinations c = (j & 3), (j & 3) + 4, (j & 3) + 8.  The live ones are gathered into one
+// list per row (identical on the 8 lanes) and scored two at a time with the shared dot routine.
+constexpr int MAXC = 8;                // candidates re-scored per row; more than that (rare) -> the row takes the rescan
+
+__global__ __launch_bounds__(256) void aff_rowcol_rescore_kernel(const float* __restrict__ E, const float* __restrict__ Pm,
+                                                                const float* __restrict__ resid_e,
+                                                                const float* __restrict__ resid_p, int N, int P, int segs,
+                                                                const float* __restrict__ stats,
+                                                                const int32_t* __restrict__ part_base,
+                                                                const int32_t* __restrict__ part_cnt,
+                                                                int32_t* __restrict__ idx, float* __restrict__ score,
+                                                                int32_t* __restrict__ flag_count, int32_t* __restrict__ flag_rows) {
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int j = tid & 7, hh = j >> 2, sl = j & 3;
+  const int row = blockIdx.x * 32 + (tid >> 3);
+  const bool live = row < N;
+  const int rc = live ? row : N - 1;
+  const int grp = rc / segs;
+  // everything that does not depend on other loads is requested up front
+  f32x4 T4[MAXP], C4[MAXP];
+  int pb[MAXP];
+#pragma unroll
+  for (int p = 0; p < MAXP; ++p) {       // slots a group does not use hold stale bytes: masked by np below
+    const float* src = stats + (((int64_t)rc * MAXP + p) * 2 + hh) * 8;
+    T4[p] = *reinterpret_cast<const f32x4*>(src);
+    C4[p] = *reinterpret_cast<const f32x4*>(src + 4);
+    pb[p] = part_base[grp * MAXP + p];
+  }
+  int np = part_cnt[grp];
+  np = np < MAXP ? np : MAXP;
+  const float re = resid_e[rc];
+  float e24[24];
+#pragma unroll
+  for (int q = 0; q < 6; ++q) {
+    const f32x4 v = *reinterpret_cast<const f32x4*>(E + (int64_t)rc * D + 24 * j + 4 * q);
+    e24[4 * q] = v[0]; e24[4 * q + 1] = v[1]; e24[4 * q + 2] = v[2]; e24[4 * q + 3] = v[3];
+  }
+  // rigorous |exact - coarse| bound for this row (resid_p = max profile residual); the slack covers the tag bits
+  // (2^-13 relative), the MFMA's fp32 accumulation and this formula's own rounding
+  const float eps = (re + (1.0f + re) * resid_p[0]) * 1.0001f + 1.5e-4f;
+  float best = -INFINITY;
+#pragma unroll
+  for (int p = 0; p < MAXP; ++p)
+    if (p < np) best = fmaxf(best, __uint_as_float(__float_as_uint(T4[p][0]) & ~TMASK));
+  best = fmaxf(best, __shfl_xor(best, 4, 64));                       // the other half
+  const int gsh = lane & ~7;
+  // Phase 1: the exact score s1 of the best coarse entry (intersection (0, 0) of the half that holds it).  Any exact
+  // score is a lower bound on the winner's, so everything whose bound is below s1 - eps cannot win: a far tighter cut
+  // than best - 3 eps (which assumes the worst about the best entry's own rounding).
+  int first = -1;
+#pragma unroll
+  for (int p = 0; p < MAXP; ++p) {
+    if (p < np && sl == 0 && __uint_as_float(__float_as_uint(T4[p][0]) & ~TMASK) == best) {
+      const uint32_t tb = __float_as_uint(T4[p][0]) & TMASK, r = __float_as_uint(C4[p][0]) & CMASK;
+      const int pidx = ((int)tb + pb[p]) * PT + (int)((r & 3) + 8 * (r >> 2)) + 4 * hh;
+      if (pidx < P) first = pidx;
+    }
+  }
+  float bs;
+  int bi;
+  {
+    const uint32_t bits = (uint32_t)(__ballot(first >= 0) >> gsh) & 0xffu;
+    const int o = bits ? __ffs(bits) - 1 : 0;
+    bi = __shfl(first, gsh + o, 64);
+    bi = bi >= 0 ? bi : 0;                                           // cannot happen for P >= 1; stay in bounds regardless
+    bs = dot192_group8(e24, Pm + (int64_t)bi * D, j);
+  }
+  const int c_first = bi;
+  const float cut = fmaxf(best - 3.0f * eps, bs - eps);
+  float u = -INFINITY;
+  int mine[MAXP][3];
+#pragma unroll
+  for (int p = 0; p < MAXP; ++p) {
+#pragma unroll
+    for (int q = 0; q < 3; ++q) mine[p][q] = -1;
+    if (p < np) {
+      float Tv[4], Cv[4];
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        Tv[q] = __uint_as_float(__float_as_uint(T4[p][q]) & ~TMASK);
+        Cv[q] = __uint_as_float(__float_as_uint(C4[p][q]) & ~CMASK);
+      }
+      u = fmaxf(u, fmaxf(Tv[3], Cv[3]));
+#pragma unroll
+      for (int q = 0; q < 3; ++q) {
+        const int c = sl + 4 * q;                       // combination owned by this lane
+        if (c < 9) {
+          const int ii = c / 3, jj = c - 3 * ii;
+          const float tv = ii == 0 ? Tv[0] : ii == 1 ? Tv[1] : Tv[2];
+          const float cv = jj == 0 ? Cv[0] : jj == 1 ? Cv[1] : Cv[2];
+          if (tv >= cut && cv >= cut) {                 // x[t][r] <= min(T_t, C_r): may still matter
+            const uint32_t tb = __float_as_uint(ii == 0 ? T4[p][0] : ii == 1 ? T4[p][1] : T4[p][2]) & TMASK;
+            const uint32_t r = __float_as_uint(jj == 0 ? C4[p][0] : jj == 1 ? C4[p][1] : C4[p][2]) & CMASK;
+            const int pidx = ((int)tb + pb[p]) * PT + (int)((r & 3) + 8 * (r >> 2)) + 4 * hh;
+            if (pidx < P && pidx != c_first) mine[p][q] = pidx;
+          }
+        }
+      }
+    }
+  }
+  // Phase 2: the row's remaining candidates, gathered into one list (identical on its 8 lanes), scored two at a time
+  int list[MAXC];
+#pragma unroll
+  for (int m = 0; m < MAXC; ++m) list[m] = 0;
+  int M = 0;
+#pragma unroll
+  for (int p = 0; p < MAXP; ++p) {
+#pragma unroll
+    for (int q = 0; q < 3; ++q) {
+      const unsigned long long bal = __ballot(mine[p][q] >= 0);
+      uint32_t bits = (uint32_t)(bal >> gsh) & 0xffu;
+      while (bits) {                                               // uniform inside a lane group
+        const int o = __ffs(bits) - 1;
+        bits &= bits - 1;
+        const int ci = __shfl(mine[p][q], gsh + o, 64);
+#pragma unroll
+        for (int m = 0; m < MAXC; ++m)
+          if (m == M) list[m] = ci;
+        ++M;
+      }
+    }
+  }
+#pragma unroll
+  for (int m = 0; m < MAXC; m += 2) {
+    if (m < M) {                                                   // uniform inside a lane group
+      const int c0 = list[m], c1 = m + 1 < M ? list[m + 1] : list[m];
+      f32x4 pv0[6], pv1[6];
+      load_prow(Pm + (int64_t)c0 * D, j, pv0);
+      load_prow(Pm + (int64_t)c1 * D, j, pv1);
+      const float s0 = dot192_regs(e24, pv0);
+      const float s1 = dot192_regs(e24, pv1);
+      if (better(s0, c0, bs, bi)) { bs = s0; bi = c0; }
+      if (better(s1, c1, bs, bi)) { bs = s1; bi = c1; }           // c1 == c0 when the list is odd: no effect
+    }
+  }
+  u = fmaxf(u, __shfl_xor(u, 4, 64));
+  if (live && j == 0) {
+    // What was not re-scored: (a) entries outside the top-3 rows x top-3 columns: coarse <= u, exact <= u + eps;
+    // (b) intersections pruned by best - 3 eps: exact < best - 2 eps; (c) intersections pruned by s1 - eps: exact < s1
+    // (the slack inside eps exceeds the tag truncation), and s1 <= the winner's score by construction.
+    const float outside = fmaxf(u + eps, best - 2.0f * eps);
+    const bool uncertain = M > MAXC || !(bs > outside);
+    if (uncertain) {
+      const int slot = atomicAdd(flag_count, 1);
+      flag_rows[slot] = row;
+    }
+    idx[row] = bi;
+    score[row] = bs;
+  }
+}
+
+// ---- exact rescan of the rows the certificate could not settle ----------------------------------------------------------
+// Work item = (four flagged rows, slice of 256 profiles): a profile row fetched from L2 is scored against four segment
+// rows held in registers (the old form streamed all of P once PER flagged row: 768 MB of L2 traffic at config #3).
+constexpr int RS_SLICE = 256, RS_ROWS = 4;
+
+__device__ __forceinline__ void group_best32(float& s, int& i) {     // best over the 32 lanes 0..31 of a wave
+#pragma unroll
+  for (int o = 16; o > 0; o >>= 1) {
+    const float ts = __shfl_xor(s, o, 64);
+    const int ti = __shfl_xor(i, o, 64);
+    if (better(ts, ti, s, i)) { s = ts; i = ti; }
+  }
+}
+
+__global__ __launch_bounds__(256) void aff_rescan4_kernel(const float* __restrict__ E, const float* __restrict__ Pm, int P,
+                                                         const int32_t* __restrict__ flag_count,
+                                                         const int32_t* __restrict__ flag_rows, float* __restrict__ part_s,
+                                                         int32_t* __restrict__ part_i, int32_t* __restrict__ idx,
+                                                         float* __restrict__ score) {
+  __shared__ float ls[RS_ROWS][32];
+  __shared__ int li[RS_ROWS][32];
+  const int tid = threadIdx.x, j = tid & 7, g = tid >> 3;
+  const int count = *flag_count;
+  const int nsl = (P + RS_SLICE - 1) / RS_SLICE;
+  const int nq = (count + RS_ROWS - 1) / RS_ROWS;
+  for (int item = blockIdx.x; item < nq * nsl; item += gridDim.x) {
+    const int q = item / nsl, sl = item - q * nsl;
+    const int p0 = sl * RS_SLICE, p1 = min(P, p0 + RS_SLICE);
+    float e24[RS_ROWS][24];
+#pragma unroll
+    for (int x = 0; x < RS_ROWS; ++x) {
+      const int f = min(q * RS_ROWS + x, count - 1);
+      const int row = flag_rows[f];
+#pragma unroll
+      for (int qq = 0; qq < 6; ++qq) {
+        const f32x4 v = *reinterpret_cast<const f32x4*>(E + (int64_t)row * D + 24 * j + 4 * qq);
+        e24[x][4 * qq] = v[0]; e24[x][4 * qq + 1] = v[1]; e24[x][4 * qq + 2] = v[2]; e24[x][4 * qq + 3] = v[3];
+      }
+    }
+    float bs[RS_ROWS];
+    int bi[RS_ROWS];
+#pragma unroll
+    for (int x = 0; x < RS_ROWS; ++x) { bs[x] = -INFINITY; bi[x] = 0x7fffffff; }
+    for (int p = p0 + g; p < p1; p += 64) {                     // two profile rows in flight per lane group
+      f32x4 pv[2][6];
+      const int pb = p + 32;
+      load_prow(Pm + (int64_t)p * D, j, pv[0]);
+      load_prow(Pm + (int64_t)(pb < p1 ? pb : p1 - 1) * D, j, pv[1]);
+#pragma unroll
+      for (int x = 0; x < RS_ROWS; ++x) {
+        const float sc = dot192_regs(e24[x], pv[0]);
+        if (better(sc, p, bs[x], bi[x])) { bs[x] = sc; bi[x] = p; }
+      }
+#pragma unroll
+      for (int x = 0; x < RS_ROWS; ++x) {
+        const float sc = dot192_regs(e24[x], pv[1]);              // every lane of the group runs the shuffles
+        if (pb < p1 && better(sc, pb, bs[x], bi[x])) { bs[x] = sc; bi[x] = pb; }
+      }
+    }
+    if (j == 0) {
+#pragma unroll
+      for (int x = 0; x < RS_ROWS; ++x) { ls[x][g] = bs[x]; li[x][g] = bi[x]; }
+    }
+    __syncthreads();
+    {
+      const int x = tid >> 6, l = tid & 63;                        // wave x settles row x
+      float s = l < 32 ? ls[x][l] : -INFINITY;
+      int i = l < 32 ? li[x][l] : 0x7fffffff;
+      group_best32(s, i);
+      const int f = q * RS_ROWS + x;
+      if (l == 0 && f < count) {
+        if (nsl == 1) { const int row = flag_rows[f]; idx[row] = i; score[row] = s; }
+        else { part_s[(int64_t)f * nsl + sl] = s; part_i[(int64_t)f * nsl + sl] = i; }
+      }
+    }
+    __syncthreads();
+  }
+}
+
+__global__ __launch_bounds__(64) void aff_rescan4_merge_kernel(int P, const int32_t* __restrict__ flag_count,
+                                                              const int32_t* __restrict__ flag_rows,
+                                                              const float* __restrict__ part_s, const int32_t* __restrict__ part_i,
+                                                              int32_t* __restrict__ idx, float* __restrict__ score) {
+  const int nsl = (P + RS_SLICE - 1) / RS_SLICE;
+  if (nsl == 1) return;
+  const int count = *flag_count, lane = threadIdx.x;
+  for (int f = blockIdx.x; f < count; f += gridDim.x) {
+    float s = -INFINITY;
+    int i = 0x7fffffff;
+    for (int e = lane; e < nsl; e += 64) {
+      const float ts = part_s[(int64_t)f * nsl + e];
+      const int ti = part_i[(int64_t)f * nsl + e];
+      if (better(ts, ti, s, i)) { s = ts; i = ti; }
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) {
+      const float ts = __shfl_xor(s, o, 64);
+      const int ti = __shfl_xor(i, o, 64);
+      if (better(ts, ti, s, i)) { s = ts; i = ti; }
+    }
+    if (lane == 0) { const int row = flag_rows[f]; idx[row] = i; score[row] = s; }
+  }
+}
+
+__global__ void copy_count_kernel(const int32_t* src, int32_t* dst) { *dst = *src; }
+
+struct Ws {
+  float* stats; int32_t* part_base; int32_t* part_cnt; int32_t* flag_count; int32_t* flag_rows; float* part_s; int32_t* part_i;
+};
+inline size_t al256(size_t v) { return (v + 255) & ~(size_t)255; }
+size_t ws_layout(int N, int P, char* base, Ws* w) {
+  size_t off = 0;
+  auto take = [&](size_t bytes) { char* p = base ? base + off : nullptr; off += al256(bytes); return p; };
+  const size_t ngroups_max = (size_t)(N + 255) / 256;          // the smallest group any variant uses
+  const size_t nsl = (size_t)(P + RS_SLICE - 1) / RS_SLICE;
+  char* a = take((size_t)N * MAXP * 2 * 8 * 4);
+  char* b = take(ngroups_max * MAXP * 4);
+  char* c = take(ngroups_max * 4);
+  char* d = take(256);                                          // flag_count, err
+  char* e = take((size_t)N * 4);
+  char* f1 = take(nsl > 1 ? (size_t)N * nsl * 4 : 16);
+  char* f2 = take(nsl > 1 ? (size_t)N * nsl * 4 : 16);
+  if (w) { w->stats = (float*)a; w->part_base = (int32_t*)b; w->part_cnt = (int32_t*)c; w->flag_count = (int32_t*)d;
+           w->flag_rows = (int32_t*)e; w->part_s = (float*)f1; w->part_i = (int32_t*)f2; }
+  return off;
+}
+
+template <int WAVES, int SEGB, int TPS, int NSTAGE>
+int launch_coarse(sdk_ctx* ctx, const bf16_t* Eb, const bf16_t* Pb, int N, int P, const Ws& w, int32_t* err, hipStream_t s) {
+  constexpr int SEGS = WAVES * SEGB * 32;
+  constexpr int LDS = NSTAGE * TPS * TILE_BYTES;
+  Geom gm;
+  gm.segs = SEGS;
+  gm.ngroups = ceil_div(N, SEGS);
+  const int ntiles = ceil_div(P, PT);
+  gm.nst = ceil_div(ntiles, TPS);
+  gm.U = (long long)gm.ngroups * gm.nst;
+  long long G = ctx->num_cu;
+  if (G > 2LL * gm.ngroups) G = 2LL * gm.ngroups;     // a group's sweep is split over <= 3 workgroups (MAXP slots)
+  if (G > gm.U) G = gm.U;
+  gm.G = (int)G;
+  auto kern = aff_rowcol_kernel<WAVES, SEGB, TPS, NSTAGE>;
+  if (sdk_lds_optin(ctx, (const void*)kern, LDS)) return 1;
+  hipLaunchKernelGGL(kern, dim3(gm.G), dim3(WAVES * 64), LDS, s, Eb, Pb, N, P, gm, w.stats, w.part_base, w.part_cnt, err);
+  return 0;
+}
+
+}  // namespace
+
+size_t aff_rowcol_workspace_bytes(int N, int P) { return ws_layout(N, P, nullptr, nullptr); }
+bool aff_rowcol_supported(int P) { return P <= 32768; }
+
+// k = 1.  Same contract as sdk_affinity_topk (which dispatches here).
+int aff_rowcol_top1(sdk_ctx* ctx, const float* E, const uint16_t* Eb, const float* resid_e, const float* P, const uint16_t* Pb,
+                    const float* resid_p, int N, int Pn, int32_t* idx, float* score, int32_t* n_rescanned, void* ws,
+                    void* stream) {
+  hipStream_t s = (hipStream_t)stream;
+  Ws w;
+  ws_layout(N, Pn, (char*)ws, &w);
+  SDK_HIP_OK(hipMemsetAsync(w.flag_count, 0, 2 * sizeof(int32_t), s));
+  int32_t* err = w.flag_count + 1;
+  int segs;
+  {
+    ProfScope ps(ctx, stream, SDK_K_AFF_COARSE, 2.0 * N * (double)Pn * D, 2.0 * ((double)N + Pn) * D + 64.0 * N);
+    int rc;
+    switch (ctx->aff_variant) {
+      case 1: rc = launch_coarse<4, 2, 2, 4>(ctx, (const bf16_t*)Eb, (const bf16_t*)Pb, N, Pn, w, err, s); segs = 256; break;
+      case 2: rc = launch_coarse<8, 2, 2, 4>(ctx, (const bf16_t*)Eb, (const bf16_t*)Pb, N, Pn, w, err, s); segs = 512; break;
+      case 3: rc = launch_coarse<8, 1, 2, 4>(ctx, (const bf16_t*)Eb, (const bf16_t*)Pb, N, Pn, w, err, s); segs = 256; break;
+      default: rc = launch_coarse<8, 2, 4, 3>(ctx, (const bf16_t*)Eb, (const bf16_t*)Pb, N, Pn, w, err, s); segs = 512; break;
+    }
+    if (rc) return rc;
+  }
+  SDK_LAUNCH_CHECK();
+  {
+    ProfScope ps(ctx, stream, SDK_K_AFF_RESCORE, 0.0, 4.0 * N * D + 64.0 * N + 8.0 * N);
+    hipLaunchKernelGGL(aff_rowcol_rescore_kernel, dim3(ceil_div(N, 32)), dim3(256), 0, s, E, P, resid_e, resid_p, N, Pn, segs,
+                       w.stats, w.part_base, w.part_cnt, idx, score, w.flag_count, w.flag_rows);
+  }
+  SDK_LAUNCH_CHECK();
+  {
+    ProfScope ps(ctx, stream, SDK_K_AFF_RESCAN, 0.0, 0.0);
+    hipLaunchKernelGGL(aff_rescan4_kernel, dim3(1024), dim3(256), 0, s, E, P, Pn, w.flag_count, w.flag_rows, w.part_s, w.part_i,
+                       idx, score);
+    if (Pn > RS_SLICE)
+      hipLaunchKernelGGL(aff_rescan4_merge_kernel, dim3(256), dim3(64), 0, s, Pn, w.flag_count, w.flag_rows, w.part_s, w.part_i,
+                         idx, score);
+  }
+  SDK_LAUNCH_CHECK();
+  if (n_rescanned) {
+    hipLaunchKernelGGL(copy_count_kernel, dim3(1), dim3(1), 0, s, w.flag_count, n_rescanned);
+    SDK_LAUNCH_CHECK();
+  }
+  return 0;
+}

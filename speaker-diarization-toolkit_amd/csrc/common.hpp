@@ -30,8 +30,15 @@ struct sdk_ctx {
   bool prof_on = false;
   bool no_chain_fusion = false;   // A/B + test knob: run the Res2Net chain as separate conv_gemm launches
   bool no_asp_seg = false;        // A/B + test knob: ASP by (segment, 128-channel) workgroups instead of one per segment
+  int aff_fast = 1;               // k = 1 affinity: 1 = row/column-maxima kernel (affinity_rowcol.hip), 0 = general sorted-list kernel
+  int aff_variant = 0;            // A/B knob: workgroup shape of the row/column kernel (see affinity_rowcol.hip)
+  std::vector<const void*> lds_optin;   // kernels of THIS context's device already opted in to > 64 KiB dynamic LDS
   std::vector<sdk_prof_rec> prof;
 };
+
+// > 64 KiB of dynamic LDS needs a per-function, per-device opt-in: tracked per context (one context = one device),
+// with the context's device made current first, so a second Engine on another GPU of the same process gets its own.
+int sdk_lds_optin(sdk_ctx* ctx, const void* func, int bytes);
 
 struct ProfScope {   // brackets one kernel launch with two events when profiling is enabled
   sdk_ctx* c; hipStream_t s; size_t slot; bool on;

@@ -550,8 +550,6 @@ extern "C" int sdk_colstats_finish(sdk_ctx* ctx, const float* stats_part, int M,
 }
 
 extern "C" int sdk_set_gemm_variant(int v) {   // tuning knob: 1 = 128^2 register-staged, 2 = 256^2 LDS-DMA (default)
-  if (g_gemm_variant < 0)
-    SDK_HIP_OK(hipFuncSetAttribute((const void*)conv_gemm256_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, LDS2_TOTAL));
   g_gemm_variant = v;
   return 0;
 }
@@ -576,8 +574,8 @@ extern "C" int sdk_conv_gemm(sdk_ctx* ctx, const sdk_conv_gemm_args* a, void* st
   if (g_gemm_variant < 0) {
     const char* e = getenv("SDK_GEMM_VARIANT");
     g_gemm_variant = e ? atoi(e) : 2;
-    SDK_HIP_OK(hipFuncSetAttribute((const void*)conv_gemm256_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, LDS2_TOTAL));
   }
+  if (sdk_lds_optin(ctx, (const void*)conv_gemm256_kernel, LDS2_TOTAL)) return 1;
   Params p;
   p.A = (const bf16_t*)a->A; p.lda = a->lda; p.W = (const bf16_t*)a->W;
   p.C = (bf16_t*)a->C; p.ldc = a->ldc; p.C32 = a->C32; p.ldc32 = a->ldc32;

@@ -900,11 +900,7 @@ extern "C" int sdk_asp_fused(sdk_ctx* ctx, const uint16_t* ah, int64_t ldah, con
   SDK_REQUIRE(C % 128 == 0 && ldah % 8 == 0 && ldh % 8 == 0, "sdk_asp_fused: C=%d must be a multiple of 128", C);
   ProfScope ps(ctx, stream, SDK_K_ASP_FUSED, 2.0 * B * T * (double)A * C, 2.0 * B * T * ((double)C + A) + 8.0 * B * C);
   if (T > 96 && T <= SEG_ROWS && C % 256 == 0 && !ctx->no_asp_seg) {     // one workgroup per segment (hidden tile read once)
-    static bool attr_set = false;
-    if (!attr_set) {
-      SDK_HIP_OK(hipFuncSetAttribute((const void*)asp_seg_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, SEG_LDS));
-      attr_set = true;
-    }
+    if (sdk_lds_optin(ctx, (const void*)asp_seg_kernel, SEG_LDS)) return 1;
     hipLaunchKernelGGL(asp_seg_kernel, dim3(B), dim3(SEG_NT), SEG_LDS, (hipStream_t)stream, (const bf16_t*)ah, ldah, (const bf16_t*)w2,
                        (const bf16_t*)h, ldh, T, C, pooled);
     SDK_LAUNCH_CHECK();

@@ -189,12 +189,8 @@ extern "C" int sdk_res2net_chain(sdk_ctx* ctx, const uint16_t* U, int64_t ldu, u
     p.W[i] = (const bf16_t*)W[k]; p.bias[i] = bias[k]; p.scale[i] = scale[k]; p.shift[i] = shift[k];
   }
   ProfScope ps(ctx, stream, SDK_K_RES2NET, 2.0 * B * T * (double)RS * 3 * RS * nconv, 2.0 * 2.0 * B * T * RS * nconv);
-  static bool attr_set = false;
-  if (!attr_set) {
-    SDK_HIP_OK(hipFuncSetAttribute((const void*)res2net_chain_kernel<13>, hipFuncAttributeMaxDynamicSharedMemorySize, 2 * 208 * 256 + PAR_BYTES));
-    SDK_HIP_OK(hipFuncSetAttribute((const void*)res2net_chain_kernel<7>, hipFuncAttributeMaxDynamicSharedMemorySize, 2 * 112 * 256 + PAR_BYTES));
-    attr_set = true;
-  }
+  if (sdk_lds_optin(ctx, (const void*)res2net_chain_kernel<13>, 2 * 208 * 256 + PAR_BYTES)) return 1;
+  if (sdk_lds_optin(ctx, (const void*)res2net_chain_kernel<7>, 2 * 112 * 256 + PAR_BYTES)) return 1;
   if (T <= 112) hipLaunchKernelGGL(res2net_chain_kernel<7>, dim3(B), dim3(RNT), 2 * 112 * 256 + PAR_BYTES, (hipStream_t)stream, p);
   else hipLaunchKernelGGL(res2net_chain_kernel<13>, dim3(B), dim3(RNT), 2 * 208 * 256 + PAR_BYTES, (hipStream_t)stream, p);
   SDK_LAUNCH_CHECK();

@@ -95,13 +95,9 @@ extern "C" int sdk_resample_s16(sdk_ctx* ctx, const int16_t* x, int64_t n_in, in
   const size_t win_bytes = ((size_t)(((int64_t)(RS_PER_WG - 1) * M) / L + K + 2) * sizeof(int16_t) + 3) & ~(size_t)3;
   const bool lds_taps = tab_bytes <= 64 * 1024;
   const bool lds_win = win_bytes <= 64 * 1024;
-  static bool attr_set = false;
-  if (!attr_set) {
-    SDK_HIP_OK(hipFuncSetAttribute((const void*)resample_kernel<true, true>, hipFuncAttributeMaxDynamicSharedMemorySize, 128 * 1024));
-    SDK_HIP_OK(hipFuncSetAttribute((const void*)resample_kernel<true, false>, hipFuncAttributeMaxDynamicSharedMemorySize, 64 * 1024));
-    SDK_HIP_OK(hipFuncSetAttribute((const void*)resample_kernel<false, true>, hipFuncAttributeMaxDynamicSharedMemorySize, 64 * 1024));
-    attr_set = true;
-  }
+  if (sdk_lds_optin(ctx, (const void*)resample_kernel<true, true>, 128 * 1024)) return 1;
+  if (sdk_lds_optin(ctx, (const void*)resample_kernel<true, false>, 64 * 1024)) return 1;
+  if (sdk_lds_optin(ctx, (const void*)resample_kernel<false, true>, 64 * 1024)) return 1;
   const dim3 grid((unsigned)nwg), block(RS_NT);
   hipStream_t st = (hipStream_t)stream;
   if (lds_taps && lds_win)

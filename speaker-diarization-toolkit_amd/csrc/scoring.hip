@@ -21,10 +21,12 @@
 #include <stdlib.h>
 
 #include "common.hpp"
+#include "scoring_exact.hpp"
+
+using namespace sdk_exact;
 
 namespace {
 
-constexpr int D = 192;                 // embedding width (12 MFMA k-steps of 16)
 constexpr int KS = D / 16;
 constexpr int SEG_PER_WAVE = 32;
 constexpr int WAVES = 4;
@@ -198,52 +200,6 @@ __global__ __launch_bounds__(WAVES * 64, 2) void affinity_coarse_kernel(const bf
   }
 }
 
-// ---- exact fp32 dot product of two 192-vectors by a group of 8 consecutive lanes ---------------
-// lane j of the group owns elements [24 j, 24 j + 24); fixed order: sequential fma inside the lane,
-// then the xor-butterfly 1,2,4 (fp add is commutative, so all 8 lanes hold the same bits).
-__device__ __forceinline__ float dot192_regs(const float* __restrict__ e24, const f32x4* __restrict__ pv) {
-  float a = 0.f;
-#pragma unroll
-  for (int q = 0; q < 6; ++q) {
-    const f32x4 v = pv[q];
-    a = fmaf(e24[4 * q + 0], v[0], a);
-    a = fmaf(e24[4 * q + 1], v[1], a);
-    a = fmaf(e24[4 * q + 2], v[2], a);
-    a = fmaf(e24[4 * q + 3], v[3], a);
-  }
-  a += __shfl_xor(a, 1, 64);
-  a += __shfl_xor(a, 2, 64);
-  a += __shfl_xor(a, 4, 64);
-  return a;
-}
-__device__ __forceinline__ void load_prow(const float* __restrict__ prow, int j, f32x4* pv) {
-  const f32x4* p = reinterpret_cast<const f32x4*>(prow + 24 * j);
-#pragma unroll
-  for (int q = 0; q < 6; ++q) pv[q] = p[q];
-}
-__device__ __forceinline__ float dot192_group8(const float* __restrict__ e24, const float* __restrict__ prow, int j) {
-  f32x4 pv[6];
-  load_prow(prow, j, pv);
-  return dot192_regs(e24, pv);
-}
-
-__device__ __forceinline__ bool better(float s, int i, float s2, int i2) { return s > s2 || (s == s2 && i < i2); }
-
-// insert (s, i) into a best-first list of length K kept in registers
-template <int K>
-__device__ __forceinline__ void insert_exact(float s, int i, float* bs, int* bi) {
-  int pos = K;
-#pragma unroll
-  for (int q = K - 1; q >= 0; --q)
-    if (better(s, i, bs[q], bi[q])) pos = q;
-#pragma unroll
-  for (int q = K - 1; q >= 1; --q)
-    if (q > pos) { bs[q] = bs[q - 1]; bi[q] = bi[q - 1]; }
-#pragma unroll
-  for (int q = 0; q < K; ++q)
-    if (q == pos) { bs[q] = s; bi[q] = i; }
-}
-
 __global__ __launch_bounds__(256) void affinity_rescore_kernel(const float* __restrict__ E, const float* __restrict__ Pm,
                                                               const float* __restrict__ resid_e,
                                                               const float* __restrict__ resid_p, int N, int P, int k,
@@ -328,24 +284,6 @@ __global__ __launch_bounds__(256) void affinity_rescore_kernel(const float* __re
 // score 32 profiles each (four rows in flight per group), the 128 partial entries meet in LDS and one
 // wave selects the slice's best four by shuffles.  A second tiny kernel merges a row's slices.
 constexpr int SLICE = 1024;
-
-// wave-wide selection of the K best (score desc, index asc) among 2 entries per lane; result on every lane
-__device__ __forceinline__ void wave_select4(float s0, int i0, float s1, int i1, float* os, int* oi) {
-#pragma unroll
-  for (int q = 0; q < 4; ++q) {
-    float bs = s0; int bi = i0;
-    if (better(s1, i1, bs, bi)) { bs = s1; bi = i1; }
-#pragma unroll
-    for (int o = 32; o > 0; o >>= 1) {
-      const float ts = __shfl_xor(bs, o, 64);
-      const int ti = __shfl_xor(bi, o, 64);
-      if (better(ts, ti, bs, bi)) { bs = ts; bi = ti; }
-    }
-    os[q] = bs; oi[q] = bi;
-    if (s0 == bs && i0 == bi) { s0 = -INFINITY; i0 = 0x7fffffff; }      // the winner leaves the pool
-    if (s1 == bs && i1 == bi) { s1 = -INFINITY; i1 = 0x7fffffff; }
-  }
-}
 
 __global__ __launch_bounds__(256) void affinity_rescan_kernel(const float* __restrict__ E, const float* __restrict__ Pm,
                                                              int P, int k, const int32_t* __restrict__ flag_count,
@@ -437,7 +375,17 @@ __global__ void copy_count_kernel(const int32_t* src, int32_t* dst) { *dst = *sr
 
 }  // namespace
 
-extern "C" size_t sdk_affinity_workspace_bytes(int N, int P) { return N > 0 && P > 0 ? ws_layout(N, P, nullptr, nullptr) : 0; }
+// k = 1 fast path (affinity_rowcol.hip)
+size_t aff_rowcol_workspace_bytes(int N, int P);
+bool aff_rowcol_supported(int P);
+int aff_rowcol_top1(sdk_ctx* ctx, const float* E, const uint16_t* Eb, const float* resid_e, const float* P, const uint16_t* Pb,
+                    const float* resid_p, int N, int Pn, int32_t* idx, float* score, int32_t* n_rescanned, void* ws, void* stream);
+
+extern "C" size_t sdk_affinity_workspace_bytes(int N, int P) {
+  if (N <= 0 || P <= 0) return 0;
+  const size_t a = ws_layout(N, P, nullptr, nullptr), b = aff_rowcol_workspace_bytes(N, P);
+  return a > b ? a : b;
+}
 
 extern "C" int sdk_affinity_topk(sdk_ctx* ctx, const float* E, const uint16_t* Eb, const float* resid_e,
                                  const float* P, const uint16_t* Pb, const float* resid_p, int N, int Pn, int d, int k,
@@ -450,6 +398,8 @@ extern "C" int sdk_affinity_topk(sdk_ctx* ctx, const float* E, const uint16_t* E
   SDK_REQUIRE(ws_bytes >= sdk_affinity_workspace_bytes(N, Pn), "sdk_affinity_topk: workspace too small");
   SDK_REQUIRE(((uintptr_t)E % 16) == 0 && ((uintptr_t)Eb % 16) == 0 && ((uintptr_t)P % 16) == 0 && ((uintptr_t)Pb % 16) == 0,
               "sdk_affinity_topk: matrices must be 16-byte aligned");
+  if (k == 1 && ctx->aff_fast && aff_rowcol_supported(Pn))
+    return aff_rowcol_top1(ctx, E, Eb, resid_e, P, Pb, resid_p, N, Pn, idx, score, n_rescanned, ws, stream);
   hipStream_t s = (hipStream_t)stream;
   Workspace w;
   ws_layout(N, Pn, (char*)ws, &w);

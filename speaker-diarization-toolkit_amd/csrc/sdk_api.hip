@@ -49,6 +49,15 @@ extern "C" int sdk_init(int device, sdk_ctx** out) {
   return 0;
 }
 
+int sdk_lds_optin(sdk_ctx* ctx, const void* func, int bytes) {
+  for (const void* f : ctx->lds_optin)
+    if (f == func) return 0;
+  SDK_HIP_OK(hipSetDevice(ctx->device));
+  SDK_HIP_OK(hipFuncSetAttribute(func, hipFuncAttributeMaxDynamicSharedMemorySize, bytes));
+  ctx->lds_optin.push_back(func);
+  return 0;
+}
+
 extern "C" int sdk_shutdown(sdk_ctx* ctx) {
   delete ctx;
   return 0;
@@ -72,6 +81,8 @@ extern "C" int sdk_set_option(sdk_ctx* ctx, const char* name, int value) {
   if (strcmp(name, "res2net_chain_fusion") == 0) { ctx->no_chain_fusion = value == 0; return 0; }
   if (strcmp(name, "asp_per_segment") == 0) { ctx->no_asp_seg = value == 0; return 0; }
   if (strcmp(name, "gemm_variant") == 0) return sdk_set_gemm_variant(value);
+  if (strcmp(name, "affinity_fast_path") == 0) { ctx->aff_fast = value; return 0; }
+  if (strcmp(name, "affinity_variant") == 0) { ctx->aff_variant = value; return 0; }
   sdk_set_error("sdk_set_option: unknown option '%s'", name);
   return 2;
 }

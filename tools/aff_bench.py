@@ -1,18 +1,49 @@
 #!/usr/bin/env python3
+"""k4 A/B on one device, one process: general sorted-list kernel vs the k = 1 row/column-maxima variants.
+Checks every variant against an independent fp32 product (torch.matmul, checker only), then times interleaved rounds."""
 import importlib, sys
 from pathlib import Path
 import torch
 sys.path.insert(0, str(Path(__file__).resolve().parent.parent))
 ops = importlib.import_module("speaker-diarization-toolkit_amd.ops")
 eng = ops.get_engine(0)
-for N3, P3 in ((100_000, 1000), (125_000, 10_000)):
+VARIANTS = [("general", 0, 0), ("rc8x2x4x3", 1, 0), ("rc4x2x2x4", 1, 1), ("rc8x2x2x4", 1, 2), ("rc8x1x2x4", 1, 3)]
+shapes = [(100_000, 1000), (125_000, 10_000)] if len(sys.argv) < 2 else [tuple(int(x) for x in a.split("x")) for a in sys.argv[1:]]
+for N3, P3 in shapes:
     E3, E3b, r3 = eng.l2norm(torch.randn(N3, 192, device="cuda", generator=torch.Generator(device="cuda").manual_seed(3)))
     Q3, Q3b, q3 = eng.l2norm(torch.randn(P3, 192, device="cuda", generator=torch.Generator(device="cuda").manual_seed(4)))
     q3m = q3.max().reshape(1)
-    for _ in range(3): eng.affinity_topk(E3, E3b, r3, Q3, Q3b, q3m, k=1)
-    eng.profile_begin()
-    for _ in range(10): _, _, cnt = eng.affinity_topk(E3, E3b, r3, Q3, Q3b, q3m, k=1, want_count=True)
-    p = eng.profile_end()
-    tot = sum(v["ms"] for v in p.values()) / 10
-    print(N3, P3, {k: round(v["ms"] / 10 * 1e3, 1) for k, v in p.items()}, "us; total", round(tot * 1e3, 1), "us;",
-          round(N3 * P3 / tot / 1e6, 1), "Gpairs/s; coarse", round(2 * N3 * P3 * 192 / (p["affinity_coarse"]["ms"] / 10) / 1e9, 1), "TF; rescanned", int(cnt.item()))
+    ref = None
+    for name, fast, var in VARIANTS:
+        eng.set_option("affinity_fast_path", fast); eng.set_option("affinity_variant", var)
+        idx, sc, cnt = eng.affinity_topk(E3, E3b, r3, Q3, Q3b, q3m, k=1, want_count=True)
+        torch.cuda.synchronize()
+        if ref is None:
+            ref = (idx.clone(), sc.clone())
+            bad = 0
+            for a in range(0, N3, 12500):
+                S = E3[a:a + 12500] @ Q3.t()
+                top = S.max(1).values
+                got = S.gather(1, idx[a:a + 12500].long())[:, 0]
+                bad += int(((top - got) > 1e-5).sum())
+            print(f"{N3}x{P3} {name}: rows off the fp32 maximum by > 1e-5: {bad}; rescanned {int(cnt.item())}", flush=True)
+        else:
+            same_i = bool(torch.equal(idx, ref[0])); same_s = bool(torch.equal(sc, ref[1]))
+            nd = int((idx != ref[0]).sum())
+            print(f"{N3}x{P3} {name}: idx identical {same_i} ({nd} differ), scores bit-identical {same_s}, rescanned {int(cnt.item())}", flush=True)
+    res = {n: [] for n, _, _ in VARIANTS}
+    for rnd in range(5):
+        for name, fast, var in VARIANTS:
+            eng.set_option("affinity_fast_path", fast); eng.set_option("affinity_variant", var)
+            for _ in range(2): eng.affinity_topk(E3, E3b, r3, Q3, Q3b, q3m, k=1)
+            eng.profile_begin()
+            for _ in range(10): eng.affinity_topk(E3, E3b, r3, Q3, Q3b, q3m, k=1)
+            p = eng.profile_end()
+            res[name].append({k: v["ms"] / 10 * 1e3 for k, v in p.items()})
+    for name, _, _ in VARIANTS:
+        keys = res[name][0].keys()
+        med = {k: sorted(r[k] for r in res[name])[len(res[name]) // 2] for k in keys}
+        tot = sum(med.values())
+        print(f"{N3}x{P3} {name:10s} " + " ".join(f"{k.replace('affinity_', '')}={v:.1f}" for k, v in med.items()) +
+              f" total={tot:.1f} us  coarse {2 * N3 * P3 * 192 / med['affinity_coarse'] / 1e6:.0f} TF  total {2 * N3 * P3 * 192 / tot / 1e6:.0f} TF", flush=True)
+eng.set_option("affinity_fast_path", 1); eng.set_option("affinity_variant", 0)
