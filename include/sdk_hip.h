@@ -53,6 +53,9 @@ int sdk_get_device_info(sdk_ctx* ctx, sdk_device_info* out);
  * 0 = one workgroup per (segment, 128 channels)), "gemm_variant" (see
  * sdk_set_gemm_variant).  Results do not depend on them. */
 int sdk_set_option(sdk_ctx* ctx, const char* name, int value);
+/* Diagnostic builds only: "stamps" = device buffer [workgroups][64] of uint64 that the affinity kernel fills with
+ * in-kernel wall-clock stamps (tools/aff_timeline.py); NULL (default) switches it off. */
+int sdk_debug_set_ptr(sdk_ctx* ctx, const char* name, void* device_ptr);
 
 /* ---- measurement: per-kernel-family HIP-event timing on the launch stream (bench.py roofline) -- */
 enum {
@@ -206,6 +209,10 @@ int sdk_l2norm(sdk_ctx* ctx, const float* X, int N, int d, float* E, uint16_t* E
  * n_rescanned (device int32, may be NULL) receives the number of rows that took the exact path.
  * ws: sdk_affinity_workspace_bytes(N, P). */
 size_t sdk_affinity_workspace_bytes(int N, int P);
+/* Host-only (no device): the k = 1 path's work decomposition, for tests.  out5 = {segment groups, profile stages per group,
+ * workgroups, segments per group, record slots per segment}; *units = groups * stages; workgroup i sweeps the units
+ * [i * units / workgroups, (i + 1) * units / workgroups) in (group, stage) order. */
+int sdk_affinity_plan(int N, int P, int num_cu, int32_t* out5, int64_t* units);
 int sdk_affinity_topk(sdk_ctx* ctx, const float* E, const uint16_t* Eb, const float* resid_e,
                       const float* P, const uint16_t* Pb, const float* resid_p,
                       int N, int Pn, int d, int k, int32_t* idx, float* score,

@@ -13,6 +13,13 @@ papers use (25 ms Hamming window, 10 ms hop, 400-point DFT, 80 triangular mel fi
     M[t,m]    = sum_f P[t,f] * melW[f,m]
     L[t,m]    = 10 log10(max(M[t,m], 1e-10));  L = max(L, max_{t,m} L - 80)
     out[t,m]  = L[t,m] - mean_t L[t,m]
+
+Filter shape - a BUILD CHOICE, parity unpinned: melW uses the HTK/Slaney-style triangle whose three corners are consecutive
+points of a grid equally spaced on the HTK mel scale (rise from point m to m+1, fall to m+2: the two sides have different
+widths in Hz, and neighbouring filters sum to one between the outer centres).  Toolkits differ here (some use one band
+width per filter, i.e. symmetric triangles in Hz); none is importable in this image and the reference pins none, so no
+published recipe is claimed for the triangle shape.  tests/test_oracle_cpu.py checks this matrix against a second,
+per-bin construction of the same definition.
 """
 from __future__ import annotations
 

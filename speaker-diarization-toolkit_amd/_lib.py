@@ -65,6 +65,7 @@ SIGNATURES = {
     "sdk_last_error": (C.c_char_p, []),
     "sdk_get_device_info": (_i, [_vp, C.POINTER(DeviceInfo)]),
     "sdk_set_option": (_i, [_vp, C.c_char_p, _i]),
+    "sdk_debug_set_ptr": (_i, [_vp, C.c_char_p, _vp]),
     "sdk_profile_begin": (_i, [_vp]),
     "sdk_profile_end": (_i, [_vp, C.POINTER(ProfileReport)]),
     "sdk_fbank_tables_bytes": (_sz, []),
@@ -91,6 +92,7 @@ SIGNATURES = {
     "sdk_resample_s16": (_i, [_vp, _vp, _i64, _i, _vp, _i, _i, _i, _vp, _i64, _vp]),
     "sdk_l2norm": (_i, [_vp, _vp, _i, _i, _vp, _vp, _vp, _vp]),
     "sdk_affinity_workspace_bytes": (_sz, [_i, _i]),
+    "sdk_affinity_plan": (_i, [_i, _i, _i, _vp, _vp]),
     "sdk_affinity_matvec_workspace_bytes": (_sz, [_i]),
     "sdk_affinity_matvec": (_i, [_vp, _vp, _i, _i, _i, _i, _vp, _vp, _i, _vp, _vp, _sz, _vp]),
     "sdk_rows_gram_workspace_bytes": (_sz, [_i, _i]),

@@ -55,10 +55,17 @@ __device__ __forceinline__ float max3(float a, float b, float c) { return fmaxf(
 
 // WAVES waves x SEGB blocks of 32 segments; TPS tiles per LDS stage; NSTAGE stages.
 template <int WAVES, int SEGB, int TPS, int NSTAGE>
-__global__ __launch_bounds__(WAVES * 64) void aff_rowcol_kernel(const bf16_t* __restrict__ Eb, const bf16_t* __restrict__ Pb,
+__global__ __launch_bounds__(WAVES * 64, 2) void aff_rowcol_kernel(const bf16_t* __restrict__ Eb, const bf16_t* __restrict__ Pb,
                                                                int N, int P, Geom gm, float* __restrict__ stats,
                                                                int32_t* __restrict__ part_base, int32_t* __restrict__ part_cnt,
-                                                               int32_t* __restrict__ err) {
+                                                               int32_t* __restrict__ err, unsigned long long* __restrict__ dbg) {
+  // diagnostic time stamps (100 MHz wall clock) of wave 0: [0] start, [1] count, then one per event; never set in production
+  int nstamp = 2;
+  auto stamp = [&]() {
+    if (dbg && threadIdx.x == 0 && nstamp < 62) dbg[blockIdx.x * 64 + nstamp++] = __builtin_amdgcn_s_memrealtime();
+  };
+  if (dbg && threadIdx.x == 0) dbg[blockIdx.x * 64] = __builtin_amdgcn_s_memrealtime();
+  const unsigned long long clk0 = dbg ? __builtin_amdgcn_s_memtime() : 0;
   constexpr int STAGE_BYTES = TPS * TILE_BYTES;
   constexpr int DMA_PER_STAGE = STAGE_BYTES / 1024;
   static_assert(DMA_PER_STAGE % WAVES == 0, "stage must split evenly over the waves");
@@ -159,6 +166,7 @@ __global__ __launch_bounds__(WAVES * 64) void aff_rowcol_kernel(const bf16_t* __
     // The segment fragments are ordinary loads issued OUTSIDE the stage loop, so the compiler drains them once here and
     // the stage loop keeps its counted waits (a load inside the loop makes it wait vmcnt(0) before every tile).
     begin_portion();
+    stamp();
     for (; u < uend; ++u, ++k) {
       // stage u must have landed; the stages issued after it (at most AHEAD - 1) may stay in flight
       const long long after = u1 - 1 - u < AHEAD - 1 ? u1 - 1 - u : AHEAD - 1;
@@ -174,6 +182,7 @@ __global__ __launch_bounds__(WAVES * 64) void aff_rowcol_kernel(const bf16_t* __
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
       }
       __builtin_amdgcn_s_barrier();                 // stage k landed for everyone; the buffer of stage k-1 is free
+      stamp();
       if (u + AHEAD < u1) issue();
       const char* stg = sP + (k % NSTAGE) * STAGE_BYTES + col * PROWB;
 #pragma unroll
@@ -215,8 +224,14 @@ __global__ __launch_bounds__(WAVES * 64) void aff_rowcol_kernel(const bf16_t* __
       }
       ++s;
     }
+    stamp();
     end_portion(s == nst);
     if (s == nst) { ++b; s = 0; slot = 0; }         // the next portion starts a new group
+  }
+  stamp();
+  if (dbg && threadIdx.x == 0) {
+    dbg[blockIdx.x * 64 + 1] = nstamp;
+    dbg[blockIdx.x * 64 + 63] = __builtin_amdgcn_s_memtime() - clk0;     // shader cycles between the first and this stamp
   }
 }
 
@@ -374,9 +389,21 @@ __global__ __launch_bounds__(256) void aff_rowcol_rescore_kernel(const float* __
 }
 
 // ---- exact rescan of the rows the certificate could not settle ----------------------------------------------------------
-// Work item = (four flagged rows, slice of 256 profiles): a profile row fetched from L2 is scored against four segment
-// rows held in registers (the old form streamed all of P once PER flagged row: 768 MB of L2 traffic at config #3).
-constexpr int RS_SLICE = 256, RS_ROWS = 4;
+// Work item = (four flagged rows, slice of 64 profiles): a profile row fetched from L2 is scored against four segment rows
+// held in registers (the old form streamed all of P once PER flagged row: 768 MB of L2 traffic at config #3), and an item
+// is ONE round of loads (2 profile rows + 4 segment rows per lane group, all requested before the first use): with ~100
+// flagged rows the kernel is a chain of memory round trips, so the chain is kept short and the items many.
+constexpr int RS_SLICE = 64, RS_ROWS = 4;
+
+constexpr int RS_GRID = 2048;
+// slices per row quad: enough items to fill the grid once, never shorter than RS_SLICE profiles (same split in both kernels)
+__device__ __forceinline__ void rescan_split(int P, int nq, int& nsl, int& slen) {
+  const int nmax = (P + RS_SLICE - 1) / RS_SLICE;
+  int want = nq > 0 ? RS_GRID / nq : 1;
+  want = want < 1 ? 1 : (want > nmax ? nmax : want);
+  slen = ((nmax + want - 1) / want) * RS_SLICE;
+  nsl = (P + slen - 1) / slen;
+}
 
 __device__ __forceinline__ void group_best32(float& s, int& i) {     // best over the 32 lanes 0..31 of a wave
 #pragma unroll
@@ -396,11 +423,12 @@ __global__ __launch_bounds__(256) void aff_rescan4_kernel(const float* __restric
   __shared__ int li[RS_ROWS][32];
   const int tid = threadIdx.x, j = tid & 7, g = tid >> 3;
   const int count = *flag_count;
-  const int nsl = (P + RS_SLICE - 1) / RS_SLICE;
   const int nq = (count + RS_ROWS - 1) / RS_ROWS;
+  int nsl, slen;
+  rescan_split(P, nq, nsl, slen);
   for (int item = blockIdx.x; item < nq * nsl; item += gridDim.x) {
     const int q = item / nsl, sl = item - q * nsl;
-    const int p0 = sl * RS_SLICE, p1 = min(P, p0 + RS_SLICE);
+    const int s0 = sl * slen, s1 = min(P, s0 + slen);
     float e24[RS_ROWS][24];
 #pragma unroll
     for (int x = 0; x < RS_ROWS; ++x) {
@@ -416,20 +444,17 @@ __global__ __launch_bounds__(256) void aff_rescan4_kernel(const float* __restric
     int bi[RS_ROWS];
 #pragma unroll
     for (int x = 0; x < RS_ROWS; ++x) { bs[x] = -INFINITY; bi[x] = 0x7fffffff; }
-    for (int p = p0 + g; p < p1; p += 64) {                     // two profile rows in flight per lane group
+    for (int p0 = s0; p0 < s1; p0 += RS_SLICE) {                  // ascending profile index per lane group
+      const int pa = min(p0 + g, s1 - 1), pb = min(p0 + g + 32, s1 - 1);
       f32x4 pv[2][6];
-      const int pb = p + 32;
-      load_prow(Pm + (int64_t)p * D, j, pv[0]);
-      load_prow(Pm + (int64_t)(pb < p1 ? pb : p1 - 1) * D, j, pv[1]);
+      load_prow(Pm + (int64_t)pa * D, j, pv[0]);
+      load_prow(Pm + (int64_t)pb * D, j, pv[1]);
 #pragma unroll
       for (int x = 0; x < RS_ROWS; ++x) {
-        const float sc = dot192_regs(e24[x], pv[0]);
-        if (better(sc, p, bs[x], bi[x])) { bs[x] = sc; bi[x] = p; }
-      }
-#pragma unroll
-      for (int x = 0; x < RS_ROWS; ++x) {
-        const float sc = dot192_regs(e24[x], pv[1]);              // every lane of the group runs the shuffles
-        if (pb < p1 && better(sc, pb, bs[x], bi[x])) { bs[x] = sc; bi[x] = pb; }
+        const float sa = dot192_regs(e24[x], pv[0]);              // every lane of the group runs the shuffles
+        const float sb = dot192_regs(e24[x], pv[1]);
+        if (p0 + g < s1 && better(sa, pa, bs[x], bi[x])) { bs[x] = sa; bi[x] = pa; }
+        if (p0 + g + 32 < s1 && better(sb, pb, bs[x], bi[x])) { bs[x] = sb; bi[x] = pb; }
       }
     }
     if (j == 0) {
@@ -456,9 +481,10 @@ __global__ __launch_bounds__(64) void aff_rescan4_merge_kernel(int P, const int3
                                                               const int32_t* __restrict__ flag_rows,
                                                               const float* __restrict__ part_s, const int32_t* __restrict__ part_i,
                                                               int32_t* __restrict__ idx, float* __restrict__ score) {
-  const int nsl = (P + RS_SLICE - 1) / RS_SLICE;
-  if (nsl == 1) return;
   const int count = *flag_count, lane = threadIdx.x;
+  int nsl, slen;
+  rescan_split(P, (count + RS_ROWS - 1) / RS_ROWS, nsl, slen);
+  if (nsl == 1) return;
   for (int f = blockIdx.x; f < count; f += gridDim.x) {
     float s = -INFINITY;
     int i = 0x7fffffff;
@@ -500,29 +526,47 @@ size_t ws_layout(int N, int P, char* base, Ws* w) {
   return off;
 }
 
-template <int WAVES, int SEGB, int TPS, int NSTAGE>
-int launch_coarse(sdk_ctx* ctx, const bf16_t* Eb, const bf16_t* Pb, int N, int P, const Ws& w, int32_t* err, hipStream_t s) {
-  constexpr int SEGS = WAVES * SEGB * 32;
-  constexpr int LDS = NSTAGE * TPS * TILE_BYTES;
+// Work decomposition of the coarse kernel (host side; the kernel derives each workgroup's range from it).
+Geom plan_geometry(int N, int P, int segs, int tps, long long max_wg) {
   Geom gm;
-  gm.segs = SEGS;
-  gm.ngroups = ceil_div(N, SEGS);
-  const int ntiles = ceil_div(P, PT);
-  gm.nst = ceil_div(ntiles, TPS);
+  gm.segs = segs;
+  gm.ngroups = ceil_div(N, segs);
+  gm.nst = ceil_div(ceil_div(P, PT), tps);
   gm.U = (long long)gm.ngroups * gm.nst;
-  long long G = ctx->num_cu;
-  if (G > 2LL * gm.ngroups) G = 2LL * gm.ngroups;     // a group's sweep is split over <= 3 workgroups (MAXP slots)
+  long long G = max_wg;
+  if (G > 2LL * gm.ngroups) G = 2LL * gm.ngroups;     // every range >= half a sweep: a group's sweep meets <= 3 workgroups (MAXP slots)
   if (G > gm.U) G = gm.U;
   gm.G = (int)G;
+  return gm;
+}
+
+template <int WAVES, int SEGB, int TPS, int NSTAGE>
+int launch_coarse(sdk_ctx* ctx, const bf16_t* Eb, const bf16_t* Pb, int N, int P, const Ws& w, int32_t* err, hipStream_t s, int wg_per_cu,
+                  int* segs) {
+  constexpr int SEGS = WAVES * SEGB * 32;
+  constexpr int LDS = NSTAGE * TPS * TILE_BYTES;
+  *segs = SEGS;
+  const Geom gm = plan_geometry(N, P, SEGS, TPS, (long long)ctx->num_cu * wg_per_cu);
   auto kern = aff_rowcol_kernel<WAVES, SEGB, TPS, NSTAGE>;
   if (sdk_lds_optin(ctx, (const void*)kern, LDS)) return 1;
-  hipLaunchKernelGGL(kern, dim3(gm.G), dim3(WAVES * 64), LDS, s, Eb, Pb, N, P, gm, w.stats, w.part_base, w.part_cnt, err);
+  hipLaunchKernelGGL(kern, dim3(gm.G), dim3(WAVES * 64), LDS, s, Eb, Pb, N, P, gm, w.stats, w.part_base, w.part_cnt, err,
+                     (unsigned long long*)ctx->dbg_ptr);
   return 0;
 }
 
 }  // namespace
 
 size_t aff_rowcol_workspace_bytes(int N, int P) { return ws_layout(N, P, nullptr, nullptr); }
+
+// Host-only view of the decomposition for tests (no device needed): out = {groups, stages per group, workgroups, segments per
+// group, record slots per segment}, units = groups * stages.  Workgroup i sweeps units [i*units/wg, (i+1)*units/wg).
+extern "C" int sdk_affinity_plan(int N, int P, int num_cu, int32_t* out5, int64_t* units) {
+  SDK_REQUIRE(N > 0 && P > 0 && num_cu > 0 && out5 && units, "sdk_affinity_plan: bad argument");
+  const Geom gm = plan_geometry(N, P, 8 * 2 * 32, 2, num_cu);       // the default variant: 8 waves x 2 blocks, 2 tiles per stage
+  out5[0] = gm.ngroups; out5[1] = gm.nst; out5[2] = gm.G; out5[3] = gm.segs; out5[4] = MAXP;
+  *units = gm.U;
+  return 0;
+}
 bool aff_rowcol_supported(int P) { return P <= 32768; }
 
 // k = 1.  Same contract as sdk_affinity_topk (which dispatches here).
@@ -539,10 +583,9 @@ int aff_rowcol_top1(sdk_ctx* ctx, const float* E, const uint16_t* Eb, const floa
     ProfScope ps(ctx, stream, SDK_K_AFF_COARSE, 2.0 * N * (double)Pn * D, 2.0 * ((double)N + Pn) * D + 64.0 * N);
     int rc;
     switch (ctx->aff_variant) {
-      case 1: rc = launch_coarse<4, 2, 2, 4>(ctx, (const bf16_t*)Eb, (const bf16_t*)Pb, N, Pn, w, err, s); segs = 256; break;
-      case 2: rc = launch_coarse<8, 2, 2, 4>(ctx, (const bf16_t*)Eb, (const bf16_t*)Pb, N, Pn, w, err, s); segs = 512; break;
-      case 3: rc = launch_coarse<8, 1, 2, 4>(ctx, (const bf16_t*)Eb, (const bf16_t*)Pb, N, Pn, w, err, s); segs = 256; break;
-      default: rc = launch_coarse<8, 2, 4, 3>(ctx, (const bf16_t*)Eb, (const bf16_t*)Pb, N, Pn, w, err, s); segs = 512; break;
+      case 1: rc = launch_coarse<8, 2, 4, 3>(ctx, (const bf16_t*)Eb, (const bf16_t*)Pb, N, Pn, w, err, s, 1, &segs); break;
+      case 2: rc = launch_coarse<4, 2, 2, 3>(ctx, (const bf16_t*)Eb, (const bf16_t*)Pb, N, Pn, w, err, s, 2, &segs); break;
+      default: rc = launch_coarse<8, 2, 2, 4>(ctx, (const bf16_t*)Eb, (const bf16_t*)Pb, N, Pn, w, err, s, 1, &segs); break;
     }
     if (rc) return rc;
   }
@@ -555,7 +598,7 @@ int aff_rowcol_top1(sdk_ctx* ctx, const float* E, const uint16_t* Eb, const floa
   SDK_LAUNCH_CHECK();
   {
     ProfScope ps(ctx, stream, SDK_K_AFF_RESCAN, 0.0, 0.0);
-    hipLaunchKernelGGL(aff_rescan4_kernel, dim3(1024), dim3(256), 0, s, E, P, Pn, w.flag_count, w.flag_rows, w.part_s, w.part_i,
+    hipLaunchKernelGGL(aff_rescan4_kernel, dim3(RS_GRID), dim3(256), 0, s, E, P, Pn, w.flag_count, w.flag_rows, w.part_s, w.part_i,
                        idx, score);
     if (Pn > RS_SLICE)
       hipLaunchKernelGGL(aff_rescan4_merge_kernel, dim3(256), dim3(64), 0, s, Pn, w.flag_count, w.flag_rows, w.part_s, w.part_i,

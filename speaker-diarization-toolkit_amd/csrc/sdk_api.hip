@@ -87,6 +87,13 @@ extern "C" int sdk_set_option(sdk_ctx* ctx, const char* name, int value) {
   return 2;
 }
 
+extern "C" int sdk_debug_set_ptr(sdk_ctx* ctx, const char* name, void* p) {
+  SDK_REQUIRE(ctx && name, "sdk_debug_set_ptr: null argument");
+  if (strcmp(name, "stamps") == 0) { ctx->dbg_ptr = p; return 0; }
+  sdk_set_error("sdk_debug_set_ptr: unknown name '%s'", name);
+  return 2;
+}
+
 extern "C" int sdk_profile_begin(sdk_ctx* ctx) {
   SDK_REQUIRE(ctx, "sdk_profile_begin: null ctx");
   for (auto& r : ctx->prof) { (void)hipEventDestroy(r.a); (void)hipEventDestroy(r.b); }

@@ -117,3 +117,43 @@ def test_bf16_bits_roundtrip():
     ours = WP.bf16_bits_to_f32(WP.f32_to_bf16_bits(x))
     ref = torch.from_numpy(x).to(torch.bfloat16).to(torch.float32).numpy()
     assert np.array_equal(ours, ref)
+
+
+def test_affinity_plan_every_group_sweep_is_covered_by_at_most_three_workgroups():
+    """Host side of the k = 1 affinity decomposition (csrc/affinity_rowcol.hip): workgroup i owns the units
+    [i*U/G, (i+1)*U/G) of the (segment group, profile stage) grid.  Replays the kernel's range / slot arithmetic and checks
+    that every group's sweep is tiled exactly once, by consecutive record slots 0..n-1 with n <= the slot count."""
+    lib = LIB.load_library()
+    rng = np.random.default_rng(11)
+    worst = 0
+    cases = [(1, 1), (2, 3), (31, 100), (512, 64), (513, 65), (1000, 100), (5000, 1000), (100_000, 1000), (125_000, 10_000),
+             (2000, 10_000), (300_000, 32_768)]
+    cases += [(int(rng.integers(1, 300_000)), int(rng.integers(1, 32_769))) for _ in range(300)]
+    for N, P in cases:
+        for cu in (256, 240, 304):
+            out = (C.c_int32 * 5)()
+            units = C.c_int64()
+            assert lib.sdk_affinity_plan(N, P, cu, out, C.byref(units)) == 0
+            ngroups, nst, G, segs, slots = list(out)
+            U = units.value
+            assert ngroups == -(-N // segs) and U == ngroups * nst and 1 <= G <= min(cu, U)
+            parts = {}
+            for i in range(G):
+                u0, u1 = i * U // G, (i + 1) * U // G
+                assert u1 > u0                                             # no idle workgroup
+                b0 = u0 // nst
+                ifirst = ((b0 * nst + 1) * G + U - 1) // U - 1              # the kernel's formula for the first slot
+                assert ifirst * U // G <= b0 * nst < (ifirst + 1) * U // G
+                u, first = u0, True
+                while u < u1:
+                    b = u // nst
+                    e = min(u1, (b + 1) * nst)
+                    parts.setdefault(b, []).append((i - ifirst if first else 0, u - b * nst, e - b * nst))
+                    first, u = False, e
+            assert len(parts) == ngroups
+            for b, lst in parts.items():
+                assert [s for s, _, _ in lst] == list(range(len(lst))), (N, P, cu, b, lst)
+                assert lst[0][1] == 0 and lst[-1][2] == nst and all(x[2] == y[1] for x, y in zip(lst, lst[1:]))
+                worst = max(worst, len(lst))
+            assert worst <= slots
+    assert worst == 3

@@ -41,6 +41,46 @@ def test_fbank_mel_and_normalisation_properties():
     assert np.abs(a - b).max() < 0.2
 
 
+def test_mel_matrix_against_a_per_bin_construction():
+    """Second construction of the filterbank, written from the other side: walk the DFT bins, locate the two mel-spaced
+    band edges that bracket each bin frequency, and hand the bin to the (at most two) filters that straddle it.  Inside
+    the covered band the two weights are complementary, which the vectorised min/max form in oracle/fbank.py never states."""
+    hz2mel = lambda f: 2595.0 * np.log10(1.0 + f / 700.0)
+    mel2hz = lambda m: 700.0 * (10.0 ** (m / 2595.0) - 1.0)
+    edges = mel2hz(np.linspace(hz2mel(0.0), hz2mel(8000.0), 82))           # 80 filters -> 82 edges
+    W2 = np.zeros((201, 80))
+    for b in range(201):
+        f = b * 8000.0 / 200.0
+        i = int(np.searchsorted(edges, f, side="right")) - 1                 # edges[i] <= f < edges[i+1]
+        if i < 0 or i >= 81:
+            continue
+        frac = (f - edges[i]) / (edges[i + 1] - edges[i])                    # position inside the band
+        if i < 80:
+            W2[b, i] = frac                                                  # rising side of filter i (centre edges[i+1])
+        if i >= 1:
+            W2[b, i - 1] = 1.0 - frac                                        # falling side of filter i-1 (centre edges[i])
+    Wm = ofbank.mel_matrix()
+    assert np.abs(Wm - W2).max() < 1e-12
+    inside = (np.arange(201) * 40.0 >= edges[1]) & (np.arange(201) * 40.0 <= edges[80])
+    assert np.abs(Wm[inside].sum(axis=1) - 1.0).max() < 1e-12               # partition of unity between the outer centres
+
+
+def test_ecapa_oracle_against_independent_torch_nn_model():
+    """The whole forward (C = 1024, the shipped configuration) against a model composed from torch.nn modules that shares
+    only the weight dictionary with the oracle (tests/nn_ecapa_ref.py): Conv1d(padding_mode='reflect'), BatchNorm1d.eval(),
+    chunked Res2Net, SE, attentive statistics pooling with global context."""
+    from nn_ecapa_ref import EcapaNN, load_from_dict
+    w = W.synthetic_weights(3)
+    feats = torch.randn(2, 40, 80, generator=torch.Generator().manual_seed(5), dtype=torch.float64) * 3
+    with torch.no_grad():
+        ref = load_from_dict(EcapaNN(), w)(feats)
+    got = oecapa.EcapaOracle(w, "fp32", torch.float64).embed(feats.float())
+    assert ref.shape == got.shape == (2, 192)
+    assert float((got.double() - ref).abs().max()) < 1e-4, float((got.double() - ref).abs().max())
+    cos = torch.nn.functional.cosine_similarity(got.double(), ref, dim=1)
+    assert float(cos.min()) > 1 - 1e-9
+
+
 def test_conv_is_torch_conv1d_with_reflect_padding():
     w = W.synthetic_weights(1, SMALL)
     o = oecapa.EcapaOracle(w, "fp32", torch.float64, n_dilations=SMALL.dilations, scale=SMALL.res2net_scale)
