@@ -104,6 +104,16 @@ def synthesize_case(case: Dict[str, Any], audio_root: Path) -> None:
 
 
 # ---------------------------------------------------------------------------- one case
+def records_hash(path: Path) -> str:
+    """sha256[:32] of the file: what the toolkit's compute_b3sum falls back to without the b3sum tool (speaker_detection:253-269)."""
+    import hashlib
+    h = hashlib.sha256()
+    with open(path, "rb") as f:
+        for chunk in iter(lambda: f.read(1 << 16), b""):
+            h.update(chunk)
+    return h.hexdigest()[:32]
+
+
 def run_case(case: Dict[str, Any], backend_name: str, audio_root: Path, work: Path, verbose: bool = False) -> Dict[str, Any]:
     res = {"test_id": case["id"], "passed": False, "enrolled": [], "identified": [], "expected": list(case["expected_speakers"]),
            "error": None, "scores": {}}
@@ -124,11 +134,10 @@ def run_case(case: Dict[str, Any], backend_name: str, audio_root: Path, work: Pa
             res["error"] = f"Enrollment failed for {sid}: {e}"
             return res
         prof = {"id": sid, "version": 1, "names": {"default": sid.title()}, "nicknames": [], "description": f"Test speaker {sid}",
-                "metadata": {}, "tags": ["test"],
-                "embeddings": {backend_name: [{"id": f"emb-{sid}", "external_id": enr.get("external_id"),
-                                               "all_identifiers": enr.get("all_identifiers", []),
-                                               "model_version": enr.get("model_version", f"{backend_name}-v2"),
-                                               "source_audio": str(path)}]}}
+                "metadata": {}, "tags": ["test"], "embeddings": {}}
+        records = importlib.import_module(f"{PKG}.records")    # the record cmd_enroll would store (speaker_detection:890-904)
+        records.attach_embedding(prof, backend_name, records.make_embedding_record(
+            enr, path, records_hash(path), emb_id=f"emb-{sid}"))
         (work / "db" / f"{sid}.json").write_text(json.dumps(prof, indent=2))
         profiles.append(prof)
         res["enrolled"].append(sid)

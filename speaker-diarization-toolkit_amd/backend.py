@@ -84,10 +84,17 @@ class Backend(EmbeddingBackend):
 
     # ---- the GPU path ----------------------------------------------------------------------
     def embed_windows(self, pcm: np.ndarray):
-        """pcm [B, S] int16 (host) -> torch device tensors (E fp32, Eb bf16, resid)."""
+        """pcm [B, S] int16 (host) -> torch device tensors (E fp32, Eb bf16, resid).
+        Recordings of any length: the forward's scratch is ~6.7 MB per 2-s window, so the windows go through in batches
+        of SDK_MAX_BATCH (default 2048 = 13.7 GB of scratch; a 1-h file at a 1-s hop is two batches)."""
         import torch
         eng = self.engine()
-        return eng.embed_pcm(torch.from_numpy(np.ascontiguousarray(pcm)).to(eng.device))
+        step = max(1, int(os.environ.get("SDK_MAX_BATCH", "2048")))
+        if pcm.shape[0] <= step:
+            return eng.embed_pcm(torch.from_numpy(np.ascontiguousarray(pcm)).to(eng.device))
+        parts = [eng.embed_pcm(torch.from_numpy(np.ascontiguousarray(pcm[a:a + step])).to(eng.device))
+                 for a in range(0, pcm.shape[0], step)]
+        return tuple(torch.cat([p[i] for p in parts], dim=0) for i in range(3))
 
     def _windows(self, audio_path: Path, segments):
         samples = decode_to_profile(Path(audio_path), self.engine(), self.get_audio_profile())   # other rates / layouts: GPU resampler
@@ -124,7 +131,7 @@ class Backend(EmbeddingBackend):
         return idx.cpu().numpy(), sc.cpu().numpy()
 
     def identify_speaker(self, audio_path: Path, candidates: List[Dict[str, Any]], threshold: float = 0.354) -> List[Dict[str, Any]]:
-        batch = load_profile_batch(candidates, self.name, model_prefix=f"{self.name}-")
+        batch = load_profile_batch(candidates, self.name, model_prefix=f"{self.name}-", model_version=self.model_version)
         for why in batch.skipped:
             print(f"mi355x backend: skipped embedding {why}", file=sys.stderr)
         if len(batch) == 0:

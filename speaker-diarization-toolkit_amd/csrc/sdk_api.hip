@@ -148,7 +148,9 @@ size_t fwd_layout(const sdk_ecapa_desc* d, int B, int T, char* base, FwdWs* w) {
   char* ah = take(M * A * 2);
   char* cx = take((size_t)B * 2 * Cm * 4);
   char* ub = take((size_t)B * A * 4);
-  char* lg = take(M * Cm * 4);
+  // the [M, Cm] fp32 attention logits exist in HBM only on the unfused pooling path (37 % of the workspace otherwise)
+  const bool fused_asp = A == 128 && T <= sdk_asp_fused_max_frames();
+  char* lg = take(fused_asp ? 256 : M * Cm * 4);
   char* po = take((size_t)B * 2 * Cm * 4);
   char* se = take(sdk_se_workspace_bytes(B, (int)C, d->se_channels));
   char* stp = take(sdk_conv_gemm_stats_bytes((int)M, (int)Cm, 2));

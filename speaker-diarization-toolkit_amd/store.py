@@ -17,6 +17,7 @@ from __future__ import annotations
 
 import hashlib
 import os
+import re
 from dataclasses import dataclass, field
 from pathlib import Path
 from typing import Any, Dict, List, Optional
@@ -25,6 +26,7 @@ import numpy as np
 
 EXTERNAL_PREFIX = "npy:"
 EMBED_DIM = 192
+_KEY_RE = re.compile(r"[0-9a-f]{24}")          # vector_key(): the only thing that may follow "npy:" (it becomes a file name)
 
 
 def embeddings_root() -> Path:
@@ -55,7 +57,10 @@ def save_vector(vec: np.ndarray, root: Optional[Path] = None) -> str:
 def vector_path(external_id: str, root: Optional[Path] = None) -> Path:
     if not isinstance(external_id, str) or not external_id.startswith(EXTERNAL_PREFIX):
         raise ValueError(f"not an mi355x external_id: {external_id!r}")
-    return (root or embeddings_root()) / "by-hash" / f"{external_id[len(EXTERNAL_PREFIX):]}.npy"
+    key = external_id[len(EXTERNAL_PREFIX):]
+    if not _KEY_RE.fullmatch(key):              # db/*.json is user-editable: never let the key walk out of by-hash/
+        raise ValueError(f"malformed mi355x external_id: {external_id!r}")
+    return (root or embeddings_root()) / "by-hash" / f"{key}.npy"
 
 
 def load_vector(external_id: str, root: Optional[Path] = None) -> np.ndarray:
@@ -94,10 +99,13 @@ class ProfileBatch:
 
 
 def load_profile_batch(candidates: List[Dict[str, Any]], backend_name: str, model_prefix: Optional[str] = None,
-                       root: Optional[Path] = None, link: bool = True) -> ProfileBatch:
+                       root: Optional[Path] = None, link: bool = True, model_version: Optional[str] = None) -> ProfileBatch:
     """Gather every usable embedding of every candidate into one matrix.
     Records with a foreign model_version prefix, a foreign external_id or a missing file are
-    skipped with a reason (the caller logs them to stderr - never silently)."""
+    skipped with a reason (the caller logs them to stderr - never silently).
+    `model_version` (exact) is stricter than the toolkit's prefix rule (base.py:92-93), which was written for a versioned
+    remote API: a LOCAL model's version carries its weights digest, and a vector enrolled under other weights lives in a
+    different embedding space - its cosines against the current model's embeddings are noise, so it is skipped too."""
     rows, sids, eids, trusts, skipped = [], [], [], [], []
     for prof in candidates:
         sid = prof.get("id")
@@ -106,6 +114,9 @@ def load_profile_batch(candidates: List[Dict[str, Any]], backend_name: str, mode
             tag = f"{sid}/{rec.get('id')}"
             if model_prefix and not str(mv).startswith(model_prefix):
                 skipped.append(f"{tag}: model_version {mv} is not {model_prefix}*")
+                continue
+            if model_version and mv != model_version:
+                skipped.append(f"{tag}: enrolled under {mv}, the loaded weights are {model_version} (re-enroll)")
                 continue
             try:
                 vec = load_vector(ext, root)

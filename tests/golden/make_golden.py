@@ -62,6 +62,128 @@ def write_wav(path: Path, seconds: float = 1.0, seed: int = 7) -> None:
     path.write_bytes(hdr + pcm)
 
 
+def make_schema_golden(ref: Path, here: Path) -> None:
+    """(1) verdicts of the reference's own validators (schemas.py:45-251) on the records a local backend
+    produces - good ones, and ones with missing keys / wrong types; (2) the embedding record the reference's `enroll` CLI
+    (speaker_detection:754-919) writes when a registered backend returns `external_id = "npy:<key>"`, run black-box with a
+    canned backend module registered through $SPEAKER_BACKENDS_CONFIG."""
+    from speaker_detection_backends import schemas as rs
+
+    def verdict(fn, obj):
+        v = {"warnings": fn(obj, strict=False)}
+        try:
+            fn(obj, strict=True)
+            v["strict_error"] = None
+        except rs.ValidationError as exc:
+            v["strict_error"] = str(exc)
+        return v
+
+    good = {"id": "emb-0a1b2c3d", "external_id": "npy:0123456789abcdef01234567", "source_audio": "/data/rec/a.wav",
+            "source_audio_b3sum": "ab" * 16, "source_segments": [{"start": 0.04, "end": 5.36}],
+            "model_version": "mi355x-ecapa1024-2f6c1e0d9b7a", "samples": {"reviewed": [], "unreviewed": [], "rejected": []},
+            "trust_level": "low", "created_at": "2026-01-13T10:11:12.131415+00:00"}
+
+    def variant(**kw):
+        r = dict(good)
+        for k, v in kw.items():
+            if v == "<drop>":
+                r.pop(k)
+            else:
+                r[k] = v
+        return r
+
+    emb_cases = [
+        ("good", good),
+        ("good_no_segments_z_time", variant(source_segments=None, created_at="2026-01-13T10:11:12Z")),
+        ("with_all_identifiers", variant(all_identifiers=["npy:0123456789abcdef01234567"])),
+        ("external_id_null", variant(external_id=None)),
+        ("external_id_int", variant(external_id=17)),
+        ("missing_external_id", variant(external_id="<drop>")),
+        ("missing_created_and_id", variant(created_at="<drop>", id="<drop>")),
+        ("empty_id", variant(id="")),
+        ("model_unknown", variant(model_version="unknown")),
+        ("model_not_str", variant(model_version=3)),
+        ("trust_bogus", variant(trust_level="certain")),
+        ("trust_invalidated", variant(trust_level="invalidated")),
+        ("created_not_iso", variant(created_at="yesterday")),
+        ("created_not_str", variant(created_at=1736762400)),
+        ("samples_bad_types", variant(samples={"reviewed": "abc", "unreviewed": [1, 2], "rejected": []})),
+        ("samples_list", variant(samples=["x"])),
+        ("samples_null", variant(samples=None)),
+        ("segments_not_list", variant(source_segments="0-5")),
+        ("segments_malformed", variant(source_segments=[{"start": 1.0}, [2.0, 3.0], {"start": 4.0, "end": 5.0}])),
+        ("not_a_dict", ["emb-1"]),
+    ]
+    prof_good = {"id": "alice", "version": 1, "names": {"default": "Alice"}, "nicknames": [], "description": None,
+                 "metadata": {}, "tags": ["team"], "embeddings": {"mi355x": [good]},
+                 "created_at": "2026-01-13T10:00:00+00:00", "updated_at": "2026-01-13T10:11:12+00:00"}
+
+    def pvariant(**kw):
+        r = json.loads(json.dumps(prof_good))
+        for k, v in kw.items():
+            if v == "<drop>":
+                r.pop(k)
+            else:
+                r[k] = v
+        return r
+
+    prof_cases = [
+        ("good", prof_good),
+        ("no_default_name", pvariant(names={"work": "A."})),
+        ("names_list", pvariant(names=["Alice"])),
+        ("missing_names", pvariant(names="<drop>")),
+        ("empty_id", pvariant(id="")),
+        ("tags_str", pvariant(tags="team")),
+        ("tags_mixed", pvariant(tags=["a", 1])),
+        ("embeddings_list", pvariant(embeddings=[good])),
+        ("backend_not_list", pvariant(embeddings={"mi355x": good})),
+        ("nested_bad_record", pvariant(embeddings={"mi355x": [good, variant(external_id=5, trust_level="x"), "oops"]})),
+        ("version_str", pvariant(version="1")),
+        ("not_a_dict", "alice"),
+    ]
+    out = {"embedding": [{"name": n, "record": r, **verdict(rs.validate_embedding, r)} for n, r in emb_cases],
+           "profile": [{"name": n, "profile": p, **verdict(rs.validate_profile, p)} for n, p in prof_cases]}
+
+    # ---- the record the reference's enroll CLI writes for a registered local backend ---------------------------------
+    with tempfile.TemporaryDirectory() as td:
+        td = Path(td)
+        (td / "cannedbackend.py").write_text(
+            "from pathlib import Path\n"
+            "from speaker_detection_backends.base import EmbeddingBackend\n"
+            "class Backend(EmbeddingBackend):\n"
+            "    @property\n"
+            "    def name(self): return 'mi355x'\n"
+            "    @property\n"
+            "    def requires_api_key(self): return False\n"
+            "    @property\n"
+            "    def model_version(self): return 'mi355x-ecapa1024-2f6c1e0d9b7a'\n"
+            "    def enroll_speaker(self, audio_path, segments=None):\n"
+            "        return {'external_id': 'npy:0123456789abcdef01234567', 'file': 'dropped.npy', 'model_version': self.model_version,\n"
+            "                'source_audio': str(audio_path), 'source_segments': segments}\n"
+            "    def identify_speaker(self, audio_path, candidates, threshold=0.354): return []\n")
+        (td / "backends.yaml").write_text("backends:\n  mi355x:\n    module: cannedbackend\n")
+        wav = td / "a.wav"
+        write_wav(wav)
+        env = dict(os.environ)
+        env.update({"SPEAKERS_EMBEDDINGS_DIR": str(td / "store"), "SPEAKER_BACKENDS_CONFIG": str(td / "backends.yaml"),
+                    "PYTHONPATH": f"{td}:{ref}", "PYTHONDONTWRITEBYTECODE": "1", "PATH": "/usr/bin:/bin"})
+        cli = [sys.executable, str(ref / "speaker_detection")]
+        runs = []
+        assert subprocess.run(cli + ["add", "alice", "--name", "Alice"], env=env, capture_output=True, text=True).returncode == 0
+        for name, extra in (("whole_file", []), ("segments", ["--segments", "0.04:0.5,0.6:0.9"]),
+                            ("trust_override", ["--trust-level", "high"])):
+            r = subprocess.run(cli + ["enroll", "alice", str(wav), "-b", "mi355x"] + extra, env=env, capture_output=True, text=True)
+            prof = json.loads((td / "store" / "db" / "alice.json").read_text())
+            rec = prof["embeddings"]["mi355x"][-1]
+            runs.append({"name": name, "argv": extra, "rc": r.returncode, "record": rec,
+                         "validate": rs.validate_embedding(rec), "profile_validate": rs.validate_profile(prof)})
+        import hashlib
+        out["enroll_cli"] = {"wav_seed": 7, "wav_sha256_32": hashlib.sha256(wav.read_bytes()).hexdigest()[:32],
+                             "audio_path": str(wav), "runs": runs}
+    (here / "schema_golden.json").write_text(json.dumps(out, indent=1) + "\n")
+    print("wrote", here / "schema_golden.json")
+
+
 def main() -> int:
     if not REF.exists():
         print("reference not mounted; golden vectors can only be regenerated in the build container",
@@ -278,6 +400,7 @@ def main() -> int:
         import hashlib
         out["cli"] = {"wav_seed": 7, "wav_sha256_32": hashlib.sha256(wav.read_bytes()).hexdigest()[:32], "runs": cli}
 
+    make_schema_golden(REF, HERE)
     (HERE / "plumbing_golden.json").write_text(json.dumps(out, indent=1, sort_keys=False) + "\n")
     print("wrote", HERE / "plumbing_golden.json", (HERE / "plumbing_golden.json").stat().st_size, "bytes")
     return 0

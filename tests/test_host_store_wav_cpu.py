@@ -76,6 +76,42 @@ def test_store_and_batch_loader(tmp_path, monkeypatch):
         store.vector_path("AD1NQVAB")
 
 
+def test_batch_loader_skips_other_weights_and_hostile_keys(tmp_path, monkeypatch):
+    """A local model's version carries its weights digest: a vector enrolled under weights A must not be scored against
+    embeddings made with weights B; and an `external_id` from a user-editable db/*.json never leaves by-hash/."""
+    monkeypatch.setenv("SPEAKERS_EMBEDDINGS_DIR", str(tmp_path))
+    vecs = np.random.default_rng(2).standard_normal((2, 192)).astype(np.float32)
+    ext = [store.save_vector(v) for v in vecs]
+    outside = tmp_path / "embeddings" / "secret.npy"
+    np.save(outside, vecs[0])
+    cands = [_profile("alice", [{"id": "emb-a1", "external_id": ext[0], "model_version": "mi355x-ecapa1024-AAAA"},
+                                {"id": "emb-a2", "external_id": ext[1], "model_version": "mi355x-ecapa1024-BBBB"},
+                                {"id": "emb-a3", "external_id": "npy:../secret", "model_version": "mi355x-ecapa1024-BBBB"},
+                                {"id": "emb-a4", "external_id": "npy:" + "g" * 24, "model_version": "mi355x-ecapa1024-BBBB"}])]
+    loose = store.load_profile_batch(cands, "mi355x", model_prefix="mi355x-", link=False)
+    assert loose.embedding_ids == ["emb-a1", "emb-a2"]                       # the toolkit's prefix rule alone lets both through
+    batch = store.load_profile_batch(cands, "mi355x", model_prefix="mi355x-", model_version="mi355x-ecapa1024-BBBB")
+    assert batch.embedding_ids == ["emb-a2"] and np.array_equal(batch.matrix[0], vecs[1])
+    why = " | ".join(batch.skipped)
+    assert "enrolled under mi355x-ecapa1024-AAAA" in why and "re-enroll" in why and why.count("malformed mi355x external_id") == 2
+    assert not (tmp_path / "embeddings" / "alice" / "emb-a3.npy").exists()   # nothing was linked out of the hostile key
+    for bad in ("npy:../../x", "npy:", "npy:ABCDEF0123456789ABCDEF01", "npy:0123456789abcdef0123456/"):
+        with pytest.raises(ValueError):
+            store.vector_path(bad)
+
+
+def test_backend_identify_uses_the_exact_model_version(tmp_path, monkeypatch):
+    """Enroll under weights A, identify under weights B: every stored vector is refused, with the reason on stderr, before
+    any GPU work (so this runs without a device)."""
+    monkeypatch.setenv("SPEAKERS_EMBEDDINGS_DIR", str(tmp_path))
+    be = backend.Backend()
+    be._digest = "bbbbbbbbbbbb"                                               # the loaded weights
+    ext = store.save_vector(np.random.default_rng(3).standard_normal(192).astype(np.float32))
+    cands = [_profile("alice", [{"id": "emb-a1", "external_id": ext, "model_version": "mi355x-ecapa1024-aaaaaaaaaaaa"}])]
+    assert be.identify_speaker(tmp_path / "missing.wav", cands) == []        # nothing usable -> [] like the reference's early exit
+    assert be.check_embedding_compatibility(cands[0]["embeddings"]["mi355x"][0])["compatible"]   # the toolkit's own prefix rule still says yes
+
+
 def test_aggregate_matches():
     batch = store.ProfileBatch(np.zeros((3, 192), np.float32), ["alice", "alice", "bob"], ["emb-a1", "emb-a2", "emb-b1"], ["high", "low", "high"])
     spans = [(0, 2), (1, 3), (2, 4), (3, 5), (4, 6)]
