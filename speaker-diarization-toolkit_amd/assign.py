@@ -297,7 +297,8 @@ def main(argv: Optional[List[str]] = None) -> int:
     a.add_argument("--output", "-o")
     a.add_argument("--format", "-f", choices=["text", "json"], default="text")
     a.add_argument("--dry-run", "-n", action="store_true")
-    a.add_argument("--per-label", action="store_true", help="score each label on its own segments")
+    a.add_argument("--per-label", action="store_true",
+                   help="score each label on its own sentences (is_eos segments, true-length windows) instead of the whole recording")
     args = ap.parse_args(argv)
     if args.command != "assign":
         ap.print_help()
@@ -311,7 +312,10 @@ def main(argv: Optional[List[str]] = None) -> int:
     if args.use_embeddings:
         from .identify import make_rows_fn
         try:
-            rows_fn = make_rows_fn(audio, tags=args.tags.split(",") if args.tags else None, per_label=args.per_label)
+            with open(transcript, "r") as fh:
+                parsed = json.load(fh) if args.per_label else None
+            rows_fn = make_rows_fn(audio, tags=args.tags.split(",") if args.tags else None, per_label=args.per_label,
+                                   transcript=parsed)
         except Exception as exc:  # noqa: BLE001
             print(f"Error during identification: {exc}", file=sys.stderr)
             return 1

@@ -25,7 +25,7 @@ import numpy as np
 from . import BACKEND_NAME
 from .plugin_api import EmbeddingBackend
 from .store import load_profile_batch, save_vector, vector_path
-from .wav import cut_windows, decode_to_profile
+from .wav import cut_ranges, cut_windows, decode_to_profile
 from .weights import DEFAULT_CONFIG, load_weights, synthetic_weights, weights_digest
 
 
@@ -103,10 +103,41 @@ class Backend(EmbeddingBackend):
             raise ValueError(f"{audio_path}: no analysable audio (every segment shorter than 0.5 s)")
         return pcm, spans
 
+    def embed_ranges(self, samples: np.ndarray, ranges: List[Tuple[float, float]]):
+        """Single-speaker ranges (sentences, enrollment segments) -> embeddings of true-length windows.
+        The windows are bucketed by length (wav.cut_ranges: 0.5 / 1 / 1.5 / 2 s = 51 / 101 / 151 / 201 frames) and each
+        bucket is ONE forward launch sequence; no window contains audio from outside its range.
+        Returns (E, Eb, resid) device tensors in window order, windows [(range index, start s, end s)], dropped ranges."""
+        import torch
+        pcm_by_len, wins, dropped = cut_ranges(samples, ranges, hop_s=self.hop_s)
+        if not wins:
+            return None, None, None, [], dropped
+        parts = {S: self.embed_windows(pcm) for S, pcm in pcm_by_len.items()}
+        order = {S: [] for S in parts}
+        for w, (_, S, row, _, _) in enumerate(wins):
+            order[S].append((row, w))
+        dev = next(iter(parts.values()))[0].device
+        out = []
+        for i in range(3):
+            ref = next(iter(parts.values()))[i]
+            full = torch.empty((len(wins),) + tuple(ref.shape[1:]), dtype=ref.dtype, device=dev)
+            for S, pairs in order.items():
+                rows = torch.tensor([r for r, _ in pairs], device=dev)
+                dst = torch.tensor([w for _, w in pairs], device=dev)
+                full[dst] = parts[S][i][rows]
+            out.append(full)
+        return out[0], out[1], out[2], [(ri, a, b) for ri, _, _, a, b in wins], dropped
+
     # ---- a2: enroll (base.py:107-128) ---------------------------------------------------------
     def enroll_speaker(self, audio_path: Path, segments: Optional[List[Tuple[float, float]]] = None) -> Dict[str, Any]:
-        pcm, spans = self._windows(audio_path, segments)
-        E, _, _ = self.embed_windows(pcm)
+        if segments:           # the caller vouches that each range is this speaker: true-length windows, never widened
+            samples = decode_to_profile(Path(audio_path), self.engine(), self.get_audio_profile())
+            E, _, _, spans, _ = self.embed_ranges(samples, list(segments))
+            if not spans:
+                raise ValueError(f"{audio_path}: no analysable audio (every segment shorter than 0.5 s)")
+        else:
+            pcm, spans = self._windows(audio_path, None)
+            E, _, _ = self.embed_windows(pcm)
         mean = E.double().mean(dim=0)
         vec = (mean / mean.norm().clamp_min(1e-12)).float().cpu().numpy()
         ext = save_vector(vec)

@@ -34,6 +34,7 @@ class SpectralResult:
     labels: np.ndarray            # [N] int32 canonical, identical on every rank
     eigenvalues: np.ndarray       # [k] descending (of S = D^-1/2 A D^-1/2)
     n_iter: int
+    timing: Optional[dict] = None  # seconds per phase when spectral_cluster(..., trace=True) (each phase then ends with a device sync)
 
 
 class _Comm:
@@ -72,9 +73,20 @@ def canonical_labels(lab: np.ndarray) -> np.ndarray:
 
 
 def spectral_cluster(provider, E_local: torch.Tensor, Eb_local: torch.Tensor, n_total: int, k: int, n_iter: int = 30,
-                     n_kmeans: int = 20, seed: int = 0, group=None) -> SpectralResult:
+                     n_kmeans: int = 20, seed: int = 0, group=None, trace: bool = False) -> SpectralResult:
     """E_local / Eb_local: this rank's unit-norm embedding rows (fp32 / bf16) under
     dist.shard_bounds(n_total, world).  Returns identical results on every rank."""
+    import time
+    timing = {} if trace else None
+    t_last = [time.perf_counter()]
+
+    def mark(name):
+        if trace:
+            if Eb_local.is_cuda:
+                torch.cuda.synchronize()
+            now = time.perf_counter()
+            timing[name] = timing.get(name, 0.0) + now - t_last[0]
+            t_last[0] = now
     comm = _Comm(group)
     lo, hi = sdist.shard_bounds(n_total, comm.world)[comm.rank]
     n_loc = hi - lo
@@ -86,11 +98,13 @@ def spectral_cluster(provider, E_local: torch.Tensor, Eb_local: torch.Tensor, n_
     deg = provider.affinity_matvec(Eb_all, ones, lo, n_loc)[lo:hi, 0].contiguous()
     dinv_loc = torch.rsqrt(deg)
     dinv_all = comm.gather_rows(dinv_loc.reshape(-1, 1), n_total).reshape(-1).contiguous()
+    mark("gather+degrees")
 
     # seeded start, same gaussian as the oracle (numpy PCG64), orthonormalised across ranks
     G0 = np.random.default_rng(seed).standard_normal((n_total, k))
     V = torch.from_numpy(G0[lo:hi].astype(np.float32)).to(dev)
     V = _orth(provider, comm, V, k)
+    mark("init")
 
     eye = torch.eye(k, dtype=torch.float32, device=dev)
 
@@ -100,8 +114,12 @@ def spectral_cluster(provider, E_local: torch.Tensor, Eb_local: torch.Tensor, n_
         return provider.rows_apply(Y, eye, scale=dinv_loc)
 
     for _ in range(n_iter):
-        V = _orth(provider, comm, apply_S(V), k)
+        Y = apply_S(V)
+        mark("apply_S")
+        V = _orth(provider, comm, Y, k)
+        mark("orth")
     SV = apply_S(V)
+    mark("apply_S")
     H = comm.sum_(provider.rows_gram(V, SV)).double().cpu().numpy()
     H = 0.5 * (H + H.T)
     lam, Q = np.linalg.eigh(H)
@@ -109,10 +127,14 @@ def spectral_cluster(provider, E_local: torch.Tensor, Eb_local: torch.Tensor, n_
     Qd = torch.from_numpy(np.ascontiguousarray(Q[:, order]).astype(np.float32)).to(dev)
     U = provider.rows_apply(V, Qd)
     R = provider.rows_unit(U)
+    mark("ritz")
 
     labels_loc = _kmeans(provider, comm, R, lo, n_total, k, n_kmeans)
+    mark("kmeans")
     lab_all = comm.gather_rows(labels_loc.reshape(-1, 1), n_total).reshape(-1)
-    return SpectralResult(canonical_labels(lab_all.cpu().numpy()), lam[order], n_iter)
+    labels = canonical_labels(lab_all.cpu().numpy())
+    mark("labels")
+    return SpectralResult(labels, lam[order], n_iter, timing)
 
 
 def _orth(provider, comm: _Comm, Y: torch.Tensor, k: int) -> torch.Tensor:

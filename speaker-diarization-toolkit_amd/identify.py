@@ -38,9 +38,14 @@ def candidates_for(backend_name: str, tags: Optional[List[str]] = None) -> List[
 
 
 def make_rows_fn(audio_path: Path, tags: Optional[List[str]] = None, per_label: bool = False, threshold: float = 0.354,
-                 backend=None):
+                 backend=None, transcript: Optional[Dict[str, Any]] = None):
     """Return rows_fn(label, segments) for assign.assign_recording.  Whole-recording mode (the
-    reference's behaviour) runs the GPU path once and serves every label from that result."""
+    reference's behaviour) runs the GPU path once and serves every label from that result.
+
+    per_label: the unit collect_embedding_signals was meant to use (its `segments` argument is accepted and ignored,
+    speaker-assign:262-278).  With the parsed `transcript`, every label's `is_eos` sentences (segments.sentence_segments)
+    are cut into true-length windows, ALL labels' windows are embedded in one bucketed GPU pass per recording, and each
+    label is scored on its own windows only; without it the label's contiguous runs passed to rows_fn are used."""
     from .backend import Backend, aggregate_matches
     from .store import load_profile_batch
     be = backend or Backend()
@@ -64,12 +69,42 @@ def make_rows_fn(audio_path: Path, tags: Optional[List[str]] = None, per_label: 
         rows = rows_with_trust(be.identify_speaker(audio_path, cands, threshold), by_id, be.name)
         return lambda label, segs: rows
 
-    batch = load_profile_batch(cands, be.name, model_prefix=f"{be.name}-")
+    from .wav import decode_to_profile
+    batch = load_profile_batch(cands, be.name, model_prefix=f"{be.name}-", model_version=be.model_version)
+    for why in batch.skipped:
+        print(f"mi355x backend: skipped embedding {why}", file=sys.stderr)
+    if len(batch) == 0:
+        return lambda label, segs: []
+    samples = decode_to_profile(Path(audio_path), be.engine(), be.get_audio_profile())
+
+    def score(ranges):
+        """ranges -> (best profile row, score, range index, span) per window"""
+        E, Eb, re, wins, _ = be.embed_ranges(samples, ranges)
+        if not wins:
+            return [], [], []
+        idx, sc = be.score_windows(E, Eb, re, batch)
+        return idx[:, 0], sc[:, 0], wins
+
+    if transcript is not None:
+        from .segments import sentence_segments
+        sents = sentence_segments(transcript)
+        idx, sc, wins = score([(s["start"], s["end"]) for s in sents])          # one pass for the whole recording
+        windows_of: Dict[str, List[int]] = {}
+        for w, (ri, _, _) in enumerate(wins):
+            windows_of.setdefault(sents[ri]["speaker"], []).append(w)
+
+        def rows_fn(label, segs):
+            ws = windows_of.get(label, [])
+            if not ws:
+                return []
+            spans = [(wins[w][1], wins[w][2]) for w in ws]
+            return rows_with_trust(aggregate_matches(idx[ws], sc[ws], spans, batch, threshold), by_id, be.name)
+        rows_fn.windows = [(sents[ri]["speaker"], a, b) for ri, a, b in wins]    # for tests / -v output
+        return rows_fn
 
     def rows_fn(label, segs):
-        spans_in = [(s["start"], s["end"]) for s in segs]
-        pcm, spans = be._windows(audio_path, spans_in)
-        E, Eb, re = be.embed_windows(pcm)
-        idx, sc = be.score_windows(E, Eb, re, batch)
-        return rows_with_trust(aggregate_matches(idx[:, 0], sc[:, 0], spans, batch, threshold), by_id, be.name)
+        idx, sc, wins = score([(s["start"], s["end"]) for s in segs])
+        if not len(wins):
+            return []
+        return rows_with_trust(aggregate_matches(idx, sc, [(a, b) for _, a, b in wins], batch, threshold), by_id, be.name)
     return rows_fn

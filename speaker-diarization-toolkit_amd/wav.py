@@ -151,7 +151,7 @@ def cut_windows(samples: np.ndarray, segments: Optional[List[Tuple[float, float]
             while pos + W <= b:
                 starts.append(pos)
                 pos += H
-            if starts and starts[-1] + W < b:
+            if pos - H + W < b:                      # this range's last window stops short of its end: add one flush with it
                 starts.append(b - W)
     out = np.zeros((len(starts), W), dtype=np.int16)
     spans = []
@@ -160,3 +160,43 @@ def cut_windows(samples: np.ndarray, segments: Optional[List[Tuple[float, float]
         out[i, :len(chunk)] = chunk
         spans.append((a / rate, min(n, a + W) / rate))
     return out, spans
+
+
+BUCKETS_S = (0.5, 1.0, 1.5, 2.0)      # window lengths the forward is launched with: 51 / 101 / 151 / 201 frames
+
+
+def cut_ranges(samples: np.ndarray, ranges: List[Tuple[float, float]], rate: int = 16000, buckets_s: Tuple[float, ...] = BUCKETS_S,
+               hop_s: float = 1.0):
+    """True-length windows for (start, end) ranges that belong to ONE speaker each (sentences, enrollment segments).
+
+    A window never leaves its range - nothing is widened into the neighbouring speech and nothing is zero padded:
+      * a range at least as long as the largest bucket is covered by largest-bucket windows at `hop_s`, the last one flush
+        with the range's end (the whole-recording rule, applied inside the range);
+      * a shorter range takes the largest bucket that fits and is covered by one or two such windows (first flush with
+        its start, second flush with its end);
+      * a range shorter than the smallest bucket is dropped (returned in `dropped`).
+    Returns (pcm_by_len {window samples: int16 [B, S]}, windows [(range index, S, row in pcm_by_len[S], start s, end s)],
+    dropped [range index]).  The forward takes a uniform length per launch, so the caller runs one launch per bucket."""
+    n = len(samples)
+    sizes = sorted(int(round(b * rate)) for b in buckets_s)
+    hop = int(round(hop_s * rate))
+    starts_by = {S: [] for S in sizes}
+    windows, dropped = [], []
+    for ri, (s, e) in enumerate(ranges):
+        a, b = max(0, int(round(s * rate))), min(n, int(round(e * rate)))
+        fit = [S for S in sizes if S <= b - a]
+        if not fit:
+            dropped.append(ri)
+            continue
+        S = fit[-1]
+        if S == sizes[-1]:
+            st = list(range(a, b - S + 1, hop))
+            if st[-1] + S < b:
+                st.append(b - S)
+        else:
+            st = [a] if b - a == S else [a, b - S]
+        for x in st:
+            windows.append((ri, S, len(starts_by[S]), x / rate, (x + S) / rate))
+            starts_by[S].append(x)
+    pcm_by_len = {S: np.stack([samples[x:x + S] for x in st]).astype(np.int16) for S, st in starts_by.items() if st}
+    return pcm_by_len, windows, dropped

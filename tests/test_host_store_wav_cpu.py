@@ -41,6 +41,36 @@ def test_cut_windows():
     assert pcm.shape == (1, 32000) and pcm[0, 8000:].sum() == 0 and spans == [(0.0, 0.5)]
 
 
+def test_cut_ranges_never_leaves_a_sentence():
+    """the committed Speechmatics fixture's 10 `is_eos` sentences (5 Alice, 5 Bob).  Every window lies
+    inside its own sentence - so none crosses the speaker change at 5.36 s, which the old 2-s widening did
+    (Alice's (4.64, 5.36) was embedded from 4.0-6.0 s) - lengths come from the bucket table, nothing is padded."""
+    seg = sub("segments")
+    data = json.loads((ROOT / "tests" / "golden" / "test_001-two-speakers.wav.speechmatics.json").read_text())
+    sents = seg.sentence_segments(data)
+    assert [s["speaker"] for s in sents] == ["Alice"] * 5 + ["Bob"] * 5
+    x = np.arange(16000 * 12, dtype=np.int32).astype(np.int16)
+    pcm_by_len, wins, dropped = wav.cut_ranges(x, [(s["start"], s["end"]) for s in sents])
+    assert dropped == [6]                                            # Bob's 0.48-s sentence is below the smallest bucket
+    assert set(pcm_by_len) <= {8000, 16000, 24000, 32000} and sum(len(v) for v in pcm_by_len.values()) == len(wins)
+    covered = {}
+    for ri, S, row, a, b in wins:
+        s0, s1 = sents[ri]["start"], sents[ri]["end"]
+        assert s0 - 1e-9 <= a and b <= s1 + 1e-9 and abs((b - a) * 16000 - S) < 1e-6          # inside the sentence, true length
+        assert S <= round((s1 - s0) * 16000) and (S == 32000 or round((s1 - s0) * 16000) < S + 8000)   # the largest bucket that fits
+        assert np.array_equal(pcm_by_len[S][row], x[round(a * 16000):round(a * 16000) + S])
+        covered.setdefault(ri, []).append((a, b))
+    for ri, spans in covered.items():                                 # a sentence is covered end to end
+        assert abs(min(a for a, _ in spans) - sents[ri]["start"]) < 1e-9 and abs(max(b for _, b in spans) - sents[ri]["end"]) < 1e-9
+    assert not any(a < 5.36 < b for _, _, _, a, b in wins)
+    # long ranges: 2-s windows at the hop, the last flush with the end; and the old cut_windows slip (a range's tail test
+    # looked at the PREVIOUS range's last start when the current range produced none) stays fixed
+    _, w2, _ = wav.cut_ranges(x, [(1.0, 6.3)])
+    assert [(round(a, 2), round(b, 2)) for _, _, _, a, b in w2] == [(1.0, 3.0), (2.0, 4.0), (3.0, 5.0), (4.0, 6.0), (4.3, 6.3)]
+    pcm, spans = wav.cut_windows(x, [(0.0, 4.5), (6.0, 8.0)])
+    assert spans == [(0.0, 2.0), (1.0, 3.0), (2.0, 4.0), (2.5, 4.5), (6.0, 8.0)]
+
+
 def _profile(sid, recs):
     return {"id": sid, "names": {"default": sid.title()}, "embeddings": {"mi355x": recs}}
 

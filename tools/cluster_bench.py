@@ -26,4 +26,8 @@ res = CL.spectral_cluster(eng, En, Eb, N, k, n_iter=15, n_kmeans=15)
 torch.cuda.synchronize(); out["spectral_cluster_s"] = round(time.perf_counter() - t0, 3)
 out["ari_vs_truth"] = ospec.adjusted_rand_index(res.labels, truth)
 out["eigenvalues"] = [round(float(x), 5) for x in res.eigenvalues[:6]]
+tr = CL.spectral_cluster(eng, En, Eb, N, k, n_iter=15, n_kmeans=15, trace=True)
+out["phases_s"] = {a: round(b, 4) for a, b in tr.timing.items()}
+out["n_matvec"] = 17
+out["ratio_to_matvec_time"] = round(out["spectral_cluster_s"] / (17 * ms * 1e-3), 2)
 print(json.dumps(out))
