@@ -214,31 +214,67 @@ def main() -> int:
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         elapsed = float(tt.item())
 
-    # ---- k5 measured on its own: the all-gather of the embedding shards, every rank taking part.
-    # Two sizes: this run's [B, 192] shard, and config #4's 125 000-row shard (96 MB fp32 per rank, 768 MB gathered at 8).
-    exchange = None
+    # ---- N > 1: what configs #4 and #5 define, every rank taking part (skipped at N = 1: those configs ARE 8-GPU shapes; their
+    # one-GPU kernels are timed in the `affinity` / `affinity_cluster` objects).  Wall time between fences, max over ranks.
+    exchange, cfg4, cfg5 = None, None, None
     if world > 1:
+        def timed(fn, reps):
+            for _ in range(2):
+                fn()
+            fence()
+            t1 = time.perf_counter()
+            for _ in range(reps):
+                fn()
+            fence()
+            dt = torch.tensor([(time.perf_counter() - t1) / reps], dtype=torch.float64, device=dev)
+            dist.all_reduce(dt, op=dist.ReduceOp.MAX)
+            return float(dt.item()) * 1e3
+
+        # k5 on its own: the all-gather of the embedding shards, this run's [B, 192] shard and config #4's 125 000-row shard
+        # (96 MB fp32 per rank, 768 MB gathered at 8 ranks)
         exchange = {}
         for label, rows in (("bench_shard", B), ("config4_shard", 125_000)):
             src = torch.empty((rows, 192), dtype=torch.float32, device=dev).normal_()
             dst = torch.empty((world * rows, 192), dtype=torch.float32, device=dev)
-            for _ in range(2):
-                sdist._gather_into(dst, src)
-            fence()
-            t1 = time.perf_counter()
-            reps = 10
-            for _ in range(reps):
-                sdist._gather_into(dst, src)
-            fence()
-            dt = torch.tensor([(time.perf_counter() - t1) / reps], dtype=torch.float64, device=dev)
-            dist.all_reduce(dt, op=dist.ReduceOp.MAX)
-            ms = float(dt.item()) * 1e3
+            ms = timed(lambda: sdist._gather_into(dst, src), 10)
             recv = (world - 1) * rows * 192 * 4
             exchange[label] = {"rows_per_rank": rows, "ms": round(ms, 4), "bytes_received_per_rank": recv,
                                "recv_GBps_per_rank": round(recv / (ms * 1e-3) / 1e9, 1)}
             del src, dst
         exchange["note"] = ("torch.distributed all_gather_into_tensor (backend nccl = RCCL over xGMI); xGMI is point to point, 7 links x ~153 GB/s "
                             "per GPU: direct-exchange floor for the config #4 shard at 8 GPUs = 672 MB / 1071 GB/s = 0.63 ms")
+
+        # config #4: 125 000 segments per GPU (1 M at 8) vs 10 000 replicated profiles: affinity + argmax per shard, no data-path
+        # collective (profiles are replicated), then the all-gather of the real 96 MB embedding shard for the clustering stage
+        N4, P4 = 125_000, 10_000
+        E4, E4b, r4 = eng.l2norm(torch.randn(N4, 192, device=dev, generator=torch.Generator(device=dev).manual_seed(40 + rank)))
+        Q4, Q4b, q4 = eng.l2norm(torch.randn(P4, 192, device=dev, generator=torch.Generator(device=dev).manual_seed(4)))
+        q4m = q4.max().reshape(1)
+        all4 = torch.empty((world * N4, 192), dtype=torch.float32, device=dev)
+        ms_aff = timed(lambda: eng.affinity_topk(E4, E4b, r4, Q4, Q4b, q4m, k=1), 5)
+        ms_both = timed(lambda: (eng.affinity_topk(E4, E4b, r4, Q4, Q4b, q4m, k=1), sdist._gather_into(all4, E4)), 5)
+        cfg4 = {"workload": f"config #4: {world} x 125k segments vs 10k replicated profiles (affinity + argmax per shard), then all-gather of the 96 MB shards",
+                "segments_total": world * N4, "profiles": P4, "ms_affinity": round(ms_aff, 4), "ms_affinity_plus_allgather": round(ms_both, 4),
+                "pairs_per_sec_total": round(world * N4 * P4 / (ms_aff * 1e-3), 1), "scaling": "weak"}
+        del E4, E4b, r4, all4
+
+        # config #5: one step of the row-sharded subspace iteration at N_total = 100 000, k = 16: all-gather of V [N, k] (6.4 MB) +
+        # the recomputed-affinity mat-vec on this rank's N / world rows against ALL embeddings (strong scaling: total work fixed)
+        N5, k5 = 100_000, 16
+        lo, hi = sdist.shard_bounds(N5, world)[rank]
+        E5, E5b, _ = eng.l2norm(torch.randn(N5, 192, device=dev, generator=torch.Generator(device=dev).manual_seed(5)))   # same on every rank
+        Eb_all = sdist.all_gather_rows(E5b[lo:hi].contiguous(), N5)                                                      # k5 on the bf16 copy
+        Vloc = torch.randn(hi - lo, k5, device=dev, generator=torch.Generator(device=dev).manual_seed(6 + rank))
+
+        def apply_step():
+            Vall = sdist.all_gather_rows(Vloc, N5)
+            return eng.affinity_matvec(Eb_all, Vall, lo, hi - lo)
+        ms5s = timed(apply_step, 5)
+        cfg5 = {"workload": f"config #5: one subspace-iteration step, 100k x 100k rectified affinity recomputed, rows sharded x{world} (V all-gather + mat-vec on N/{world} rows)",
+                "n_total": N5, "k": k5, "rows_per_rank": hi - lo, "ms_step": round(ms5s, 4),
+                "pairs_per_sec_total": round(N5 * float(N5) / (ms5s * 1e-3), 1), "scaling": "strong",
+                "gathered_equals_replica": bool(torch.equal(Eb_all, E5b))}
+        del E5, E5b, Eb_all
 
     out = None
     if rank == 0:
@@ -339,7 +375,7 @@ def main() -> int:
                        + (", RCCL all-gather of embeddings per step" if use_dist else "")},
             "affinity_pairs_per_sec": aff["pairs_per_sec"] if aff else None,
             "roofline": roofline, "roofline_forward_mfma": fwd_mfma, "roofline_forward_hbm_model": fwd_hbm, "affinity": aff,
-            "affinity_cluster": clus, "embedding_exchange": exchange,
+            "affinity_cluster": clus, "embedding_exchange": exchange, "config4_multi_gpu": cfg4, "config5_multi_gpu": cfg5,
             "kernels": kernels, "step_device_ms": round(step_dev_ms, 3),
             "device": {"name": info["name"], "arch": info["arch"], "cus": info["compute_units"], "clock_mhz": info["clock_khz"] / 1000.0},
             "peaks_used": {"bf16_mfma_tflops": PEAK_BF16_MFMA / 1e12, "hbm_gbps": PEAK_HBM / 1e9,

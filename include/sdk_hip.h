@@ -53,8 +53,9 @@ int sdk_get_device_info(sdk_ctx* ctx, sdk_device_info* out);
  * 0 = one workgroup per (segment, 128 channels)), "gemm_variant" (see
  * sdk_set_gemm_variant).  Results do not depend on them. */
 int sdk_set_option(sdk_ctx* ctx, const char* name, int value);
-/* Diagnostic builds only: "stamps" = device buffer [workgroups][64] of uint64 that the affinity kernel fills with
- * in-kernel wall-clock stamps (tools/aff_timeline.py); NULL (default) switches it off. */
+/* Diagnostics: "stamps" = device buffer [workgroups][64] of uint64 that the affinity kernel fills with in-kernel wall-clock
+ * stamps (tools/aff_timeline.py); "gemm_clock" = [workgroups <= 4096][2] uint64 {shader cycles, 100 MHz ticks} of each
+ * conv_gemm256 workgroup's lifetime (bench.py: the clock the chip holds inside the dominant kernel).  NULL (default) = off. */
 int sdk_debug_set_ptr(sdk_ctx* ctx, const char* name, void* device_ptr);
 
 /* ---- measurement: per-kernel-family HIP-event timing on the launch stream (bench.py roofline) -- */

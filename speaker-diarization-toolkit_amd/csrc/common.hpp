@@ -31,7 +31,8 @@ struct sdk_ctx {
   bool no_chain_fusion = false;   // A/B + test knob: run the Res2Net chain as separate conv_gemm launches
   bool no_asp_seg = false;        // A/B + test knob: ASP by (segment, 128-channel) workgroups instead of one per segment
   int aff_fast = 1;               // k = 1 affinity: 1 = row/column-maxima kernel (affinity_rowcol.hip), 0 = general sorted-list kernel
-  void* dbg_ptr = nullptr;         // diagnostic builds only: device buffer for in-kernel time stamps (sdk_debug_set_ptr)
+  void* dbg_ptr = nullptr;         // diagnostics only: device buffer for the affinity kernel's time stamps (sdk_debug_set_ptr "stamps")
+  void* gemm_clk_ptr = nullptr;    // diagnostics only: [workgroup][2] uint64 {shader cycles, 100 MHz ticks} of conv_gemm256_kernel ("gemm_clock")
   int aff_variant = 0;            // A/B knob: workgroup shape of the row/column kernel (see affinity_rowcol.hip)
   std::vector<const void*> lds_optin;   // kernels of THIS context's device already opted in to > 64 KiB dynamic LDS
   std::vector<sdk_prof_rec> prof;

@@ -43,6 +43,7 @@ struct Params {
   int tune;
   float* stats_part; int stats_mode;   // fused per-segment column statistics (256^2 kernel only)
   const bf16_t* A2; int64_t lda2;      // optional addend of the A operand (128^2 kernel only): A := bf16(A + A2)
+  unsigned long long* clk;             // diagnostics (256^2 kernel): per workgroup {shader cycles, 100 MHz ticks} of its lifetime, or null
 };
 
 __global__ __launch_bounds__(NT, 2) void conv_gemm_kernel(Params p) {
@@ -244,6 +245,8 @@ typedef void __attribute__((address_space(3)))* lptr_t;
 __global__ __launch_bounds__(NT2, 2) void conv_gemm256_kernel(Params p) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
+  // in-kernel clock probe (bench.py prints it next to the peaks): two scalar reads per workgroup, only when asked for
+  const unsigned long long clk_c0 = p.clk ? __builtin_amdgcn_s_memtime() : 0, clk_r0 = p.clk ? __builtin_amdgcn_s_memrealtime() : 0;
   const int wm = wid >> 2, wn = wid & 3;
 
   const int nbn = p.N / BN2;
@@ -497,6 +500,10 @@ __global__ __launch_bounds__(NT2, 2) void conv_gemm256_kernel(Params p) {
     }
     lds_barrier();                                      // the image is free: the next tile's DMA may overwrite it
   }   // persistent tile loop
+  if (p.clk && tid == 0 && blockIdx.x < 4096) {
+    p.clk[blockIdx.x * 2] = __builtin_amdgcn_s_memtime() - clk_c0;
+    p.clk[blockIdx.x * 2 + 1] = __builtin_amdgcn_s_memrealtime() - clk_r0;
+  }
 }
 
 // Combine the per-tile partials of a segment in tile order: mean (mode 1) or mean | std (mode 2).
@@ -585,6 +592,7 @@ extern "C" int sdk_conv_gemm(sdk_ctx* ctx, const sdk_conv_gemm_args* a, void* st
   p.tune = g_gemm_variant / 16;
   p.stats_part = nullptr; p.stats_mode = 0;
   p.A2 = (const bf16_t*)a->A2; p.lda2 = a->lda2;
+  p.clk = (unsigned long long*)ctx->gemm_clk_ptr;
   if (a->A2) SDK_REQUIRE(a->lda2 % 8 == 0 && a->lda2 >= a->Cin && ((uintptr_t)a->A2 % 16) == 0, "sdk_conv_gemm: bad A2/lda2");
 
   const double kk = (double)a->taps * a->Cin;

@@ -99,6 +99,10 @@ class Engine:
             self.load_weights()
         return self._desc
 
+    def debug_ptr(self, name: str, tensor: Optional[torch.Tensor]) -> None:
+        """Diagnostics: hand a device buffer to (or, with None, take it away from) an in-kernel probe (sdk_debug_set_ptr)."""
+        check(self.lib.sdk_debug_set_ptr(self.ctx, name.encode(), tensor.data_ptr() if tensor is not None else None), "sdk_debug_set_ptr")
+
     def set_option(self, name: str, value: int) -> None:
         check(self.lib.sdk_set_option(self.ctx, name.encode(), int(value)), "sdk_set_option")
 

@@ -15,10 +15,10 @@ qm = rq.max().reshape(1)
 eng.set_option("affinity_fast_path", 1); eng.set_option("affinity_variant", var)
 for _ in range(5): eng.affinity_topk(E, Eb, re, Q, Qb, qm, k=1)
 buf = torch.zeros(256 * 64 + 256 * 64, dtype=torch.int64, device="cuda")
-ops.check(eng.lib.sdk_debug_set_ptr(eng.ctx, b"stamps", buf.data_ptr()), "dbg")
+eng.debug_ptr("stamps", buf)
 eng.affinity_topk(E, Eb, re, Q, Qb, qm, k=1)
 torch.cuda.synchronize()
-ops.check(eng.lib.sdk_debug_set_ptr(eng.ctx, b"stamps", None), "dbg")
+eng.debug_ptr("stamps", None)
 allb = buf.cpu().numpy()
 t = allb[:256 * 64].reshape(256, 64)
 fine = allb[256 * 64:].reshape(256, 2, 32)

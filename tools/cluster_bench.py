@@ -23,7 +23,13 @@ out = {"N": N, "kv": k, "matvec_ms": round(ms, 3), "pairs_per_sec": round(N * N 
        "algorithmic_tflops_2N2(d+k)": round(2.0 * N * N * (192 + k) / (ms * 1e-3) / 1e12, 1)}
 torch.cuda.synchronize(); t0 = time.perf_counter()
 res = CL.spectral_cluster(eng, En, Eb, N, k, n_iter=15, n_kmeans=15)
-torch.cuda.synchronize(); out["spectral_cluster_s"] = round(time.perf_counter() - t0, 3)
+torch.cuda.synchronize(); out["spectral_cluster_first_call_s"] = round(time.perf_counter() - t0, 3)   # includes one-time costs (code-object load, scratch)
+times = []
+for _ in range(3):
+    torch.cuda.synchronize(); t0 = time.perf_counter()
+    res = CL.spectral_cluster(eng, En, Eb, N, k, n_iter=15, n_kmeans=15)
+    torch.cuda.synchronize(); times.append(time.perf_counter() - t0)
+out["spectral_cluster_s"] = round(sorted(times)[1], 4)
 out["ari_vs_truth"] = ospec.adjusted_rand_index(res.labels, truth)
 out["eigenvalues"] = [round(float(x), 5) for x in res.eigenvalues[:6]]
 tr = CL.spectral_cluster(eng, En, Eb, N, k, n_iter=15, n_kmeans=15, trace=True)
