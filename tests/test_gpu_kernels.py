@@ -461,6 +461,31 @@ def test_conv_gemm_fused_column_stats(engine, M, T, N, Cin, mode):
         assert torch.allclose(got[:, N:], sd, rtol=2e-4, atol=2e-5), float((got[:, N:] - sd).abs().max())
 
 
+@pytest.mark.parametrize("M,T,N,Cin,taps,dil,mode", [(2010, 201, 1024, 128, 1, 1, 1), (3000, 1500, 256, 64, 1, 1, 2), (2613, 201, 512, 128, 5, 1, 0),
+                                                     (1005, 201, 256, 64, 1, 1, 0), (4020, 201, 1024, 1024, 1, 1, 2), (1280, 128, 256, 192, 3, 3, 0)])
+def test_conv_gemm_overlapped_boundary_variant_is_bit_identical(engine, M, T, N, Cin, taps, dil, mode):
+    """gemm_variant 258 = the 256^2 kernel with the tile boundary overlapped (next tile's first K-step and parameters
+    prefetched by LDS-DMA, tile image in two 128-row passes, counted vmcnt that leaves the stores in flight): output and
+    fused column statistics must equal the default kernel's bit for bit, over several tiles per workgroup, edge tiles,
+    conv taps and one-K-step tiles."""
+    g = torch.Generator().manual_seed(M + N + taps)
+    A = dev(bf16_round(torch.randn(M, Cin, generator=g)), torch.bfloat16)
+    Wt = dev(bf16_round(torch.randn(N, taps * Cin, generator=g) * 0.1), torch.bfloat16)
+    bias, sc, sh = dev(torch.randn(N, generator=g)), dev(torch.rand(N, generator=g) + 0.5), dev(torch.randn(N, generator=g))
+    outs = {}
+    try:
+        for v in (2, 258):
+            engine.lib.sdk_set_gemm_variant(v)
+            outs[v] = engine.conv_gemm(A, Wt, N, Cin, taps=taps, dil=dil, T=T, bias=bias, scale=sc, shift=sh, relu=True, stats_mode=mode)
+            torch.cuda.synchronize()
+    finally:
+        engine.lib.sdk_set_gemm_variant(2)
+    a, b = outs[2], outs[258]
+    assert torch.equal(a[0], b[0])
+    if mode:
+        assert torch.equal(a[3], b[3])
+
+
 def test_conv_gemm_a2_addend(engine):
     """A2: the GEMM consumes bf16(A + A2) (Res2Net running sum formed on the way into LDS)."""
     M, T, N, Cin = 603, 201, 128, 128
