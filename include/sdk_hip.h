@@ -18,6 +18,21 @@
  *   - bf16 tensors are passed as uint16_t* (raw bfloat16 bits).
  *   - "rows" of an activation tensor are frames: row m = segment (m / T), frame (m % T),
  *     channel-last, row stride given explicitly (ld*, in elements).
+ *
+ * STABLE SURFACE - what a backend binds (INTEGRATION.md shows the stub); SDK_ABI_VERSION changes when any of these does:
+ *     sdk_abi_version  sdk_init  sdk_shutdown  sdk_last_error  sdk_get_device_info
+ *     sdk_resample_out_len  sdk_resample_s16                                   audio -> AudioProfile format
+ *     sdk_fbank_tables_bytes  sdk_fbank_tables_fill  sdk_fbank_workspace_bytes  sdk_fbank              k1
+ *     sdk_ecapa_workspace_bytes  sdk_ecapa_forward                                                      k2
+ *     sdk_l2norm                                                                                        k3
+ *     sdk_affinity_workspace_bytes  sdk_affinity_topk                                                   k4
+ *     sdk_affinity_matvec_workspace_bytes  sdk_affinity_matvec  sdk_rows_gram_workspace_bytes  sdk_rows_gram
+ *     sdk_rows_apply  sdk_rows_unit  sdk_kmeans_mindist  sdk_kmeans_assign                              k6 (driven by cluster.py)
+ * BUILDING BLOCKS AND KNOBS - exported for the parity tests and the A/B tools, free to change between rounds, not for binding:
+ *     sdk_conv_gemm*  sdk_colstats_finish  sdk_res2net_chain*  sdk_se_*  sdk_asp_*  sdk_rows_fc  (pieces of sdk_ecapa_forward)
+ *     sdk_set_option  sdk_set_gemm_variant  sdk_profile_begin / _end  sdk_debug_set_ptr  sdk_affinity_plan
+ * k5 (the embedding all-gather) is NOT here by design: the library holds no communicator; the exchange is one
+ * torch.distributed all_gather_into_tensor (backend "nccl" = RCCL over xGMI) in the host layer (dist.py).
  */
 #ifndef SDK_HIP_H
 #define SDK_HIP_H

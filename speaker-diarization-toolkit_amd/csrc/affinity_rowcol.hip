@@ -527,7 +527,7 @@ size_t ws_layout(int N, int P, char* base, Ws* w) {
 }
 
 // Work decomposition of the coarse kernel (host side; the kernel derives each workgroup's range from it).
-Geom plan_geometry(int N, int P, int segs, int tps, long long max_wg) {
+Geom plan_geometry(int N, int P, int segs, int tps, long long max_wg, int whole_groups_mode = 1) {
   Geom gm;
   gm.segs = segs;
   gm.ngroups = ceil_div(N, segs);
@@ -536,6 +536,15 @@ Geom plan_geometry(int N, int P, int segs, int tps, long long max_wg) {
   long long G = max_wg;
   if (G > 2LL * gm.ngroups) G = 2LL * gm.ngroups;     // every range >= half a sweep: a group's sweep meets <= 3 workgroups (MAXP slots)
   if (G > gm.U) G = gm.U;
+  // Short sweeps (few profile stages): splitting a group's sweep over workgroups costs each of them a fragment reload, a
+  // ring refill and a record (~8 us at config #3, against 8 stages of ~4.5 us).  When the groups alone fill most of the
+  // chip, give every workgroup ONE whole group instead: fewer CUs busy, no parts.  Estimated in stage units.
+  if (whole_groups_mode && gm.ngroups <= max_wg && G > gm.ngroups) {
+    // measured at config #3 (100k x 1k, 2-tile stages): split 50.1 us vs whole 47.2 us => the split costs ~4.5 stages extra
+    const double split = (double)gm.U / (double)G + 3.5 /* reload + refill + record */ + 1.0 /* one stage of granularity */;
+    const double whole = (double)gm.nst;
+    if (whole <= split || whole_groups_mode == 2) G = gm.ngroups;     // mode 2 (A/B knob): whenever the groups fit
+  }
   gm.G = (int)G;
   return gm;
 }
@@ -546,7 +555,7 @@ int launch_coarse(sdk_ctx* ctx, const bf16_t* Eb, const bf16_t* Pb, int N, int P
   constexpr int SEGS = WAVES * SEGB * 32;
   constexpr int LDS = NSTAGE * TPS * TILE_BYTES;
   *segs = SEGS;
-  const Geom gm = plan_geometry(N, P, SEGS, TPS, (long long)ctx->num_cu * wg_per_cu);
+  const Geom gm = plan_geometry(N, P, SEGS, TPS, (long long)ctx->num_cu * wg_per_cu, ctx->aff_whole_groups);
   auto kern = aff_rowcol_kernel<WAVES, SEGB, TPS, NSTAGE>;
   if (sdk_lds_optin(ctx, (const void*)kern, LDS)) return 1;
   hipLaunchKernelGGL(kern, dim3(gm.G), dim3(WAVES * 64), LDS, s, Eb, Pb, N, P, gm, w.stats, w.part_base, w.part_cnt, err,

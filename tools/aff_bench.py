@@ -7,15 +7,15 @@ import torch
 sys.path.insert(0, str(Path(__file__).resolve().parent.parent))
 ops = importlib.import_module("speaker-diarization-toolkit_amd.ops")
 eng = ops.get_engine(0)
-VARIANTS = [("general", 0, 0), ("rc8x2x2x4", 1, 0)]
+VARIANTS = [("general", 0, 0, 1), ("rc auto", 1, 0, 1), ("rc split", 1, 0, 0)]
 shapes = [(100_000, 1000), (125_000, 10_000)] if len(sys.argv) < 2 else [tuple(int(x) for x in a.split("x")) for a in sys.argv[1:]]
 for N3, P3 in shapes:
     E3, E3b, r3 = eng.l2norm(torch.randn(N3, 192, device="cuda", generator=torch.Generator(device="cuda").manual_seed(3)))
     Q3, Q3b, q3 = eng.l2norm(torch.randn(P3, 192, device="cuda", generator=torch.Generator(device="cuda").manual_seed(4)))
     q3m = q3.max().reshape(1)
     ref = None
-    for name, fast, var in VARIANTS:
-        eng.set_option("affinity_fast_path", fast); eng.set_option("affinity_variant", var)
+    for name, fast, var, wg in VARIANTS:
+        eng.set_option("affinity_fast_path", fast); eng.set_option("affinity_variant", var); eng.set_option("affinity_whole_groups", wg)
         idx, sc, cnt = eng.affinity_topk(E3, E3b, r3, Q3, Q3b, q3m, k=1, want_count=True)
         torch.cuda.synchronize()
         if ref is None:
@@ -31,19 +31,19 @@ for N3, P3 in shapes:
             same_i = bool(torch.equal(idx, ref[0])); same_s = bool(torch.equal(sc, ref[1]))
             nd = int((idx != ref[0]).sum())
             print(f"{N3}x{P3} {name}: idx identical {same_i} ({nd} differ), scores bit-identical {same_s}, rescanned {int(cnt.item())}", flush=True)
-    res = {n: [] for n, _, _ in VARIANTS}
+    res = {n: [] for n, _, _, _ in VARIANTS}
     for rnd in range(5):
-        for name, fast, var in VARIANTS:
-            eng.set_option("affinity_fast_path", fast); eng.set_option("affinity_variant", var)
+        for name, fast, var, wg in VARIANTS:
+            eng.set_option("affinity_fast_path", fast); eng.set_option("affinity_variant", var); eng.set_option("affinity_whole_groups", wg)
             for _ in range(2): eng.affinity_topk(E3, E3b, r3, Q3, Q3b, q3m, k=1)
             eng.profile_begin()
             for _ in range(10): eng.affinity_topk(E3, E3b, r3, Q3, Q3b, q3m, k=1)
             p = eng.profile_end()
             res[name].append({k: v["ms"] / 10 * 1e3 for k, v in p.items()})
-    for name, _, _ in VARIANTS:
+    for name, _, _, _ in VARIANTS:
         keys = res[name][0].keys()
         med = {k: sorted(r[k] for r in res[name])[len(res[name]) // 2] for k in keys}
         tot = sum(med.values())
         print(f"{N3}x{P3} {name:10s} " + " ".join(f"{k.replace('affinity_', '')}={v:.1f}" for k, v in med.items()) +
               f" total={tot:.1f} us  coarse {2 * N3 * P3 * 192 / med['affinity_coarse'] / 1e6:.0f} TF  total {2 * N3 * P3 * 192 / tot / 1e6:.0f} TF", flush=True)
-eng.set_option("affinity_fast_path", 1); eng.set_option("affinity_variant", 0)
+eng.set_option("affinity_fast_path", 1); eng.set_option("affinity_variant", 0); eng.set_option("affinity_whole_groups", 1)
