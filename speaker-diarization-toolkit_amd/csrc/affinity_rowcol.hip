@@ -240,7 +240,13 @@ __global__ __launch_bounds__(WAVES * 64, 2) void aff_rowcol_kernel(const bf16_t*
 // (i, j) = (c / 3, c % 3), the combinations c = (j & 3), (j & 3) + 4, (j & 3) + 8.  The live ones are gathered into one
 // list per row (identical on the 8 lanes) and scored two at a time with the shared dot routine.
 constexpr int MAXC = 8;                // candidates re-scored per row; more than that (rare) -> the row takes the rescan
+constexpr int INLINE_MAX_P = 0;        // rows the certificate cannot settle are scanned INSIDE the re-score kernel up to this many profiles.
+                                       // Measured at config #3 (P = 1000): re-score 25.7 -> 41-52 us (the few workgroups that own an uncertain row
+                                       // become a 15-us tail) against the 12 us of the two rescan launches it saves: off.
 
+// INLINE: the workgroup scans its own uncertain rows (typically none, ~0.1 % of rows) over all P right away - 32 lane groups
+// x P/32 profiles each - instead of queueing them for two more launches that cost ~12 us to settle ~100 rows at config #3.
+template <bool INLINE>
 __global__ __launch_bounds__(256) void aff_rowcol_rescore_kernel(const float* __restrict__ E, const float* __restrict__ Pm,
                                                                 const float* __restrict__ resid_e,
                                                                 const float* __restrict__ resid_p, int N, int P, int segs,
@@ -373,6 +379,14 @@ __global__ __launch_bounds__(256) void aff_rowcol_rescore_kernel(const float* __
     }
   }
   u = fmaxf(u, __shfl_xor(u, 4, 64));
+  __shared__ int fcount_s;
+  __shared__ int flist_s[32];
+  __shared__ float ls_s[32];
+  __shared__ int li_s[32];
+  if constexpr (INLINE) {
+    if (tid == 0) fcount_s = 0;
+    __syncthreads();
+  }
   if (live && j == 0) {
     // What was not re-scored: (a) entries outside the top-3 rows x top-3 columns: coarse <= u, exact <= u + eps;
     // (b) intersections pruned by best - 3 eps: exact < best - 2 eps; (c) intersections pruned by s1 - eps: exact < s1
@@ -380,11 +394,54 @@ __global__ __launch_bounds__(256) void aff_rowcol_rescore_kernel(const float* __
     const float outside = fmaxf(u + eps, best - 2.0f * eps);
     const bool uncertain = M > MAXC || !(bs > outside);
     if (uncertain) {
-      const int slot = atomicAdd(flag_count, 1);
-      flag_rows[slot] = row;
+      if constexpr (INLINE) flist_s[atomicAdd(&fcount_s, 1)] = row;
+      else flag_rows[atomicAdd(flag_count, 1)] = row;
     }
-    idx[row] = bi;
-    score[row] = bs;
+    if (!(INLINE && uncertain)) {       // INLINE: an uncertain row is written once, by the scan below (no two writers of one address)
+      idx[row] = bi;
+      score[row] = bs;
+    }
+  }
+  if constexpr (INLINE) {
+    __syncthreads();
+    const int nf = fcount_s;
+    if (nf > 0 && tid == 0) atomicAdd(flag_count, nf);             // reported only (n_rescanned)
+    const int g = tid >> 3;
+    for (int f = 0; f < nf; ++f) {                                  // workgroup-uniform
+      const int frow = flist_s[f];
+      float ef[24];
+#pragma unroll
+      for (int q = 0; q < 6; ++q) {
+        const f32x4 v = *reinterpret_cast<const f32x4*>(E + (int64_t)frow * D + 24 * j + 4 * q);
+        ef[4 * q] = v[0]; ef[4 * q + 1] = v[1]; ef[4 * q + 2] = v[2]; ef[4 * q + 3] = v[3];
+      }
+      float fs = -INFINITY;
+      int fi = 0x7fffffff;
+      for (int p0 = g; p0 < P; p0 += 64) {                          // ascending per lane group, two rows in flight
+        const int pa = p0, pb2 = p0 + 32 < P ? p0 + 32 : p0;
+        f32x4 pv0[6], pv1[6];
+        load_prow(Pm + (int64_t)pa * D, j, pv0);
+        load_prow(Pm + (int64_t)pb2 * D, j, pv1);
+        const float sa = dot192_regs(ef, pv0);
+        const float sb2 = dot192_regs(ef, pv1);
+        if (better(sa, pa, fs, fi)) { fs = sa; fi = pa; }
+        if (better(sb2, pb2, fs, fi)) { fs = sb2; fi = pb2; }     // pb2 == pa past the end: no effect
+      }
+      if (j == 0) { ls_s[g] = fs; li_s[g] = fi; }
+      __syncthreads();
+      if (tid < 64) {
+        float s2 = tid < 32 ? ls_s[tid] : -INFINITY;
+        int i2 = tid < 32 ? li_s[tid] : 0x7fffffff;
+#pragma unroll
+        for (int o = 16; o > 0; o >>= 1) {
+          const float ts = __shfl_xor(s2, o, 64);
+          const int ti = __shfl_xor(i2, o, 64);
+          if (better(ts, ti, s2, i2)) { s2 = ts; i2 = ti; }
+        }
+        if (tid == 0) { idx[frow] = i2; score[frow] = s2; }
+      }
+      __syncthreads();
+    }
   }
 }
 
@@ -601,11 +658,15 @@ int aff_rowcol_top1(sdk_ctx* ctx, const float* E, const uint16_t* Eb, const floa
   SDK_LAUNCH_CHECK();
   {
     ProfScope ps(ctx, stream, SDK_K_AFF_RESCORE, 0.0, 4.0 * N * D + 64.0 * N + 8.0 * N);
-    hipLaunchKernelGGL(aff_rowcol_rescore_kernel, dim3(ceil_div(N, 32)), dim3(256), 0, s, E, P, resid_e, resid_p, N, Pn, segs,
-                       w.stats, w.part_base, w.part_cnt, idx, score, w.flag_count, w.flag_rows);
+    if (Pn <= INLINE_MAX_P)
+      hipLaunchKernelGGL(aff_rowcol_rescore_kernel<true>, dim3(ceil_div(N, 32)), dim3(256), 0, s, E, P, resid_e, resid_p, N, Pn, segs,
+                         w.stats, w.part_base, w.part_cnt, idx, score, w.flag_count, w.flag_rows);
+    else
+      hipLaunchKernelGGL(aff_rowcol_rescore_kernel<false>, dim3(ceil_div(N, 32)), dim3(256), 0, s, E, P, resid_e, resid_p, N, Pn, segs,
+                         w.stats, w.part_base, w.part_cnt, idx, score, w.flag_count, w.flag_rows);
   }
   SDK_LAUNCH_CHECK();
-  {
+  if (Pn > INLINE_MAX_P) {
     ProfScope ps(ctx, stream, SDK_K_AFF_RESCAN, 0.0, 0.0);
     hipLaunchKernelGGL(aff_rescan4_kernel, dim3(RS_GRID), dim3(256), 0, s, E, P, Pn, w.flag_count, w.flag_rows, w.part_s, w.part_i,
                        idx, score);
