@@ -276,6 +276,14 @@ def main() -> int:
                 "gathered_equals_replica": bool(torch.equal(Eb_all, E5b))}
         del E5, E5b, Eb_all
 
+    if os.environ.get("SDK_BENCH_PMC"):      # counter passes (tools/pmc_bench.sh): exactly warmup + steps passes of the hot path, nothing else
+        if rank == 0:
+            print(json.dumps({"pmc_mode": True, "steps": args.steps, "warmup": args.warmup, "segments": B}), flush=True)
+        if use_dist:
+            dist.barrier()
+            dist.destroy_process_group()
+        return 0
+
     out = None
     if rank == 0:
         ms_step = elapsed / args.steps * 1e3

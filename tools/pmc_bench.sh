@@ -2,7 +2,7 @@
 # HBM-side traffic of the bench step per kernel: separate --pmc passes (FETCH_SIZE and WRITE_SIZE do not fit one pass)
 cd "${GRAFT_REPO_ROOT:-/root/repo}"; mkdir -p gpurun_out/pmcb; export TMPDIR=/tmp
 for c in FETCH_SIZE WRITE_SIZE; do
-  timeout -k 10 400 rocprofv3 --kernel-trace --pmc $c --output-format csv -d gpurun_out/pmcb/$c -o b -- python3 bench.py --steps 1 --warmup 1 --no-cpu-baseline --no-affinity-config3 > gpurun_out/pmcb/$c.log 2>&1 || { tail -5 gpurun_out/pmcb/$c.log; exit 1; }
+  SDK_BENCH_PMC=1 timeout -k 10 400 rocprofv3 --kernel-trace --pmc $c --output-format csv -d gpurun_out/pmcb/$c -o b -- python3 bench.py --steps 1 --warmup 1 --no-cpu-baseline --no-affinity-config3 > gpurun_out/pmcb/$c.log 2>&1 || { tail -5 gpurun_out/pmcb/$c.log; exit 1; }
 done
 python3 - <<'PY'
 import csv, glob, json, collections
@@ -17,10 +17,12 @@ for c in ("FETCH_SIZE", "WRITE_SIZE"):
         name = r["Kernel_Name"].replace("(anonymous namespace)::", "").split("(")[0].split("<")[0]
         per_kernel[name].append(float(r["Counter_Value"]))
     for k, v in per_kernel.items():
-        n = len(v) // 3          # bench ran warmup + timed + profiled step = 3 identical steps
+        n = len(v) // 2          # SDK_BENCH_PMC=1: bench ran exactly 1 warm-up + 1 timed pass of the hot path
         last = v[-n:] if n else v
         out[k][c + "_KB"] = sum(last)
         out[k]["launches"] = len(last)
+out["_workload"] = {"segments": 1000, "steps": 1, "warmup": 1, "note": "per-kernel sums over ONE pass of the hot path"}
 json.dump(out, open("gpurun_out/pmcb/pmc_bench.json", "w"), indent=1)
-for k, v in out.items(): print(k, dict(v))
+for k, v in out.items():
+    if not k.startswith("_"): print(k, dict(v))
 PY
