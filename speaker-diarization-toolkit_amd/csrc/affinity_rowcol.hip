@@ -276,7 +276,7 @@ __global__ __launch_bounds__(256) void aff_rowcol_rescore_kernel(const float* __
   const float re = resid_e[rc];
   float e24[24];
 #pragma unroll
-  for (int q = 0; q < 6; ++q) {
+  for (int q = 0; q < 6; ++q) {     // plain loads: a non-temporal hint here cost 19 us (25.7 -> 44.6: E then comes from HBM instead of the Infinity Cache)
     const f32x4 v = *reinterpret_cast<const f32x4*>(E + (int64_t)rc * D + 24 * j + 4 * q);
     e24[4 * q] = v[0]; e24[4 * q + 1] = v[1]; e24[4 * q + 2] = v[2]; e24[4 * q + 3] = v[3];
   }
@@ -365,17 +365,14 @@ __global__ __launch_bounds__(256) void aff_rowcol_rescore_kernel(const float* __
       }
     }
   }
+  for (int m = 0; m < MAXC; ++m) {                                 // one at a time: the list is empty for ~85 % of the rows, and 24 fewer
+    if (m < M) {                                                   // registers buy a wave more per SIMD for the two dependent round trips
+      int c0 = list[0];
 #pragma unroll
-  for (int m = 0; m < MAXC; m += 2) {
-    if (m < M) {                                                   // uniform inside a lane group
-      const int c0 = list[m], c1 = m + 1 < M ? list[m + 1] : list[m];
-      f32x4 pv0[6], pv1[6];
-      load_prow(Pm + (int64_t)c0 * D, j, pv0);
-      load_prow(Pm + (int64_t)c1 * D, j, pv1);
-      const float s0 = dot192_regs(e24, pv0);
-      const float s1 = dot192_regs(e24, pv1);
+      for (int q = 1; q < MAXC; ++q)
+        if (q == m) c0 = list[q];
+      const float s0 = dot192_group8(e24, Pm + (int64_t)c0 * D, j);
       if (better(s0, c0, bs, bi)) { bs = s0; bi = c0; }
-      if (better(s1, c1, bs, bi)) { bs = s1; bi = c1; }           // c1 == c0 when the list is odd: no effect
     }
   }
   u = fmaxf(u, __shfl_xor(u, 4, 64));
@@ -584,7 +581,7 @@ size_t ws_layout(int N, int P, char* base, Ws* w) {
 }
 
 // Work decomposition of the coarse kernel (host side; the kernel derives each workgroup's range from it).
-Geom plan_geometry(int N, int P, int segs, int tps, long long max_wg, int whole_groups_mode = 1) {
+Geom plan_geometry(int N, int P, int segs, int tps, long long max_wg, int whole_groups_mode = 0) {
   Geom gm;
   gm.segs = segs;
   gm.ngroups = ceil_div(N, segs);
