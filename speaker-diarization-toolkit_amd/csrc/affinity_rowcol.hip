@@ -158,6 +158,9 @@ __global__ __launch_bounds__(WAVES * 64, 2) void aff_rowcol_kernel(const bf16_t*
   for (int a = 0; a < AHEAD; ++a)
     if (u0 + a < u1) issue();
   const int rsw = (col >> 1) & 7;
+  int aoff[4];
+#pragma unroll
+  for (int q = 0; q < 4; ++q) aoff[q] = col * PROWB + (((2 * q + h) ^ rsw) << 4);
   int k = 0;
   long long u = u0;
   while (u < u1) {                                 // one portion = this workgroup's share of one group's sweep
@@ -184,12 +187,16 @@ __global__ __launch_bounds__(WAVES * 64, 2) void aff_rowcol_kernel(const bf16_t*
       __builtin_amdgcn_s_barrier();                 // stage k landed for everyone; the buffer of stage k-1 is free
       stamp();
       if (u + AHEAD < u1) issue();
-      const char* stg = sP + (k % NSTAGE) * STAGE_BYTES + col * PROWB;
+      // Fragment addresses: chunk c = 2 ks + h of this lane's row sits at 16 * ((c & ~7) | ((c & 7) ^ rsw)); its low three
+      // bits depend only on ks & 3, so four per-lane offsets + compile-time immediates (tile, ks >> 2) cover all 12 reads of
+      // every tile.  (Left to the compiler, the XOR was re-derived per read: ~50 of the ~118 vector instructions per tile.)
+      const char* sq[4];
+#pragma unroll
+      for (int q = 0; q < 4; ++q) sq[q] = sP + (k % NSTAGE) * STAGE_BYTES + aoff[q];
 #pragma unroll
       for (int tt = 0; tt < TPS; ++tt) {
         const int tile = s * TPS + tt;
         if (tile < ntiles) {                         // wave-uniform
-          const char* st = stg + tt * TILE_BYTES;
           f32x16 acc[SEGB];
 #pragma unroll
           for (int sb = 0; sb < SEGB; ++sb)
@@ -197,8 +204,7 @@ __global__ __launch_bounds__(WAVES * 64, 2) void aff_rowcol_kernel(const bf16_t*
             for (int r = 0; r < 16; ++r) acc[sb][r] = 0.f;
 #pragma unroll
           for (int ks = 0; ks < KS; ++ks) {
-            const int c = ks * 2 + h;
-            const bf16x8 a = *reinterpret_cast<const bf16x8*>(st + (((c & ~7) | ((c & 7) ^ rsw)) << 4));
+            const bf16x8 a = *reinterpret_cast<const bf16x8*>(sq[ks & 3] + tt * TILE_BYTES + (ks >> 2) * 128);
 #pragma unroll
             for (int sb = 0; sb < SEGB; ++sb) acc[sb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, bfrag[sb][ks], acc[sb], 0, 0, 0);
           }
