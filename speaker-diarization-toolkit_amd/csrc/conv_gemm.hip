@@ -269,6 +269,21 @@ __global__ __launch_bounds__(NT2, 2) void conv_gemm256_kernel(Params p) {
     const bool rowmajor = (p.tune & 4) != 0;            // A/B knob: plain n-fastest order
     tm0 = (rowmajor ? tile / nbn : grp * GM + in_grp % gm) * BM2;
     tn0 = (rowmajor ? tile % nbn : in_grp / gm) * BN2;
+    if (p.tune & 32) {
+      // A/B knob: a workgroup walks ALL n-tiles of one m-tile back to back (its A row block is re-read from the Infinity Cache by
+      // the same CU instead of by three other workgroups at unrelated times); the last, partial round of m-tiles is dealt out
+      // tile by tile so the tail stays one tile long.  vt = blockIdx + gridDim * i.
+      const int G = gridDim.x, b = vt % G, i = vt / G;
+      const int full_rounds = nbm / G;                  // m-rounds in which every workgroup owns an m-tile
+      if (i < full_rounds * nbn) {
+        tm0 = (b + G * (i / nbn)) * BM2;
+        tn0 = (i % nbn) * BN2;
+      } else {
+        const int j = (i - full_rounds * nbn) * G + b;  // tail: tile index inside the remaining (nbm % G) m-tiles, n fastest
+        tm0 = (full_rounds * G + j / nbn) * BM2;
+        tn0 = (j % nbn) * BN2;
+      }
+    }
   };
 
   // ---- DMA assignment: wave wid fills rows [32 wid, 32 wid + 32) of A and of B, 8 rows per instruction.

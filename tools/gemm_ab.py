@@ -12,10 +12,11 @@ for name, N, Cin, taps, dil, stats in shapes:
     A = (torch.randn(M, Cin, device="cuda") * 0.5).bfloat16()
     W = (torch.randn(N, taps * Cin, device="cuda") * 0.03).bfloat16()
     bias = torch.randn(N, device="cuda"); sc = torch.rand(N, device="cuda") + 0.5; sh = torch.randn(N, device="cuda")
-    res = {258: [], 2: []}
+    VA, VB = (int(sys.argv[1]), int(sys.argv[2])) if len(sys.argv) > 2 else (258, 2)
+    res = {VA: [], VB: []}
     outs = {}
     for rnd in range(7):
-        for v in (258, 2):
+        for v in (VA, VB):
             eng.lib.sdk_set_gemm_variant(v)
             eng.conv_gemm(A, W, N, Cin, taps=taps, dil=dil, T=T, bias=bias, scale=sc, shift=sh, relu=True, stats_mode=stats)
             eng.profile_begin()
@@ -24,8 +25,8 @@ for name, N, Cin, taps, dil, stats in shapes:
             p = eng.profile_end()
             res[v].append(sum(x["ms"] for x in p.values()) / 3)
             outs[v] = o
-    same = all(torch.equal(a, b) for a, b in zip(outs[2] if isinstance(outs[2], tuple) else (outs[2],), outs[258] if isinstance(outs[258], tuple) else (outs[258],)) if a is not None)
-    m3, m2 = np.median(res[258]), np.median(res[2])
+    same = all(torch.equal(a, b) for a, b in zip(outs[VB] if isinstance(outs[VB], tuple) else (outs[VB],), outs[VA] if isinstance(outs[VA], tuple) else (outs[VA],)) if a is not None)
+    m3, m2 = np.median(res[VA]), np.median(res[VB])
     fl = 2.0 * M * N * taps * Cin
-    print(f"{name:26s} v3 {m3 * 1e3:8.1f} us ({fl / m3 / 1e9:6.0f} TF)   v2 {m2 * 1e3:8.1f} us ({fl / m2 / 1e9:6.0f} TF)   v3/v2 {m3 / m2:.3f}   outputs identical: {same}", flush=True)
+    print(f"{name:26s} variant {VA} {m3 * 1e3:8.1f} us ({fl / m3 / 1e9:6.0f} TF)   variant {VB} {m2 * 1e3:8.1f} us ({fl / m2 / 1e9:6.0f} TF)   ratio {m3 / m2:.3f}   outputs identical: {same}", flush=True)
 eng.lib.sdk_set_gemm_variant(2)
