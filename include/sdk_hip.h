@@ -27,7 +27,7 @@
  *     sdk_l2norm                                                                                        k3
  *     sdk_affinity_workspace_bytes  sdk_affinity_topk                                                   k4
  *     sdk_affinity_matvec_workspace_bytes  sdk_affinity_matvec  sdk_rows_gram_workspace_bytes  sdk_rows_gram
- *     sdk_rows_apply  sdk_rows_unit  sdk_kmeans_mindist  sdk_kmeans_assign                              k6 (driven by cluster.py)
+ *     sdk_rows_apply  sdk_chol_inverse  sdk_rows_unit  sdk_kmeans_mindist  sdk_kmeans_assign            k6 (driven by cluster.py)
  * BUILDING BLOCKS AND KNOBS - exported for the parity tests and the A/B tools, free to change between rounds, not for binding:
  *     sdk_conv_gemm*  sdk_colstats_finish  sdk_res2net_chain*  sdk_se_*  sdk_asp_*  sdk_rows_fc  (pieces of sdk_ecapa_forward)
  *     sdk_set_option  sdk_set_gemm_variant  sdk_profile_begin / _end  sdk_debug_set_ptr  sdk_affinity_plan
@@ -242,6 +242,8 @@ int sdk_affinity_topk(sdk_ctx* ctx, const float* E, const uint16_t* Eb, const fl
  *                         Degrees are the case X = ones.  ws: sdk_affinity_matvec_workspace_bytes(N).
  *   sdk_rows_gram       : G [k,k] = X^T Y over n rows (order-fixed two-stage reduction)
  *   sdk_rows_apply      : Y[i,:] = scale[i] * (X[i,:] @ R),  R [k,k] row-major, scale may be NULL
+ *   sdk_chol_inverse    : Rinv [k,k] = (L^T)^-1 with (G + G^T)/2 = L L^T, float64 inside (CholeskyQR without leaving the stream);
+ *                         *not_spd (device, may be NULL) is set to 1 if a pivot was not positive
  *   sdk_rows_unit       : rows scaled to unit length
  *   sdk_kmeans_mindist  : d2[i] = (first ? : min(d2[i],)) |R[i] - centre|^2      (maximin initialisation)
  *   sdk_kmeans_assign   : label[i] = nearest of kc centres (ties -> lowest), dist2, optional per-256-row-block
@@ -253,6 +255,7 @@ int sdk_affinity_matvec(sdk_ctx* ctx, const uint16_t* Eb, int N, int d, int row0
 size_t sdk_rows_gram_workspace_bytes(int n, int k);
 int sdk_rows_gram(sdk_ctx* ctx, const float* X, const float* Y, int n, int k, float* G, void* ws, size_t ws_bytes, void* stream);
 int sdk_rows_apply(sdk_ctx* ctx, const float* X, const float* R, const float* scale, int n, int k, float* Y, void* stream);
+int sdk_chol_inverse(sdk_ctx* ctx, const float* G, int k, float* Rinv, int32_t* not_spd, void* stream);
 int sdk_rows_unit(sdk_ctx* ctx, const float* X, int n, int k, float* Y, void* stream);
 int sdk_kmeans_mindist(sdk_ctx* ctx, const float* R, int n, int k, const float* centre, float* d2, int first, void* stream);
 int sdk_kmeans_assign(sdk_ctx* ctx, const float* R, int n, int k, const float* centres, int kc, int32_t* label,

@@ -99,6 +99,7 @@ SIGNATURES = {
     "sdk_rows_gram": (_i, [_vp, _vp, _vp, _i, _i, _vp, _vp, _sz, _vp]),
     "sdk_rows_apply": (_i, [_vp, _vp, _vp, _vp, _i, _i, _vp, _vp]),
     "sdk_rows_unit": (_i, [_vp, _vp, _i, _i, _vp, _vp]),
+    "sdk_chol_inverse": (_i, [_vp, _vp, _i, _vp, _vp, _vp]),
     "sdk_kmeans_mindist": (_i, [_vp, _vp, _i, _i, _vp, _vp, _i, _vp]),
     "sdk_kmeans_assign": (_i, [_vp, _vp, _i, _i, _vp, _i, _vp, _vp, _vp, _vp, _vp]),
     "sdk_affinity_topk": (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _vp, _vp, _vp, _vp, _sz, _vp]),

@@ -10,8 +10,9 @@ N L2-normalised embeddings on the rectified cosine affinity, row-sharded over th
     k-means : rows of U normalised; maximin init; Lloyd with centroid all-reduce
     labels  : canonical (order of first appearance over the global row order)
 
-Every O(N^2) and O(N k^2) operation runs in libsdk_hip.so (ops.Engine); the k x k algebra (Cholesky,
-eigh of a 16 x 16 matrix) is done on the host in float64.  The algorithm is restated for the CPU in
+Every O(N^2) and O(N k^2) operation runs in libsdk_hip.so (ops.Engine), and so does the k x k Cholesky + triangular inverse
+of every CholeskyQR pass (sdk_chol_inverse, float64): the subspace iteration, the maximin initialisation and the Lloyd passes never
+synchronise with the host.  The one k x k eigh of the Ritz step runs on the host in float64, once.  The algorithm is restated for the CPU in
 oracle/spectral.py; free choices (rectification, init, iteration counts) are identical.
 
 `provider` is the object that executes the row-block primitives: an ops.Engine on a GPU.  The
@@ -50,17 +51,6 @@ class _Comm:
 
     def sum_(self, x: torch.Tensor) -> torch.Tensor:
         return sdist.all_reduce_sum(x, self.group) if self.on else x
-
-    def argmax_row(self, value: float, row: int, dev) -> int:
-        """Global row index of the largest value (ties -> lowest row)."""
-        if not self.on:
-            return row
-        import torch.distributed as d
-        t = torch.tensor([value, float(row)], dtype=torch.float64, device=dev)
-        out = torch.zeros((self.world * 2,), dtype=torch.float64, device=dev)
-        sdist._gather_into(out, t, self.group)
-        pairs = out.reshape(self.world, 2).cpu().tolist()
-        return int(max(pairs, key=lambda p: (p[0], -p[1]))[1])
 
 
 def canonical_labels(lab: np.ndarray) -> np.ndarray:
@@ -138,46 +128,62 @@ def spectral_cluster(provider, E_local: torch.Tensor, Eb_local: torch.Tensor, n_
 
 
 def _orth(provider, comm: _Comm, Y: torch.Tensor, k: int) -> torch.Tensor:
-    """CholeskyQR2: Q = Y R^-1 with R^T R = sum_ranks Y^T Y; applied twice for fp32 stability."""
+    """CholeskyQR2: Q = Y R^-1 with R^T R = sum_ranks Y^T Y; applied twice for fp32 stability.  Nothing here synchronises with the
+    host: Gram (two-stage, order-fixed) -> all-reduce -> k x k Cholesky + triangular inverse in float64 on the device -> apply."""
     for _ in range(2):
-        G = comm.sum_(provider.rows_gram(Y, Y)).double().cpu().numpy()
-        G = 0.5 * (G + G.T)
-        L = np.linalg.cholesky(G + 1e-30 * np.eye(k))
-        Rinv = np.linalg.inv(L.T)                                                  # Y R^-1, R = L^T
-        Y = provider.rows_apply(Y, torch.from_numpy(np.ascontiguousarray(Rinv).astype(np.float32)).to(Y.device))
+        G = comm.sum_(provider.rows_gram(Y, Y))
+        Y = provider.rows_apply(Y, provider.chol_inverse(G))
     return Y
 
 
 def _kmeans(provider, comm: _Comm, R: torch.Tensor, lo: int, n_total: int, k: int, n_iter: int) -> torch.Tensor:
+    """Maximin initialisation + Lloyd, row-sharded.  Device-side selection throughout (no .item(), no host comparison): at 8 GPUs
+    every host round trip would also be a collective everyone waits in."""
     dev = R.device
     n_loc = R.shape[0]
+    kdim = R.shape[1]
 
-    def fetch_row(global_row: int) -> torch.Tensor:
-        """The row with this global index, on every rank (owner contributes it, others zeros; summed)."""
-        v = torch.zeros((R.shape[1],), dtype=torch.float32, device=dev)
-        if lo <= global_row < lo + n_loc:
-            v = R[global_row - lo].clone()
-        return comm.sum_(v)
+    def fetch_row(grow: torch.Tensor) -> torch.Tensor:
+        """The row with this GLOBAL index (0-d int64 tensor on the device), on every rank: the owner contributes it, the others
+        zeros; summed."""
+        if n_loc:
+            loc = (grow - lo).clamp(0, n_loc - 1).reshape(1)
+            mine = ((grow >= lo) & (grow < lo + n_loc)).to(torch.float32)
+            v = R.index_select(0, loc)[0] * mine
+        else:
+            v = torch.zeros((kdim,), dtype=torch.float32, device=dev)
+        return comm.sum_(v.contiguous())
 
-    centres = [fetch_row(0)]
+    def global_argmax(val: torch.Tensor, grow: torch.Tensor) -> torch.Tensor:
+        """Global row index of the largest value over the ranks (ties -> lowest row), as a device tensor."""
+        if not comm.on:
+            return grow
+        pair = torch.stack([val.double(), grow.double()])
+        out = torch.zeros((comm.world * 2,), dtype=torch.float64, device=dev)
+        sdist._gather_into(out, pair, comm.group)
+        pairs = out.reshape(comm.world, 2)
+        best = pairs[:, 0].max()
+        rows = torch.where(pairs[:, 0] == best, pairs[:, 1], torch.full_like(pairs[:, 1], float(n_total)))
+        return rows.min().to(torch.int64)
+
+    centres = [fetch_row(torch.zeros((), dtype=torch.int64, device=dev))]
     d2 = torch.empty((max(n_loc, 1),), dtype=torch.float32, device=dev)[:n_loc]
     for j in range(1, k):
         if n_loc:
             provider.kmeans_mindist(R, centres[-1], d2, first=(j == 1))
-            val, arg = torch.max(d2, dim=0)
-            cand = (float(val.item()), lo + int(arg.item()))
+            val, arg = torch.max(d2, dim=0)                 # first maximum = lowest local row
+            grow = arg.to(torch.int64) + lo
         else:
-            cand = (-1.0, n_total)
-        centres.append(fetch_row(comm.argmax_row(cand[0], cand[1], dev)))
+            val = torch.full((), -1.0, dtype=torch.float32, device=dev)
+            grow = torch.full((), n_total, dtype=torch.int64, device=dev)
+        centres.append(fetch_row(global_argmax(val, grow)))
     C = torch.stack(centres).contiguous()
-    labels = torch.zeros((n_loc,), dtype=torch.int32, device=dev)
+    # Lloyd: a fixed number of passes.  Once the centres stop moving a pass reproduces them bit for bit (same sums, same counts),
+    # so running past convergence changes nothing - and saves the host comparison every pass used to end with.
     for _ in range(n_iter):
-        labels, _, ps, pc = provider.kmeans_assign(R, C, want_sums=True)
+        _, _, ps, pc = provider.kmeans_assign(R, C, want_sums=True)
         sums = comm.sum_(ps.double().sum(dim=0))
         cnts = comm.sum_(pc.sum(dim=0).double())
-        newC = torch.where(cnts[:, None] > 0, sums / cnts.clamp_min(1.0)[:, None], C.double()).float()
-        if torch.equal(newC, C):
-            break
-        C = newC.contiguous()
+        C = torch.where(cnts[:, None] > 0, sums / cnts.clamp_min(1.0)[:, None], C.double()).float().contiguous()
     labels, _, _, _ = provider.kmeans_assign(R, C, want_sums=False)
     return labels

@@ -248,6 +248,40 @@ __global__ __launch_bounds__(256) void kmeans_mindist_kernel(const float* __rest
   d2[i] = first ? d : fminf(d2[i], d);
 }
 
+
+// k x k (k <= 32) Cholesky-QR step on the device: G = sum_ranks Y^T Y  ->  Rinv with Y Rinv orthonormal, i.e.
+// G_s = (G + G^T) / 2, G_s = L L^T, Rinv = (L^T)^-1, all in float64 by ONE lane (5 k flop at k = 16: the point is not speed but
+// that the subspace iteration never leaves the stream - the host-side form synchronised twice per CholeskyQR pass).
+__global__ __launch_bounds__(64) void chol_inverse_kernel(const float* __restrict__ G, int k, float* __restrict__ Rinv, int* __restrict__ bad) {
+  __shared__ double L[KV][KV + 1];
+  __shared__ double X[KV][KV + 1];
+  if (threadIdx.x != 0) return;
+  int fail = 0;
+  for (int i = 0; i < k; ++i)
+    for (int j = 0; j <= i; ++j) {
+      double a = 0.5 * ((double)G[i * k + j] + (double)G[j * k + i]);
+      if (i == j) a += 1e-30;
+      for (int q = 0; q < j; ++q) a -= L[i][q] * L[j][q];
+      if (i == j) {
+        if (!(a > 0.0)) { fail = 1; a = 1.0; }
+        L[i][i] = sqrt(a);
+      } else {
+        L[i][j] = a / L[j][j];
+      }
+    }
+  // X = (L^T)^-1 : upper triangular, X[i][j] for i <= j;  sum_{q=i..j} U[i][q] X[q][j] = delta_ij with U = L^T (U[i][q] = L[q][i])
+  for (int j = 0; j < k; ++j)
+    for (int i = k - 1; i >= 0; --i) {
+      if (i > j) { X[i][j] = 0.0; continue; }
+      double a = i == j ? 1.0 : 0.0;
+      for (int q = i + 1; q <= j; ++q) a -= L[q][i] * X[q][j];
+      X[i][j] = a / L[i][i];
+    }
+  for (int i = 0; i < k; ++i)
+    for (int j = 0; j < k; ++j) Rinv[i * k + j] = (float)X[i][j];
+  if (bad) *bad = fail;
+}
+
 }  // namespace
 
 extern "C" size_t sdk_affinity_matvec_workspace_bytes(int N) {
@@ -320,6 +354,13 @@ extern "C" int sdk_kmeans_assign(sdk_ctx* ctx, const float* R, int n, int k, con
 extern "C" int sdk_kmeans_mindist(sdk_ctx* ctx, const float* R, int n, int k, const float* centre, float* d2, int first, void* stream) {
   SDK_REQUIRE(ctx && R && centre && d2 && n > 0 && k >= 1 && k <= KV, "sdk_kmeans_mindist: bad arguments");
   hipLaunchKernelGGL(kmeans_mindist_kernel, dim3(ceil_div(n, 256)), dim3(256), 0, (hipStream_t)stream, R, n, k, centre, d2, first);
+  SDK_LAUNCH_CHECK();
+  return 0;
+}
+
+extern "C" int sdk_chol_inverse(sdk_ctx* ctx, const float* G, int k, float* Rinv, int32_t* not_spd, void* stream) {
+  SDK_REQUIRE(ctx && G && Rinv && k >= 1 && k <= KV && G != Rinv, "sdk_chol_inverse: bad arguments (k=%d, in-place not allowed)", k);
+  hipLaunchKernelGGL(chol_inverse_kernel, dim3(1), dim3(64), 0, (hipStream_t)stream, G, k, Rinv, not_spd);
   SDK_LAUNCH_CHECK();
   return 0;
 }

@@ -334,6 +334,13 @@ class Engine:
         check(self.lib.sdk_rows_apply(self.ctx, X.data_ptr(), R.contiguous().data_ptr(), _ptr(scale), n, k, Y.data_ptr(), _stream()), "sdk_rows_apply")
         return Y
 
+    def chol_inverse(self, G):
+        """Rinv [k,k] with (G+G^T)/2 = L L^T, Rinv = (L^T)^-1 (float64 inside, stays on the stream)."""
+        k = G.shape[0]
+        Rinv = torch.empty((k, k), dtype=torch.float32, device=self.device)
+        check(self.lib.sdk_chol_inverse(self.ctx, G.contiguous().data_ptr(), k, Rinv.data_ptr(), None, _stream()), "sdk_chol_inverse")
+        return Rinv
+
     def rows_unit(self, X):
         n, k = X.shape
         Y = torch.empty_like(X)

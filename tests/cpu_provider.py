@@ -24,6 +24,11 @@ class CpuProvider:
             Z = Z * scale.double()[:, None]
         return Z.float()
 
+    def chol_inverse(self, G):
+        g = G.double().numpy()
+        L = np.linalg.cholesky(0.5 * (g + g.T) + 1e-30 * np.eye(g.shape[0]))
+        return torch.from_numpy(np.ascontiguousarray(np.linalg.inv(L.T)).astype(np.float32))
+
     def rows_unit(self, X):
         n = X.double().norm(dim=1, keepdim=True).clamp_min(1e-12)
         return (X.double() / n).float()

@@ -426,6 +426,23 @@ def test_thin_helpers(engine):
     assert np.array_equal(pc.cpu().numpy().sum(0), np.bincount(dist.argmin(1), minlength=5))
 
 
+@pytest.mark.parametrize("k", [1, 5, 16, 32])
+def test_chol_inverse_on_device(engine, k):
+    """CholeskyQR's k x k step without leaving the stream: Rinv = (L^T)^-1, (G + G^T)/2 = L L^T, float64 inside."""
+    g = torch.Generator().manual_seed(k)
+    Y = torch.randn(500, k, generator=g, dtype=torch.float64)
+    G = (Y.T @ Y).float()
+    G[0, k - 1] += 1e-3                                       # a slightly asymmetric input is symmetrised, as the host form did
+    Rinv = engine.chol_inverse(dev(G)).cpu().double()
+    Gs = 0.5 * (G.double() + G.double().T)
+    L = np.linalg.cholesky(Gs.numpy())
+    want = np.linalg.inv(L.T)
+    assert np.abs(Rinv.numpy() - want).max() <= 1e-6 * np.abs(want).max()
+    assert np.abs(np.tril(Rinv.numpy(), -1)).max() == 0.0    # upper triangular
+    Q = Y @ Rinv
+    assert float((Q.T @ Q - torch.eye(k, dtype=torch.float64)).abs().max()) < 1e-3
+
+
 @pytest.mark.parametrize("N,k", [(2000, 6), (5000, 16)])
 def test_spectral_cluster_matches_oracle(engine, N, k):
     """Config #5 scaled down: mixture-of-clusters embeddings, GPU pipeline vs the CPU oracle run on the
