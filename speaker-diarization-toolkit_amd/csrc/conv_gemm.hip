@@ -257,10 +257,50 @@ __global__ __launch_bounds__(NT2, 2) void conv_gemm256_kernel(Params p) {
   const int nk = p.taps * ksteps_per_tap;
   const int half = p.taps >> 1;
 
-  // Tile order: every XCD owns a contiguous run of tile ids (xcd_remap); inside the run, tiles are walked in
-  // groups of GM m-tiles with m fastest, so the ~32 workgroups an XCD runs at once form an 8 x 4 block of the
-  // output: 12 distinct operand slices per K-step instead of 16+.
-  auto tile_coords = [&](int vt, int& tm0, int& tn0) {
+  // Tile schedule.  A workgroup's XCD is blockIdx & 7 (the grid is a multiple of 8), its slot on the XCD l = blockIdx >> 3.
+  // UNIT ORDER (default when the grid is 256 workgroups and N is a multiple of 1024): the output is cut into UNITS of 8 m-tiles x 4
+  // n-tiles = exactly the 32 workgroups of one XCD, slot l -> (m = l & 7, n = l >> 3), so in every round an XCD's workgroups
+  // read 8 A row blocks (each shared by 4 of them) and 4 weight blocks (each shared by 8) - and nothing else: every A block is
+  // fetched into exactly ONE L2, once, provided its four readers stay within the few K-steps that L2 holds.  Units are dealt
+  // to the XCDs in contiguous runs (n-chunk fastest inside an m-group); whatever does not fill 8 XCDs evenly - the last
+  // (full_units mod 8) units and the partial m-group - is dealt out unit by unit in the final round(s), which therefore
+  // number exactly what the plain order needs.  (Round 1's order took an XCD's tile run in steps of 32 from a base that
+  // is not a multiple of 32, so the four readers of an A block were split over two rounds on 7 of the 8 XCDs.)
+  // LEGACY ORDER (tune bit 6 = `gemm_variant` 1026, kept for A/B): xcd_remap runs, groups of 8 m-tiles.
+  // Measured (tools/pmc_gemm.sh, bytes leaving L2 per launch): K = 1024 layers 1209 -> 1031 MB (reads 1.93x -> 1.50x of A + W; what
+  // is left is W re-fetched by every XCD in every round: 13 x 8 x 2 MB), the 3072^2 layer 9223 -> 6807 MB (A once per unit = 3x, W once per
+  // unit: (8 + 4) x 1.57 MB x 296 units - the floor for 32 tiles of 256^2 per 4-MiB L2).  A per-XCD round barrier on top (bounded
+  // spin on an XCD-local counter) changed neither the bytes nor the time: inside a unit the readers already stay together.
+  const int G = gridDim.x;
+  const bool unit_order = !(p.tune & 64) && G == 256 && (nbn & 3) == 0 && nbm >= 64;
+  const int xcd = blockIdx.x & 7, slot = blockIdx.x >> 3;
+  const int nch = nbn >> 2, mg_full = nbm >> 3;
+  const int full_units = mg_full * nch, R = full_units >> 3, rem_units = full_units - 8 * R;
+  const int gm_tail = nbm & 7, tail_tiles = gm_tail * nbn;
+  const int nrounds = unit_order ? R + (rem_units + (tail_tiles + 31) / 32 + 7) / 8 : (ntiles + G - 1) / G;
+  auto tile_coords = [&](int i, int& tm0, int& tn0) -> bool {
+    if (unit_order) {
+      int u;
+      if (i < R) {
+        u = xcd * R + i;
+      } else {
+        const int q = (i - R) * 8 + xcd;
+        if (q >= rem_units) {
+          const int pj = (q - rem_units) * 32 + slot;
+          if (pj >= tail_tiles) return false;
+          tm0 = (mg_full * 8 + pj % gm_tail) * BM2;
+          tn0 = (pj / gm_tail) * BN2;
+          return true;
+        }
+        u = 8 * R + q;
+      }
+      const int mg = u / nch, ch = u - mg * nch;
+      tm0 = (mg * 8 + (slot & 7)) * BM2;
+      tn0 = (ch * 4 + (slot >> 3)) * BN2;
+      return true;
+    }
+    const int vt = blockIdx.x + G * i;
+    if (vt >= ntiles) return false;
     const int tile = xcd_remap(vt, ntiles);
     constexpr int GM = 8;
     const int per_group = GM * nbn;
@@ -272,8 +312,8 @@ __global__ __launch_bounds__(NT2, 2) void conv_gemm256_kernel(Params p) {
     if (p.tune & 32) {
       // A/B knob: a workgroup walks ALL n-tiles of one m-tile back to back (its A row block is re-read from the Infinity Cache by
       // the same CU instead of by three other workgroups at unrelated times); the last, partial round of m-tiles is dealt out
-      // tile by tile so the tail stays one tile long.  vt = blockIdx + gridDim * i.
-      const int G = gridDim.x, b = vt % G, i = vt / G;
+      // tile by tile so the tail stays one tile long.
+      const int b = blockIdx.x;
       const int full_rounds = nbm / G;                  // m-rounds in which every workgroup owns an m-tile
       if (i < full_rounds * nbn) {
         tm0 = (b + G * (i / nbn)) * BM2;
@@ -284,6 +324,7 @@ __global__ __launch_bounds__(NT2, 2) void conv_gemm256_kernel(Params p) {
         tn0 = (j % nbn) * BN2;
       }
     }
+    return true;
   };
 
   // ---- DMA assignment: wave wid fills rows [32 wid, 32 wid + 32) of A and of B, 8 rows per instruction.
@@ -344,9 +385,9 @@ __global__ __launch_bounds__(NT2, 2) void conv_gemm256_kernel(Params p) {
   };
   // Persistent workgroups (one per CU; the grid is a multiple of 8 so a workgroup keeps its XCD class) walk
   // their tiles back to back.
-  for (int vt = blockIdx.x; vt < ntiles; vt += gridDim.x) {
+  for (int rnd = 0; rnd < nrounds; ++rnd) {
     int m0, n0;
-    tile_coords(vt, m0, n0);
+    if (!tile_coords(rnd, m0, n0)) continue;
     setup_dma(m0, n0);
     // the tile's 256 columns of epilogue parameters travel through LDS: the loads ride under the K loop
     float pb = 0.f, psc = 1.f, psh = 0.f;

@@ -503,6 +503,29 @@ def test_conv_gemm_overlapped_boundary_variant_is_bit_identical(engine, M, T, N,
         assert torch.equal(a[3], b[3])
 
 
+@pytest.mark.parametrize("M,T,N,Cin,mode", [(40200, 201, 1024, 128, 1), (40200, 201, 2048, 64, 0), (20100, 201, 1024, 64, 2), (66000, 200, 1024, 64, 0)])
+def test_conv_gemm_unit_order_covers_every_tile(engine, M, T, N, Cin, mode):
+    """The 256^2 kernel's tile schedule (default: 8 x 4-tile units per XCD round; 1026: round 1's order) must write every tile exactly
+    once: integer operands, so the output is exact and can be compared with a float32 matmul as well as between schedules (full
+    unit rounds, left-over units, a partial m-group, an edge tile)."""
+    g = torch.Generator().manual_seed(M + N)
+    A = dev(torch.randint(-2, 3, (M, Cin), generator=g).float(), torch.bfloat16)
+    Wt = dev(torch.randint(-1, 2, (N, Cin), generator=g).float(), torch.bfloat16)
+    want = (A.float() @ Wt.float().T).to(torch.bfloat16)
+    outs = {}
+    try:
+        for v in (2, 1026):
+            engine.lib.sdk_set_gemm_variant(v)
+            o = engine.conv_gemm(A, Wt, N, Cin, T=T, stats_mode=mode)
+            torch.cuda.synchronize()
+            assert torch.equal(o[0], want), f"variant {v}"
+            outs.setdefault(v, o)
+    finally:
+        engine.lib.sdk_set_gemm_variant(2)
+    if mode:
+        assert torch.equal(outs[2][3], outs[1026][3])
+
+
 def test_conv_gemm_a2_addend(engine):
     """A2: the GEMM consumes bf16(A + A2) (Res2Net running sum formed on the way into LDS)."""
     M, T, N, Cin = 603, 201, 128, 128
