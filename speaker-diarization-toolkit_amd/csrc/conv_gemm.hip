@@ -242,6 +242,7 @@ static_assert(BM2 * BN2 * 2 <= LDS2, "the bf16 image of a finished tile must fit
 typedef const void __attribute__((address_space(1)))* gptr_t;
 typedef void __attribute__((address_space(3)))* lptr_t;
 
+template <bool TAPS>
 __global__ __launch_bounds__(NT2, 2) void conv_gemm256_kernel(Params p) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
@@ -328,44 +329,52 @@ __global__ __launch_bounds__(NT2, 2) void conv_gemm256_kernel(Params p) {
   };
 
   // ---- DMA assignment: wave wid fills rows [32 wid, 32 wid + 32) of A and of B, 8 rows per instruction.
-  // Only the first of a lane's 4 rows is kept (rows step by 8); the others are rebuilt at issue time.
+  // Addresses are (uniform base pointer advanced per K-step on the scalar unit) + (32-bit per-lane byte offset fixed per
+  // tile): a 1 x 1 layer's K loop then carries NO vector arithmetic for its 8 DMA pieces (it had ~40 VALU + 8 readfirstlane
+  // per K-step; beside MFMAs that is clock, not cycles - MI355X_MICROARCH 'DVFS give-back' item 4).  The host routes operands
+  // whose byte offsets do not fit 32 bits to the 128^2 kernel.
   const int rin = lane >> 3, pos = lane & 7;
   const int gch = (pos ^ rin) * 8;                   // source chunk (elements) for this lane's LDS position
-  int arow0, aseg0, atl0, woff0;
+  const int wu = __builtin_amdgcn_readfirstlane(wid);
+  uint32_t aoff[4];                                  // !TAPS: byte offset of this lane's chunk in each of its 4 A rows (rows step by 8)
+  int aseg0 = 0, atl0 = 0;                           // TAPS: segment base row and in-segment frame of the first row
+  uint32_t woff;
   auto setup_dma = [&](int tm0, int tn0) {
-    const int row = 32 * wid + rin;
-    arow0 = tm0 + row;
-    const int mm = min(arow0, p.M - 1);
-    aseg0 = (mm / p.T) * p.T;
-    atl0 = mm - aseg0;                               // rows past M fetch some valid row; their results are dropped
-    woff0 = (tn0 + row) * Ktot + gch;
+    const int row = 32 * wu + rin;
+    if constexpr (TAPS) {
+      const int mm = min(tm0 + row, p.M - 1);
+      aseg0 = (mm / p.T) * p.T;
+      atl0 = mm - aseg0;                             // rows past M fetch some valid row; their results are dropped
+    } else {
+#pragma unroll
+      for (int i = 0; i < 4; ++i) aoff[i] = ((uint32_t)min(tm0 + row + 8 * i, p.M - 1) * (uint32_t)p.lda + (uint32_t)gch) * 2u;
+    }
+    woff = ((uint32_t)(tn0 + row) * (uint32_t)Ktot + (uint32_t)gch) * 2u;
   };
   auto issue = [&](int t, int stage) {
     const int j = t / ksteps_per_tap;
     const int kc = (t - j * ksteps_per_tap) * BK;
-    const int off = (j - half) * p.dil;
-    char* sA = smem + stage * STAGE2 + (32 * wid) * 128;
+    char* sA = smem + stage * STAGE2 + (32 * wu) * 128;
     char* sB = sA + BM2 * BK * 2;
-    const bf16_t* abase = p.A + kc + gch;
-    if (p.taps > 1) {
+    const char* abase = reinterpret_cast<const char*>(p.A + kc);
+    if constexpr (TAPS) {
+      const int off = (j - half) * p.dil;
 #pragma unroll
       for (int i = 0; i < 4; ++i) {
         int tl = atl0 + 8 * i, sb = aseg0;
         if (tl >= p.T) { tl -= p.T; sb += p.T; }      // T >= 64 > 24: at most one segment boundary inside the 4 rows
-        const int src = min(sb + reflect_idx(tl + off, p.T), p.M - 1);
-        __builtin_amdgcn_global_load_lds((gptr_t)(abase + (int64_t)src * p.lda), (lptr_t)(sA + i * 1024), 16, 0, 0);
+        const uint32_t src = (uint32_t)min(sb + reflect_idx(tl + off, p.T), p.M - 1);
+        __builtin_amdgcn_global_load_lds((gptr_t)(abase + (size_t)((src * (uint32_t)p.lda + (uint32_t)gch) * 2u)), (lptr_t)(sA + i * 1024), 16, 0, 0);
       }
     } else {
 #pragma unroll
-      for (int i = 0; i < 4; ++i) {
-        const int src = min(arow0 + 8 * i, p.M - 1);
-        __builtin_amdgcn_global_load_lds((gptr_t)(abase + (int64_t)src * p.lda), (lptr_t)(sA + i * 1024), 16, 0, 0);
-      }
+      for (int i = 0; i < 4; ++i)
+        __builtin_amdgcn_global_load_lds((gptr_t)(abase + (size_t)aoff[i]), (lptr_t)(sA + i * 1024), 16, 0, 0);
     }
-    const bf16_t* wbase = p.W + (woff0 + j * p.Cin + kc);
+    const char* wbase = reinterpret_cast<const char*>(p.W + (j * p.Cin + kc));
 #pragma unroll
     for (int i = 0; i < 4; ++i)
-      __builtin_amdgcn_global_load_lds((gptr_t)(wbase + i * 8 * Ktot), (lptr_t)(sB + i * 1024), 16, 0, 0);
+      __builtin_amdgcn_global_load_lds((gptr_t)(wbase + (size_t)i * 16 * Ktot + (size_t)woff), (lptr_t)(sB + i * 1024), 16, 0, 0);
   };
 
   const int fr = lane & 15, fq = lane >> 4, sw = lane & 7;
@@ -373,7 +382,6 @@ __global__ __launch_bounds__(NT2, 2) void conv_gemm256_kernel(Params p) {
   const uint32_t b_base = BM2 * BK * 2 + (wn * 64 + fr) * 128;
   const uint32_t c0 = ((0 * 4 + fq) ^ sw) << 4, c1 = ((1 * 4 + fq) ^ sw) << 4;
   const int pol = p.tune & 3;   // 0: waves 0-3 early / 4-7 late (default), 1: all early, 2: all late, 3: odd/even
-  const int wu = __builtin_amdgcn_readfirstlane(wid);
   const bool dma_early = pol == 1 ? true : pol == 2 ? false : pol == 3 ? (wu & 1) == 0 : wu < 4;
   const bool relu = p.flags & SDK_GEMM_RELU;
   const bool stats = p.stats_part != nullptr;
@@ -964,7 +972,8 @@ extern "C" int sdk_conv_gemm(sdk_ctx* ctx, const sdk_conv_gemm_args* a, void* st
     const char* e = getenv("SDK_GEMM_VARIANT");
     g_gemm_variant = e ? atoi(e) : 2;
   }
-  if (sdk_lds_optin(ctx, (const void*)conv_gemm256_kernel, LDS2_TOTAL)) return 1;
+  if (sdk_lds_optin(ctx, (const void*)conv_gemm256_kernel<false>, LDS2_TOTAL)) return 1;
+  if (sdk_lds_optin(ctx, (const void*)conv_gemm256_kernel<true>, LDS2_TOTAL)) return 1;
   if (sdk_lds_optin(ctx, (const void*)conv_gemm256_v3_kernel<false, false>, LDS3_TOTAL)) return 1;
   if (sdk_lds_optin(ctx, (const void*)conv_gemm256_v3_kernel<true, false>, LDS3_TOTAL)) return 1;
   if (sdk_lds_optin(ctx, (const void*)conv_gemm256_v3_kernel<false, true>, LDS3_TOTAL)) return 1;
@@ -985,7 +994,8 @@ extern "C" int sdk_conv_gemm(sdk_ctx* ctx, const sdk_conv_gemm_args* a, void* st
   // the 256^2 kernel covers the plain layer shape (bias / ReLU / BN affine -> bf16, optional column statistics);
   // fp32 output, residual sum, per-segment bias, tanh and the A2 addend stay with the 128^2 kernel
   const bool use256 = (g_gemm_variant & 15) != 1 && a->N % BN2 == 0 && a->M >= BM2 && !a->A2 && a->C && !a->C32 && !a->S &&
-                      !a->ubias && !(a->flags & SDK_GEMM_TANH) && (a->taps == 1 || a->T >= 64);
+                      !a->ubias && !(a->flags & SDK_GEMM_TANH) && (a->taps == 1 || a->T >= 64) &&
+                      (uint64_t)a->M * (uint64_t)a->lda * 2u < (1ull << 32);   // the 256^2 kernel addresses A by 32-bit byte offsets
   ProfScope ps(ctx, stream, use256 ? SDK_K_CONV_GEMM256 : SDK_K_CONV_GEMM, 2.0 * a->M * a->N * kk,
                2.0 * a->M * a->Cin + 2.0 * a->N * kk + (a->C ? 2.0 : 0.0) * a->M * a->N + (a->C32 ? 4.0 : 0.0) * a->M * a->N +
                    (a->S ? 4.0 : 0.0) * a->M * a->N);
@@ -1010,7 +1020,7 @@ extern "C" int sdk_conv_gemm(sdk_ctx* ctx, const sdk_conv_gemm_args* a, void* st
       hipLaunchKernelGGL(kern, dim3(grid), dim3(NT2), LDS3_TOTAL, (hipStream_t)stream, p);
     }
     else
-      hipLaunchKernelGGL(conv_gemm256_kernel, dim3(grid), dim3(NT2), LDS2_TOTAL, (hipStream_t)stream, p);
+      hipLaunchKernelGGL(p.taps > 1 ? conv_gemm256_kernel<true> : conv_gemm256_kernel<false>, dim3(grid), dim3(NT2), LDS2_TOTAL, (hipStream_t)stream, p);
   } else {
     hipLaunchKernelGGL(conv_gemm_kernel, dim3((a->N / BN) * ceil_div(a->M, BM)), dim3(NT), LDS_BYTES, (hipStream_t)stream, p);
   }

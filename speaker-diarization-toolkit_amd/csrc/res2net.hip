@@ -35,7 +35,7 @@ template <int MT>
 __global__ __launch_bounds__(RNT, 2) void res2net_chain_kernel(ChainParams p) {
   constexpr int TP = MT * 16;
   extern __shared__ __attribute__((aligned(16))) char smem[];
-  const int tid = threadIdx.x, lane = tid & 63, wn = tid >> 6;
+  const int tid = threadIdx.x, lane = tid & 63, wn = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int fr = lane & 15, fq = lane >> 4;
   const int T = p.T;
   const int64_t base = (int64_t)blockIdx.x * T;
@@ -49,16 +49,25 @@ __global__ __launch_bounds__(RNT, 2) void res2net_chain_kernel(ChainParams p) {
     const int cc = i / (3 * RS), w = (i / RS) % 3, ch = i % RS;
     par[i] = (w == 0 ? p.bias[cc] : w == 1 ? p.scale[cc] : p.shift[cc])[ch];
   }
+  // Tile passes (u in, y out): thread -> (row r0 + 32 i, 16-byte chunk c16), i < NPASS.  32 i leaves row & 15 alone, so ONE LDS
+  // offset, ONE u offset and ONE y offset per lane serve every pass (immediate / uniform strides), and `i < nrow` is "row < T".
+  const int r0 = tid >> 4, c16 = tid & 15;
+  const int nrow = (T - r0 + 31) >> 5;
+  const int loff = lds_off(r0, c16);
+  const uint32_t uoff = ((uint32_t)r0 * (uint32_t)p.ldu + (uint32_t)c16 * 8u) * 2u, ustride = 64u * (uint32_t)p.ldu;
+  const uint32_t ulast = ((uint32_t)(T - 1) * (uint32_t)p.ldu + (uint32_t)c16 * 8u) * 2u;
+  const uint32_t yoff = ((uint32_t)r0 * (uint32_t)p.ldr + (uint32_t)c16 * 8u) * 2u, ystride = 64u * (uint32_t)p.ldr;
   // ---- s_1 = u_1 -> buf 0
   {
     char* b0 = smem;
+    u32x4 v[NPASS];
+    const char* ub = reinterpret_cast<const char*>(p.U + base * p.ldu + RS);
 #pragma unroll
-    for (int i = 0; i < NPASS; ++i) {
-      const int id = tid + RNT * i, row = id >> 4, ch16 = id & 15;
-      u32x4 v = {0u, 0u, 0u, 0u};
-      if (row < T) v = *reinterpret_cast<const u32x4*>(p.U + (base + row) * p.ldu + RS + ch16 * 8);
-      if (row < TP) *reinterpret_cast<u32x4*>(b0 + lds_off(row, ch16)) = v;
-    }
+    for (int i = 0; i < NPASS; ++i)                          // all requests first (one HBM round trip, not NPASS); rows past T: row T - 1
+      v[i] = *reinterpret_cast<const u32x4*>(ub + (size_t)(i < nrow ? uoff + (uint32_t)i * ustride : ulast));
+#pragma unroll
+    for (int i = 0; i < NPASS; ++i)
+      if (r0 + 32 * i < TP) *reinterpret_cast<u32x4*>(b0 + loff + i * (32 * 256)) = i < nrow ? v[i] : u32x4{0u, 0u, 0u, 0u};
   }
 
   // 2 x 4 waves: wave (wm, wq) owns row tiles [wm*MH, wm*MH + MH) and the 32 output channels [32 wq, 32 wq + 32).
@@ -68,34 +77,40 @@ __global__ __launch_bounds__(RNT, 2) void res2net_chain_kernel(ChainParams p) {
   const int mt0 = wm * MH;
   const int64_t wofs0 = (int64_t)(wq * 32 + fr) * (3 * RS) + fq * 8;
   const int64_t wofs1 = wofs0 + (int64_t)16 * (3 * RS);
+  int ebase[2];                                              // epilogue write offsets of row tile mt0 (8 bytes = 4 channels per lane)
+#pragma unroll
+  for (int h = 0; h < 2; ++h) ebase[h] = lds_off(mt0 * 16 + fr, wq * 4 + h * 2 + (fq >> 1)) + (fq & 1) * 8;
   bf16x8 bcur[2][4];
 #pragma unroll
   for (int ks = 0; ks < 4; ++ks) {
     bcur[0][ks] = *reinterpret_cast<const bf16x8*>(p.W[0] + wofs0 + ks * 32);
     bcur[1][ks] = *reinterpret_cast<const bf16x8*>(p.W[0] + wofs1 + ks * 32);
   }
+  // (same pin as at the end of tap 2: with every load complete on BOTH ways into the conv loop, its first wait does not have to
+  // cover the previous conv's y stores)
+#pragma unroll
+  for (int ks = 0; ks < 4; ++ks) {
+    asm volatile("" : "+v"(bcur[0][ks]));
+    asm volatile("" : "+v"(bcur[1][ks]));
+  }
   for (int c = 1; c <= p.nconv; ++c) {
     const char* cur = smem + ((c - 1) & 1) * (TP * 256);
     char* nxt = smem + (c & 1) * (TP * 256);
     __syncthreads();                                        // s_c complete; the other image is free
-    // prefetch u_{c+1} (consumed after the conv)
-    u32x4 upre[NPASS];
-    if (c < p.nconv) {
-#pragma unroll
-      for (int i = 0; i < NPASS; ++i) {
-        const int id = tid + RNT * i, row = id >> 4, ch16 = id & 15;
-        upre[i] = u32x4{0u, 0u, 0u, 0u};
-        if (row < T) upre[i] = *reinterpret_cast<const u32x4*>(p.U + (base + row) * p.ldu + (int64_t)RS * (c + 1) + ch16 * 8);
-      }
-    }
+    u32x4 upre[NPASS];                                       // u_{c+1}, consumed after the conv; requested inside tap 2 (see there)
     // ---- conv c: [TP x 384] x [384 x 128]
     f32x4 acc[MH][2];
 #pragma unroll
     for (int mi = 0; mi < MH; ++mi) acc[mi][0] = acc[mi][1] = f32x4{0.f, 0.f, 0.f, 0.f};
     const bf16_t* Wc = p.W[c - 1];
     bf16x8 bnext[2][4];                                      // one tap (4 k-steps of 32) of weights ahead
-#pragma unroll 1
-    for (int j = 0; j < 3; ++j) {
+    // vmcnt retires in order, so a wait for weights also waits for every OLDER request.  The HBM fetch of u_{c+1}
+    // (microseconds) is therefore issued BEHIND the last weight prefetch of the conv (tap 2 fetches the next conv's tap 0):
+    // the wait for those weights can leave the u loads in flight (counted vmcnt), and u has all of tap 2, the epilogue and a
+    // barrier to arrive.  Issued at the top of the conv, as before, every conv stalled at the end of tap 0 until u had come
+    // back from HBM.  Taps 0 and 1 stay a rolled loop (unrolled, hipcc hoists every fragment read and spills 89 registers);
+    // tap 2 is its own copy so that the request order around the u prefetch is static.
+    auto tap = [&](const int j, const bool fetch_u) {
       const int off = (j - 1) * p.dil;
       // next tap of this conv, or tap 0 of the next conv (its latency hides under the epilogue and the y pass)
       const bf16_t* Wn = j < 2 ? Wc + (j + 1) * RS : (c < p.nconv ? p.W[c] : Wc);
@@ -104,22 +119,47 @@ __global__ __launch_bounds__(RNT, 2) void res2net_chain_kernel(ChainParams p) {
         bnext[0][ks] = *reinterpret_cast<const bf16x8*>(Wn + wofs0 + ks * 32);
         bnext[1][ks] = *reinterpret_cast<const bf16x8*>(Wn + wofs1 + ks * 32);
       }
+      if (fetch_u) {
+        __builtin_amdgcn_sched_barrier(0);                   // the u requests must stay BEHIND the weight requests
+        const char* ub = reinterpret_cast<const char*>(p.U + base * p.ldu + (int64_t)RS * min(c + 1, p.nconv));   // uniform
+#pragma unroll
+        for (int i = 0; i < NPASS; ++i)                      // unconditional (rows past T re-read row T - 1): the request count stays static
+          upre[i] = *reinterpret_cast<const u32x4*>(ub + (size_t)(i < nrow ? uoff + (uint32_t)i * ustride : ulast));
+      }
       int rr[MH];
 #pragma unroll
       for (int mi = 0; mi < MH; ++mi) rr[mi] = reflect_idx(min((mt0 + mi) * 16 + fr, TP - 1) + off, T);
+      // frame fragments travel RING steps (one step = one fragment = two MFMAs) ahead of their use through a small register
+      // ring; the scheduling fences keep hipcc from hoisting a whole tap's 28 reads to the top (which spills)
+      constexpr int RING = 5, NSTEP = 4 * MH;
+      bf16x8 af[RING];
+      auto rd = [&](int s) {
+        const int ks = s / MH, mi = s % MH;                  // (the second row half has MT - MH tiles: its last step recomputes the
+        af[s % RING] = *reinterpret_cast<const bf16x8*>(cur + rr[mi] * 256 + (((ks * 4 + fq) ^ (rr[mi] & 15)) << 4));   // clamped last row
+      };                                                     //  tile and drops it in the epilogue - the other half has MH real tiles anyway)
 #pragma unroll
-      for (int ks = 0; ks < 4; ++ks) {
+      for (int s = 0; s < RING - 1; ++s) rd(s);
 #pragma unroll
-        for (int mi = 0; mi < MH; ++mi) {
-          if (mt0 + mi < MT) {                               // wave-uniform: the second row half has MT - MH tiles
-            const bf16x8 a = *reinterpret_cast<const bf16x8*>(cur + rr[mi] * 256 + (((ks * 4 + fq) ^ (rr[mi] & 15)) << 4));
-            acc[mi][0] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(bcur[0][ks], a, acc[mi][0], 0, 0, 0);
-            acc[mi][1] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(bcur[1][ks], a, acc[mi][1], 0, 0, 0);
-          }
-        }
+      for (int s = 0; s < NSTEP; ++s) {
+        __builtin_amdgcn_sched_barrier(0);
+        if (s + RING - 1 < NSTEP) rd(s + RING - 1);
+        const int ks = s / MH, mi = s % MH;
+        acc[mi][0] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(bcur[0][ks], af[s % RING], acc[mi][0], 0, 0, 0);
+        acc[mi][1] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(bcur[1][ks], af[s % RING], acc[mi][1], 0, 0, 0);
       }
+      __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
       for (int ks = 0; ks < 4; ++ks) { bcur[0][ks] = bnext[0][ks]; bcur[1][ks] = bnext[1][ks]; }
+    };
+#pragma unroll 1
+    for (int j = 0; j < 2; ++j) tap(j, false);
+    tap(2, true);                                           // (the last conv re-reads its own chunk: one code copy less)
+    // Pin "the next conv's tap-0 weights have arrived" HERE (a counted wait that leaves the u loads in flight): otherwise the
+    // first wait of the next conv sits behind this conv's y stores and waits for their acknowledgement from HBM.
+#pragma unroll
+    for (int ks = 0; ks < 4; ++ks) {
+      asm volatile("" : "+v"(bcur[0][ks]));
+      asm volatile("" : "+v"(bcur[1][ks]));
     }
     // ---- epilogue: y_c = bf16(relu(acc + bias) * scale + shift) -> the free image, 8 bytes (4 channels) per write
     f32x4 cb[2], cs[2], ct[2];
@@ -143,20 +183,23 @@ __global__ __launch_bounds__(RNT, 2) void res2net_chain_kernel(ChainParams p) {
           uint2 pk;
           pk.x = pack2(v[0], v[1]);
           pk.y = pack2(v[2], v[3]);
-          const int ch16 = wq * 4 + h * 2 + (fq >> 1);
-          *reinterpret_cast<uint2*>(nxt + lds_off(row, ch16) + (fq & 1) * 8) = pk;
+          *reinterpret_cast<uint2*>(nxt + ebase[h] + mi * (16 * 256)) = pk;    // row & 15 == fr for every mi: one offset per h
         }
       }
     }
     __syncthreads();                                        // y_c complete in `nxt`; every read of `cur` is done
     // ---- y_c -> HBM; s_{c+1} = bf16(y_c + u_{c+1}) in place
+    char* rb = reinterpret_cast<char*>(p.R + base * p.ldr + (int64_t)RS * c);                                    // uniform
+    // every u request is waited for HERE, on every lane: a load left pending on some path would make the first wait of the next
+    // conv cover it - and, vmcnt being in-order, the y stores issued behind it (an HBM round trip per conv)
+#pragma unroll
+    for (int i = 0; i < NPASS; ++i) asm volatile("" : "+v"(upre[i]));
 #pragma unroll
     for (int i = 0; i < NPASS; ++i) {
-      const int id = tid + RNT * i, row = id >> 4, ch16 = id & 15;
-      if (row < T) {
-        char* q = nxt + lds_off(row, ch16);
+      if (i < nrow) {
+        char* q = nxt + loff + i * (32 * 256);
         const u32x4 y = *reinterpret_cast<const u32x4*>(q);
-        *reinterpret_cast<u32x4*>(p.R + (base + row) * p.ldr + (int64_t)RS * c + ch16 * 8) = y;
+        *reinterpret_cast<u32x4*>(rb + (size_t)(yoff + (uint32_t)i * ystride)) = y;
         if (c < p.nconv) {
           float fy[8], fu[8];
           unpack8(y, fy);
