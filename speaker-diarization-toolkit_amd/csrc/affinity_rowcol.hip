@@ -58,13 +58,14 @@ template <int WAVES, int SEGB, int TPS, int NSTAGE>
 __global__ __launch_bounds__(WAVES * 64, 2) void aff_rowcol_kernel(const bf16_t* __restrict__ Eb, const bf16_t* __restrict__ Pb,
                                                                int N, int P, Geom gm, float* __restrict__ stats,
                                                                int32_t* __restrict__ part_base, int32_t* __restrict__ part_cnt,
-                                                               int32_t* __restrict__ err, unsigned long long* __restrict__ dbg) {
+                                                               int32_t* __restrict__ flag_count, unsigned long long* __restrict__ dbg) {
   // diagnostic time stamps (100 MHz wall clock) of wave 0: [0] start, [1] count, then one per event; never set in production
   int nstamp = 2;
   auto stamp = [&]() {
     if (dbg && threadIdx.x == 0 && nstamp < 62) dbg[blockIdx.x * 64 + nstamp++] = __builtin_amdgcn_s_memrealtime();
   };
   if (dbg && threadIdx.x == 0) dbg[blockIdx.x * 64] = __builtin_amdgcn_s_memrealtime();
+  if (blockIdx.x == 0 && threadIdx.x == 0) *flag_count = 0;          // the exact pass (next launch) counts its uncertain rows here
   const unsigned long long clk0 = dbg ? __builtin_amdgcn_s_memtime() : 0;
   constexpr int STAGE_BYTES = TPS * TILE_BYTES;
   constexpr int DMA_PER_STAGE = STAGE_BYTES / 1024;
@@ -128,8 +129,8 @@ __global__ __launch_bounds__(WAVES * 64, 2) void aff_rowcol_kernel(const bf16_t*
     }
     ltile = 0;
     if (tid == 0) {
-      if (slot < MAXP) part_base[b * MAXP + slot] = s * TPS;
-      else atomicAdd(err, 1);
+      if (slot < MAXP) part_base[b * MAXP + slot] = s * TPS;    // (a 4th part cannot happen - plan_geometry, tests/test_cabi_cpu.py - and would
+                                                                //  not go unnoticed: part_cnt > MAXP sends the group's rows to the exact rescan)
     }
   };
   auto end_portion = [&](bool group_done) {
@@ -252,6 +253,8 @@ constexpr int INLINE_MAX_P = 0;        // rows the certificate cannot settle are
 
 // INLINE: the workgroup scans its own uncertain rows (typically none, ~0.1 % of rows) over all P right away - 32 lane groups
 // x P/32 profiles each - instead of queueing them for two more launches that cost ~12 us to settle ~100 rows at config #3.
+constexpr int RS_SLICE = 64, RS_ROWS = 4;   // the exact rescan's work item: RS_ROWS flagged rows x a slice of profiles (below)
+
 template <bool INLINE>
 __global__ __launch_bounds__(256) void aff_rowcol_rescore_kernel(const float* __restrict__ E, const float* __restrict__ Pm,
                                                                 const float* __restrict__ resid_e,
@@ -260,7 +263,8 @@ __global__ __launch_bounds__(256) void aff_rowcol_rescore_kernel(const float* __
                                                                 const int32_t* __restrict__ part_base,
                                                                 const int32_t* __restrict__ part_cnt,
                                                                 int32_t* __restrict__ idx, float* __restrict__ score,
-                                                                int32_t* __restrict__ flag_count, int32_t* __restrict__ flag_rows) {
+                                                                int32_t* __restrict__ flag_count, int32_t* __restrict__ flag_rows,
+                                                                int32_t* __restrict__ quad_done, unsigned long long* __restrict__ row_best) {
   const int tid = threadIdx.x, lane = tid & 63;
   const int j = tid & 7, hh = j >> 2, sl = j & 3;
   const int row = blockIdx.x * 32 + (tid >> 3);
@@ -277,8 +281,8 @@ __global__ __launch_bounds__(256) void aff_rowcol_rescore_kernel(const float* __
     C4[p] = *reinterpret_cast<const f32x4*>(src + 4);
     pb[p] = part_base[grp * MAXP + p];
   }
-  int np = part_cnt[grp];
-  np = np < MAXP ? np : MAXP;
+  const int np_raw = part_cnt[grp];
+  const int np = np_raw < MAXP ? np_raw : MAXP;
   const float re = resid_e[rc];
   float e24[24];
 #pragma unroll
@@ -395,7 +399,9 @@ __global__ __launch_bounds__(256) void aff_rowcol_rescore_kernel(const float* __
     // (b) intersections pruned by best - 3 eps: exact < best - 2 eps; (c) intersections pruned by s1 - eps: exact < s1
     // (the slack inside eps exceeds the tag truncation), and s1 <= the winner's score by construction.
     const float outside = fmaxf(u + eps, best - 2.0f * eps);
-    const bool uncertain = M > MAXC || !(bs > outside);
+    const bool uncertain = M > MAXC || !(bs > outside) || np_raw > MAXP;   // (np_raw > MAXP: a part's record was dropped - cannot happen)
+    row_best[row] = 0ull;                                            // the rescan's per-flagged-row keys (index < count <= N) ...
+    if ((row & (RS_ROWS - 1)) == 0) quad_done[row / RS_ROWS] = 0;   // arrival counters of the rescan's row quads (index < count / RS_ROWS <= N / RS_ROWS)
     if (uncertain) {
       if constexpr (INLINE) flist_s[atomicAdd(&fcount_s, 1)] = row;
       else flag_rows[atomicAdd(flag_count, 1)] = row;
@@ -453,7 +459,6 @@ __global__ __launch_bounds__(256) void aff_rowcol_rescore_kernel(const float* __
 // held in registers (the old form streamed all of P once PER flagged row: 768 MB of L2 traffic at config #3), and an item
 // is ONE round of loads (2 profile rows + 4 segment rows per lane group, all requested before the first use): with ~100
 // flagged rows the kernel is a chain of memory round trips, so the chain is kept short and the items many.
-constexpr int RS_SLICE = 64, RS_ROWS = 4;
 
 constexpr int RS_GRID = 2048;
 // slices per row quad: enough items to fill the grid once, never shorter than RS_SLICE profiles (same split in both kernels)
@@ -474,13 +479,21 @@ __device__ __forceinline__ void group_best32(float& s, int& i) {     // best ove
   }
 }
 
+// (score, index) as one 64-bit key whose unsigned order is better(): higher score first, then the LOWER index
+__device__ __forceinline__ unsigned long long best_key(float s, int i) {
+  const uint32_t b = __float_as_uint(s);
+  const uint32_t o = (b & 0x80000000u) ? ~b : b | 0x80000000u;       // monotone map of the float order onto unsigned order
+  return ((unsigned long long)o << 32) | (unsigned long long)(0xffffffffu - (uint32_t)i);
+}
+
 __global__ __launch_bounds__(256) void aff_rescan4_kernel(const float* __restrict__ E, const float* __restrict__ Pm, int P,
                                                          const int32_t* __restrict__ flag_count,
-                                                         const int32_t* __restrict__ flag_rows, float* __restrict__ part_s,
-                                                         int32_t* __restrict__ part_i, int32_t* __restrict__ idx,
-                                                         float* __restrict__ score) {
+                                                         const int32_t* __restrict__ flag_rows, unsigned long long* __restrict__ row_best,
+                                                         int32_t* __restrict__ quad_done,
+                                                         int32_t* __restrict__ idx, float* __restrict__ score) {
   __shared__ float ls[RS_ROWS][32];
   __shared__ int li[RS_ROWS][32];
+  __shared__ int last_s;
   const int tid = threadIdx.x, j = tid & 7, g = tid >> 3;
   const int count = *flag_count;
   const int nq = (count + RS_ROWS - 1) / RS_ROWS;
@@ -530,59 +543,51 @@ __global__ __launch_bounds__(256) void aff_rescan4_kernel(const float* __restric
       const int f = q * RS_ROWS + x;
       if (l == 0 && f < count) {
         if (nsl == 1) { const int row = flag_rows[f]; idx[row] = i; score[row] = s; }
-        else { part_s[(int64_t)f * nsl + sl] = s; part_i[(int64_t)f * nsl + sl] = i; }
+        else __hip_atomic_fetch_max(row_best + f, best_key(s, i), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
       }
     }
-    __syncthreads();
-  }
-}
-
-__global__ __launch_bounds__(64) void aff_rescan4_merge_kernel(int P, const int32_t* __restrict__ flag_count,
-                                                              const int32_t* __restrict__ flag_rows,
-                                                              const float* __restrict__ part_s, const int32_t* __restrict__ part_i,
-                                                              int32_t* __restrict__ idx, float* __restrict__ score) {
-  const int count = *flag_count, lane = threadIdx.x;
-  int nsl, slen;
-  rescan_split(P, (count + RS_ROWS - 1) / RS_ROWS, nsl, slen);
-  if (nsl == 1) return;
-  for (int f = blockIdx.x; f < count; f += gridDim.x) {
-    float s = -INFINITY;
-    int i = 0x7fffffff;
-    for (int e = lane; e < nsl; e += 64) {
-      const float ts = part_s[(int64_t)f * nsl + e];
-      const int ti = part_i[(int64_t)f * nsl + e];
-      if (better(ts, ti, s, i)) { s = ts; i = ti; }
+    if (nsl > 1) {
+      // The quad's slices meet here instead of in a second launch, through agent-scope ATOMICS only (they are performed at the
+      // device's coherence point, so no cache write-back or invalidate is involved: a release/acquire fence pair per item made
+      // this kernel 2-3x slower): every slice folds its four winners into the rows' 64-bit (score, index) keys with
+      // atomic max, waits for those to be performed (s_waitcnt vmcnt(0)), then counts itself in; whoever
+      // counts in last reads the four keys back with atomic loads and writes the answers.
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");                // (a workgroup-scope fence compiles to no vmcnt wait at all)
+      __syncthreads();
+      if (tid == 0) last_s = __hip_atomic_fetch_add(quad_done + q, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == nsl - 1;
+      __syncthreads();
+      if (last_s && tid < RS_ROWS && q * RS_ROWS + tid < count) {
+        const int f = q * RS_ROWS + tid;
+        const unsigned long long key = __hip_atomic_load(row_best + f, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        const int row = flag_rows[f];
+        idx[row] = (int)(0xffffffffu - (uint32_t)key);
+        const uint32_t o = (uint32_t)(key >> 32);
+        score[row] = __uint_as_float((o & 0x80000000u) ? o & 0x7fffffffu : ~o);
+      }
     }
-#pragma unroll
-    for (int o = 32; o > 0; o >>= 1) {
-      const float ts = __shfl_xor(s, o, 64);
-      const int ti = __shfl_xor(i, o, 64);
-      if (better(ts, ti, s, i)) { s = ts; i = ti; }
-    }
-    if (lane == 0) { const int row = flag_rows[f]; idx[row] = i; score[row] = s; }
+    __syncthreads();                                                // ls / li / last_s are rewritten by the next item
   }
 }
 
 __global__ void copy_count_kernel(const int32_t* src, int32_t* dst) { *dst = *src; }
 
 struct Ws {
-  float* stats; int32_t* part_base; int32_t* part_cnt; int32_t* flag_count; int32_t* flag_rows; float* part_s; int32_t* part_i;
+  float* stats; int32_t* part_base; int32_t* part_cnt; int32_t* flag_count; int32_t* flag_rows; unsigned long long* row_best; int32_t* quad_done;
 };
 inline size_t al256(size_t v) { return (v + 255) & ~(size_t)255; }
 size_t ws_layout(int N, int P, char* base, Ws* w) {
   size_t off = 0;
   auto take = [&](size_t bytes) { char* p = base ? base + off : nullptr; off += al256(bytes); return p; };
   const size_t ngroups_max = (size_t)(N + 255) / 256;          // the smallest group any variant uses
-  const size_t nsl = (size_t)(P + RS_SLICE - 1) / RS_SLICE;
   char* a = take((size_t)N * MAXP * 2 * 8 * 4);
   char* b = take(ngroups_max * MAXP * 4);
   char* c = take(ngroups_max * 4);
-  char* d = take(256);                                          // flag_count, err
+  char* d = take(256);                                          // flag_count
   char* e = take((size_t)N * 4);
-  char* f1 = take(nsl > 1 ? (size_t)N * nsl * 4 : 16);
-  char* f2 = take(nsl > 1 ? (size_t)N * nsl * 4 : 16);
+  char* f1 = take((size_t)N * 8);                                // per flagged row: 64-bit (score, index) key the rescan's slices fold into
+  char* g = take(((size_t)N / RS_ROWS + 1) * 4);
   if (w) { w->stats = (float*)a; w->part_base = (int32_t*)b; w->part_cnt = (int32_t*)c; w->flag_count = (int32_t*)d;
-           w->flag_rows = (int32_t*)e; w->part_s = (float*)f1; w->part_i = (int32_t*)f2; }
+           w->flag_rows = (int32_t*)e; w->row_best = (unsigned long long*)f1; w->quad_done = (int32_t*)g; }
   return off;
 }
 
@@ -610,7 +615,7 @@ Geom plan_geometry(int N, int P, int segs, int tps, long long max_wg, int whole_
 }
 
 template <int WAVES, int SEGB, int TPS, int NSTAGE>
-int launch_coarse(sdk_ctx* ctx, const bf16_t* Eb, const bf16_t* Pb, int N, int P, const Ws& w, int32_t* err, hipStream_t s, int wg_per_cu,
+int launch_coarse(sdk_ctx* ctx, const bf16_t* Eb, const bf16_t* Pb, int N, int P, const Ws& w, hipStream_t s, int wg_per_cu,
                   int* segs) {
   constexpr int SEGS = WAVES * SEGB * 32;
   constexpr int LDS = NSTAGE * TPS * TILE_BYTES;
@@ -618,7 +623,7 @@ int launch_coarse(sdk_ctx* ctx, const bf16_t* Eb, const bf16_t* Pb, int N, int P
   const Geom gm = plan_geometry(N, P, SEGS, TPS, (long long)ctx->num_cu * wg_per_cu, ctx->aff_whole_groups);
   auto kern = aff_rowcol_kernel<WAVES, SEGB, TPS, NSTAGE>;
   if (sdk_lds_optin(ctx, (const void*)kern, LDS)) return 1;
-  hipLaunchKernelGGL(kern, dim3(gm.G), dim3(WAVES * 64), LDS, s, Eb, Pb, N, P, gm, w.stats, w.part_base, w.part_cnt, err,
+  hipLaunchKernelGGL(kern, dim3(gm.G), dim3(WAVES * 64), LDS, s, Eb, Pb, N, P, gm, w.stats, w.part_base, w.part_cnt, w.flag_count,
                      (unsigned long long*)ctx->dbg_ptr);
   return 0;
 }
@@ -645,16 +650,15 @@ int aff_rowcol_top1(sdk_ctx* ctx, const float* E, const uint16_t* Eb, const floa
   hipStream_t s = (hipStream_t)stream;
   Ws w;
   ws_layout(N, Pn, (char*)ws, &w);
-  SDK_HIP_OK(hipMemsetAsync(w.flag_count, 0, 2 * sizeof(int32_t), s));
-  int32_t* err = w.flag_count + 1;
+  // no memset: the coarse kernel zeroes the uncertain-row counter, the exact pass zeroes the rescan's arrival counters
   int segs;
   {
     ProfScope ps(ctx, stream, SDK_K_AFF_COARSE, 2.0 * N * (double)Pn * D, 2.0 * ((double)N + Pn) * D + 64.0 * N);
     int rc;
     switch (ctx->aff_variant) {
-      case 1: rc = launch_coarse<8, 2, 4, 3>(ctx, (const bf16_t*)Eb, (const bf16_t*)Pb, N, Pn, w, err, s, 1, &segs); break;
-      case 2: rc = launch_coarse<4, 2, 2, 3>(ctx, (const bf16_t*)Eb, (const bf16_t*)Pb, N, Pn, w, err, s, 2, &segs); break;
-      default: rc = launch_coarse<8, 2, 2, 4>(ctx, (const bf16_t*)Eb, (const bf16_t*)Pb, N, Pn, w, err, s, 1, &segs); break;
+      case 1: rc = launch_coarse<8, 2, 4, 3>(ctx, (const bf16_t*)Eb, (const bf16_t*)Pb, N, Pn, w, s, 1, &segs); break;
+      case 2: rc = launch_coarse<4, 2, 2, 3>(ctx, (const bf16_t*)Eb, (const bf16_t*)Pb, N, Pn, w, s, 2, &segs); break;
+      default: rc = launch_coarse<8, 2, 2, 4>(ctx, (const bf16_t*)Eb, (const bf16_t*)Pb, N, Pn, w, s, 1, &segs); break;
     }
     if (rc) return rc;
   }
@@ -663,19 +667,16 @@ int aff_rowcol_top1(sdk_ctx* ctx, const float* E, const uint16_t* Eb, const floa
     ProfScope ps(ctx, stream, SDK_K_AFF_RESCORE, 0.0, 4.0 * N * D + 64.0 * N + 8.0 * N);
     if (Pn <= INLINE_MAX_P)
       hipLaunchKernelGGL(aff_rowcol_rescore_kernel<true>, dim3(ceil_div(N, 32)), dim3(256), 0, s, E, P, resid_e, resid_p, N, Pn, segs,
-                         w.stats, w.part_base, w.part_cnt, idx, score, w.flag_count, w.flag_rows);
+                         w.stats, w.part_base, w.part_cnt, idx, score, w.flag_count, w.flag_rows, w.quad_done, w.row_best);
     else
       hipLaunchKernelGGL(aff_rowcol_rescore_kernel<false>, dim3(ceil_div(N, 32)), dim3(256), 0, s, E, P, resid_e, resid_p, N, Pn, segs,
-                         w.stats, w.part_base, w.part_cnt, idx, score, w.flag_count, w.flag_rows);
+                         w.stats, w.part_base, w.part_cnt, idx, score, w.flag_count, w.flag_rows, w.quad_done, w.row_best);
   }
   SDK_LAUNCH_CHECK();
   if (Pn > INLINE_MAX_P) {
     ProfScope ps(ctx, stream, SDK_K_AFF_RESCAN, 0.0, 0.0);
-    hipLaunchKernelGGL(aff_rescan4_kernel, dim3(RS_GRID), dim3(256), 0, s, E, P, Pn, w.flag_count, w.flag_rows, w.part_s, w.part_i,
-                       idx, score);
-    if (Pn > RS_SLICE)
-      hipLaunchKernelGGL(aff_rescan4_merge_kernel, dim3(256), dim3(64), 0, s, Pn, w.flag_count, w.flag_rows, w.part_s, w.part_i,
-                         idx, score);
+    hipLaunchKernelGGL(aff_rescan4_kernel, dim3(RS_GRID), dim3(256), 0, s, E, P, Pn, w.flag_count, w.flag_rows, w.row_best,
+                       w.quad_done, idx, score);
   }
   SDK_LAUNCH_CHECK();
   if (n_rescanned) {

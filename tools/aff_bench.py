@@ -31,6 +31,12 @@ for N3, P3 in shapes:
             same_i = bool(torch.equal(idx, ref[0])); same_s = bool(torch.equal(sc, ref[1]))
             nd = int((idx != ref[0]).sum())
             print(f"{N3}x{P3} {name}: idx identical {same_i} ({nd} differ), scores bit-identical {same_s}, rescanned {int(cnt.item())}", flush=True)
+    eng.set_option("affinity_fast_path", 1); eng.set_option("affinity_variant", 0); eng.set_option("affinity_whole_groups", 0)
+    nbad = 0
+    for rep in range(30):                                  # the rescan's slices meet through atomics: the answer must not depend on who is last
+        idx, sc = eng.affinity_topk(E3, E3b, r3, Q3, Q3b, q3m, k=1)[:2]
+        nbad += int((idx != ref[0]).sum()) + int((sc != ref[1]).sum())
+    print(f"{N3}x{P3} rowcol, 30 repeats: {nbad} entries differ from the first answer", flush=True)
     res = {n: [] for n, _, _, _ in VARIANTS}
     for rnd in range(5):
         for name, fast, var, wg in VARIANTS:
