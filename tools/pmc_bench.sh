@@ -14,7 +14,7 @@ for c in ("FETCH_SIZE", "WRITE_SIZE"):
     for r in rows:
         if r["Counter_Name"] != c: continue
         name = r["Kernel_Name"].split("(")[1].split("::")[-1] if "anonymous" in r["Kernel_Name"] else r["Kernel_Name"].split("(")[0]
-        name = r["Kernel_Name"].replace("(anonymous namespace)::", "").split("(")[0].split("<")[0]
+        name = r["Kernel_Name"].replace("(anonymous namespace)::", "").split("(")[0].split("<")[0].split()[-1]   # template kernels carry a return type
         per_kernel[name].append(float(r["Counter_Value"]))
     for k, v in per_kernel.items():
         n = len(v) // 2          # SDK_BENCH_PMC=1: bench ran exactly 1 warm-up + 1 timed pass of the hot path
