@@ -34,4 +34,10 @@
 #define EL_FC_WT 13                                 /* fp32 [2Cm][E]   */
 #define EL_FC_B 14
 
+/* OPTIONAL (-1 = absent): the Res2Net chain's 128x128 k3 conv weights once more, in MFMA fragment order, so that a wave's
+ * fragment load is 1 KiB contiguous instead of 16 row pieces of 64 B:
+ *   [tap 3][channel block wq 4][column tile h 2][k-step ks 4][lane 64][8] bf16,
+ *   lane l holds W[out = 32 wq + 16 h + (l & 15)][k = 128 tap + 32 ks + 8 (l >> 4) + 0..7]   (tap-major K as in the W slot) */
+#define EL_CHAINPACK(i, j) (160 + ((i) - 1) * 8 + (j))   /* block i = 1..n_blocks (<= 4), conv j = 0..6 */
+
 #endif

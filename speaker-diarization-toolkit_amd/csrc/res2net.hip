@@ -27,11 +27,13 @@ struct ChainParams {
   const bf16_t* U; int64_t ldu;          // [M, scale*128] tdnn1 output
   bf16_t* R; int64_t ldr;                // [M, scale*128] chain output (chunk 0 is copied by the caller)
   const bf16_t* W[7];                    // [128][3*128] bf16 each
+  const bf16_t* Wpk[7];                  // the same weights in fragment order (ecapa_layout.h EL_CHAINPACK), used when PACKED
   const float* bias[7]; const float* scale[7]; const float* shift[7];
   int T, dil, nconv;
+  unsigned long long* dbg;               // diagnostics only: [workgroup][64] 100 MHz time stamps of wave 0 (tools/res2net_timeline.py), or null
 };
 
-template <int MT>
+template <int MT, bool PACKED>
 __global__ __launch_bounds__(RNT, 2) void res2net_chain_kernel(ChainParams p) {
   constexpr int TP = MT * 16;
   extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -41,30 +43,50 @@ __global__ __launch_bounds__(RNT, 2) void res2net_chain_kernel(ChainParams p) {
   const int64_t base = (int64_t)blockIdx.x * T;
   constexpr int NPASS = (TP * 16 + RNT - 1) / RNT;   // 16-byte chunks per thread per tile pass
 
+  int nstamp = 2;
+  auto stamp = [&]() {
+    if (p.dbg && tid == 0 && blockIdx.x < 256 && nstamp < 64) p.dbg[blockIdx.x * 64 + nstamp++] = __builtin_amdgcn_s_memrealtime();
+  };
+  if (p.dbg && tid == 0 && blockIdx.x < 256) p.dbg[blockIdx.x * 64] = __builtin_amdgcn_s_memrealtime();
   auto lds_off = [](int row, int ch16) { return row * 256 + ((ch16 ^ (row & 15)) << 4); };
 
-  // bias / scale / shift of the (up to) seven convs: [7][3][128] fp32 behind the two images
+  // bias / scale / shift of the (up to) seven convs: [7][3][128] fp32 behind the two images.  Wave w fetches conv w's three
+  // arrays (uniform pointers, 2 floats per lane): three loads per lane in flight together - one round trip, where the
+  // element-by-element form (pointer picked per element) took five dependent ones (the prologue was 8 us of a 70-us workgroup)
   float* par = reinterpret_cast<float*>(smem + 2 * TP * 256);
-  for (int i = tid; i < p.nconv * 3 * RS; i += RNT) {
-    const int cc = i / (3 * RS), w = (i / RS) % 3, ch = i % RS;
-    par[i] = (w == 0 ? p.bias[cc] : w == 1 ? p.scale[cc] : p.shift[cc])[ch];
+  float2 pv[3] = {};
+  if (wn < p.nconv) {
+    pv[0] = reinterpret_cast<const float2*>(p.bias[wn])[lane];
+    pv[1] = reinterpret_cast<const float2*>(p.scale[wn])[lane];
+    pv[2] = reinterpret_cast<const float2*>(p.shift[wn])[lane];
   }
   // Tile passes (u in, y out): thread -> (row r0 + 32 i, 16-byte chunk c16), i < NPASS.  32 i leaves row & 15 alone, so ONE LDS
   // offset, ONE u offset and ONE y offset per lane serve every pass (immediate / uniform strides), and `i < nrow` is "row < T".
   const int r0 = tid >> 4, c16 = tid & 15;
   const int nrow = (T - r0 + 31) >> 5;
   const int loff = lds_off(r0, c16);
+  // u and y move through BUFFER instructions: (uniform resource = this segment's rows) + (ONE 32-bit per-lane offset) + (scalar
+  // offset = pass stride x i + chunk) - flat addressing kept a zero-extended 64-bit register pair per pass alive across the conv
+  // loop (14 + 14 registers, and a spill reload in front of the y stores).
   const uint32_t uoff = ((uint32_t)r0 * (uint32_t)p.ldu + (uint32_t)c16 * 8u) * 2u, ustride = 64u * (uint32_t)p.ldu;
   const uint32_t ulast = ((uint32_t)(T - 1) * (uint32_t)p.ldu + (uint32_t)c16 * 8u) * 2u;
   const uint32_t yoff = ((uint32_t)r0 * (uint32_t)p.ldr + (uint32_t)c16 * 8u) * 2u, ystride = 64u * (uint32_t)p.ldr;
+  const __amdgpu_buffer_rsrc_t urs = __builtin_amdgcn_make_buffer_rsrc(const_cast<bf16_t*>(p.U + base * p.ldu), 0, (int)((uint32_t)T * (uint32_t)p.ldu * 2u), 0x00020000);
+  const __amdgpu_buffer_rsrc_t yrs = __builtin_amdgcn_make_buffer_rsrc(p.R + base * p.ldr, 0, (int)((uint32_t)T * (uint32_t)p.ldr * 2u), 0x00020000);
+  // pass i of chunk ch: rows past T re-read row T - 1 (the request count stays static; the value is never used)
+  auto uload = [&](int i, int ch) -> u32x4 {
+    return __builtin_amdgcn_raw_buffer_load_b128(urs, i < nrow ? uoff : ulast - (uint32_t)i * ustride, (uint32_t)i * ustride + (uint32_t)(ch * RS * 2), 0);
+  };
   // ---- s_1 = u_1 -> buf 0
   {
     char* b0 = smem;
     u32x4 v[NPASS];
-    const char* ub = reinterpret_cast<const char*>(p.U + base * p.ldu + RS);
 #pragma unroll
-    for (int i = 0; i < NPASS; ++i)                          // all requests first (one HBM round trip, not NPASS); rows past T: row T - 1
-      v[i] = *reinterpret_cast<const u32x4*>(ub + (size_t)(i < nrow ? uoff + (uint32_t)i * ustride : ulast));
+    for (int i = 0; i < NPASS; ++i) v[i] = uload(i, 1);      // all requests first (one HBM round trip, not NPASS)
+    if (wn < p.nconv) {                                      // (the parameter loads are older than the u loads: a counted wait)
+#pragma unroll
+      for (int q = 0; q < 3; ++q) reinterpret_cast<float2*>(par + wn * (3 * RS) + q * RS)[lane] = pv[q];
+    }
 #pragma unroll
     for (int i = 0; i < NPASS; ++i)
       if (r0 + 32 * i < TP) *reinterpret_cast<u32x4*>(b0 + loff + i * (32 * 256)) = i < nrow ? v[i] : u32x4{0u, 0u, 0u, 0u};
@@ -80,11 +102,20 @@ __global__ __launch_bounds__(RNT, 2) void res2net_chain_kernel(ChainParams p) {
   int ebase[2];                                              // epilogue write offsets of row tile mt0 (8 bytes = 4 channels per lane)
 #pragma unroll
   for (int h = 0; h < 2; ++h) ebase[h] = lds_off(mt0 * 16 + fr, wq * 4 + h * 2 + (fq >> 1)) + (fq & 1) * 8;
+  // weight fragment (conv cc, tap, column tile h, k-step ks) of this lane: 16 bytes.  PACKED: the host's fragment-ordered copy -
+  // a wave's load is 1 KiB contiguous (8 cache lines); otherwise 16 row pieces of 64 B of the [128][384] matrix (16 lines
+  // half used: with every workgroup fetching 64 KiB per tap that is what the L2 was busy with - tap waits of ~1 us)
+  auto wfrag = [&](int cc, int tap, int h, int ks) -> bf16x8 {
+    if constexpr (PACKED)
+      return *reinterpret_cast<const bf16x8*>(p.Wpk[cc] + ((((tap * 4 + wq) * 2 + h) * 4 + ks) * 64 + lane) * 8);
+    else
+      return *reinterpret_cast<const bf16x8*>(p.W[cc] + tap * RS + (h ? wofs1 : wofs0) + ks * 32);
+  };
   bf16x8 bcur[2][4];
 #pragma unroll
   for (int ks = 0; ks < 4; ++ks) {
-    bcur[0][ks] = *reinterpret_cast<const bf16x8*>(p.W[0] + wofs0 + ks * 32);
-    bcur[1][ks] = *reinterpret_cast<const bf16x8*>(p.W[0] + wofs1 + ks * 32);
+    bcur[0][ks] = wfrag(0, 0, 0, ks);
+    bcur[1][ks] = wfrag(0, 0, 1, ks);
   }
   // (same pin as at the end of tap 2: with every load complete on BOTH ways into the conv loop, its first wait does not have to
   // cover the previous conv's y stores)
@@ -97,12 +128,12 @@ __global__ __launch_bounds__(RNT, 2) void res2net_chain_kernel(ChainParams p) {
     const char* cur = smem + ((c - 1) & 1) * (TP * 256);
     char* nxt = smem + (c & 1) * (TP * 256);
     __syncthreads();                                        // s_c complete; the other image is free
+    stamp();
     u32x4 upre[NPASS];                                       // u_{c+1}, consumed after the conv; requested inside tap 2 (see there)
     // ---- conv c: [TP x 384] x [384 x 128]
     f32x4 acc[MH][2];
 #pragma unroll
     for (int mi = 0; mi < MH; ++mi) acc[mi][0] = acc[mi][1] = f32x4{0.f, 0.f, 0.f, 0.f};
-    const bf16_t* Wc = p.W[c - 1];
     bf16x8 bnext[2][4];                                      // one tap (4 k-steps of 32) of weights ahead
     // vmcnt retires in order, so a wait for weights also waits for every OLDER request.  The HBM fetch of u_{c+1}
     // (microseconds) is therefore issued BEHIND the last weight prefetch of the conv (tap 2 fetches the next conv's tap 0):
@@ -112,19 +143,18 @@ __global__ __launch_bounds__(RNT, 2) void res2net_chain_kernel(ChainParams p) {
     // tap 2 is its own copy so that the request order around the u prefetch is static.
     auto tap = [&](const int j, const bool fetch_u) {
       const int off = (j - 1) * p.dil;
-      // next tap of this conv, or tap 0 of the next conv (its latency hides under the epilogue and the y pass)
-      const bf16_t* Wn = j < 2 ? Wc + (j + 1) * RS : (c < p.nconv ? p.W[c] : Wc);
+      // next tap of this conv, or tap 0 of the next conv (its latency hides under the epilogue and the y pass; the last conv
+      // re-reads its own tap 0)
+      const int ncc = j < 2 ? c - 1 : min(c, p.nconv - 1), ntap = j < 2 ? j + 1 : 0;
 #pragma unroll
       for (int ks = 0; ks < 4; ++ks) {
-        bnext[0][ks] = *reinterpret_cast<const bf16x8*>(Wn + wofs0 + ks * 32);
-        bnext[1][ks] = *reinterpret_cast<const bf16x8*>(Wn + wofs1 + ks * 32);
+        bnext[0][ks] = wfrag(ncc, ntap, 0, ks);
+        bnext[1][ks] = wfrag(ncc, ntap, 1, ks);
       }
       if (fetch_u) {
         __builtin_amdgcn_sched_barrier(0);                   // the u requests must stay BEHIND the weight requests
-        const char* ub = reinterpret_cast<const char*>(p.U + base * p.ldu + (int64_t)RS * min(c + 1, p.nconv));   // uniform
 #pragma unroll
-        for (int i = 0; i < NPASS; ++i)                      // unconditional (rows past T re-read row T - 1): the request count stays static
-          upre[i] = *reinterpret_cast<const u32x4*>(ub + (size_t)(i < nrow ? uoff + (uint32_t)i * ustride : ulast));
+        for (int i = 0; i < NPASS; ++i) upre[i] = uload(i, min(c + 1, p.nconv));   // unconditional: the request count stays static
       }
       int rr[MH];
 #pragma unroll
@@ -152,7 +182,7 @@ __global__ __launch_bounds__(RNT, 2) void res2net_chain_kernel(ChainParams p) {
       for (int ks = 0; ks < 4; ++ks) { bcur[0][ks] = bnext[0][ks]; bcur[1][ks] = bnext[1][ks]; }
     };
 #pragma unroll 1
-    for (int j = 0; j < 2; ++j) tap(j, false);
+    for (int j = 0; j < 2; ++j) { tap(j, false); stamp(); }
     tap(2, true);                                           // (the last conv re-reads its own chunk: one code copy less)
     // Pin "the next conv's tap-0 weights have arrived" HERE (a counted wait that leaves the u loads in flight): otherwise the
     // first wait of the next conv sits behind this conv's y stores and waits for their acknowledgement from HBM.
@@ -161,6 +191,7 @@ __global__ __launch_bounds__(RNT, 2) void res2net_chain_kernel(ChainParams p) {
       asm volatile("" : "+v"(bcur[0][ks]));
       asm volatile("" : "+v"(bcur[1][ks]));
     }
+    stamp();
     // ---- epilogue: y_c = bf16(relu(acc + bias) * scale + shift) -> the free image, 8 bytes (4 channels) per write
     f32x4 cb[2], cs[2], ct[2];
 #pragma unroll
@@ -187,9 +218,12 @@ __global__ __launch_bounds__(RNT, 2) void res2net_chain_kernel(ChainParams p) {
         }
       }
     }
+    stamp();
     __syncthreads();                                        // y_c complete in `nxt`; every read of `cur` is done
-    // ---- y_c -> HBM; s_{c+1} = bf16(y_c + u_{c+1}) in place
-    char* rb = reinterpret_cast<char*>(p.R + base * p.ldr + (int64_t)RS * c);                                    // uniform
+    stamp();
+    // ---- y_c -> HBM; s_{c+1} = bf16(y_c + u_{c+1}) in place.  (Doing both straight from the accumulators in the epilogue - no
+    // barrier, no second pass - was measured: the 8-byte-per-lane u loads and y stores it needs touch 16 cache lines per
+    // instruction, and the chain went from 0.66 to 0.96 ms.)
     // every u request is waited for HERE, on every lane: a load left pending on some path would make the first wait of the next
     // conv cover it - and, vmcnt being in-order, the y stores issued behind it (an HBM round trip per conv)
 #pragma unroll
@@ -199,7 +233,7 @@ __global__ __launch_bounds__(RNT, 2) void res2net_chain_kernel(ChainParams p) {
       if (i < nrow) {
         char* q = nxt + loff + i * (32 * 256);
         const u32x4 y = *reinterpret_cast<const u32x4*>(q);
-        *reinterpret_cast<u32x4*>(rb + (size_t)(yoff + (uint32_t)i * ystride)) = y;
+        __builtin_amdgcn_raw_buffer_store_b128(y, yrs, yoff, (uint32_t)i * ystride + (uint32_t)(c * RS * 2), 0);
         if (c < p.nconv) {
           float fy[8], fu[8];
           unpack8(y, fy);
@@ -210,32 +244,52 @@ __global__ __launch_bounds__(RNT, 2) void res2net_chain_kernel(ChainParams p) {
         }
       }
     }
+    stamp();
   }
+  if (p.dbg && tid == 0 && blockIdx.x < 256) p.dbg[blockIdx.x * 64 + 1] = nstamp;
 }
 
 }  // namespace
 
 extern "C" int sdk_res2net_chain_max_frames(void) { return 208; }
 
-extern "C" int sdk_res2net_chain(sdk_ctx* ctx, const uint16_t* U, int64_t ldu, uint16_t* R, int64_t ldr, const uint16_t* const* W,
-                                 const float* const* bias, const float* const* scale, const float* const* shift, int nconv,
-                                 int B, int T, int dil, void* stream) {
+// Internal entry (sdk_ecapa_forward): Wpk may be null, or hold the fragment-ordered copies of W (ecapa_layout.h EL_CHAINPACK).
+int res2net_chain_launch(sdk_ctx* ctx, const uint16_t* U, int64_t ldu, uint16_t* R, int64_t ldr, const uint16_t* const* W,
+                         const uint16_t* const* Wpk, const float* const* bias, const float* const* scale, const float* const* shift,
+                         int nconv, int B, int T, int dil, void* stream) {
   SDK_REQUIRE(ctx && U && R && W && bias && scale && shift, "sdk_res2net_chain: null argument");
   SDK_REQUIRE(nconv >= 1 && nconv <= 7, "sdk_res2net_chain: nconv=%d must be in [1, 7]", nconv);
   SDK_REQUIRE(B > 0 && T > dil && T <= 208 && dil >= 1, "sdk_res2net_chain: T=%d frames (dilation %d) unsupported (dil < T <= 208)", T, dil);
   SDK_REQUIRE(ldu % 8 == 0 && ldr % 8 == 0 && ldu >= (int64_t)RS * (nconv + 1) && ldr >= (int64_t)RS * (nconv + 1), "sdk_res2net_chain: bad row strides");
+  SDK_REQUIRE((uint64_t)T * (uint64_t)(ldu > ldr ? ldu : ldr) * 2u < (1ull << 32), "sdk_res2net_chain: row strides too large for 32-bit in-segment offsets");
   ChainParams p;
   p.U = (const bf16_t*)U; p.ldu = ldu; p.R = (bf16_t*)R; p.ldr = ldr; p.T = T; p.dil = dil; p.nconv = nconv;
+  p.dbg = (unsigned long long*)ctx->dbg_ptr;
+  bool packed = Wpk != nullptr && !ctx->no_chain_packed;
   for (int i = 0; i < 7; ++i) {
     const int k = i < nconv ? i : 0;
     SDK_REQUIRE(W[k] && bias[k] && scale[k] && shift[k], "sdk_res2net_chain: conv %d parameters missing", k);
+    SDK_REQUIRE(((uintptr_t)bias[k] % 8) == 0 && ((uintptr_t)scale[k] % 8) == 0 && ((uintptr_t)shift[k] % 8) == 0, "sdk_res2net_chain: conv %d parameter arrays must be 8-byte aligned", k);
     p.W[i] = (const bf16_t*)W[k]; p.bias[i] = bias[k]; p.scale[i] = scale[k]; p.shift[i] = shift[k];
+    if (packed && !Wpk[k]) packed = false;
+    p.Wpk[i] = packed ? (const bf16_t*)Wpk[k] : nullptr;
   }
   ProfScope ps(ctx, stream, SDK_K_RES2NET, 2.0 * B * T * (double)RS * 3 * RS * nconv, 2.0 * 2.0 * B * T * RS * nconv);
-  if (sdk_lds_optin(ctx, (const void*)res2net_chain_kernel<13>, 2 * 208 * 256 + PAR_BYTES)) return 1;
-  if (sdk_lds_optin(ctx, (const void*)res2net_chain_kernel<7>, 2 * 112 * 256 + PAR_BYTES)) return 1;
-  if (T <= 112) hipLaunchKernelGGL(res2net_chain_kernel<7>, dim3(B), dim3(RNT), 2 * 112 * 256 + PAR_BYTES, (hipStream_t)stream, p);
-  else hipLaunchKernelGGL(res2net_chain_kernel<13>, dim3(B), dim3(RNT), 2 * 208 * 256 + PAR_BYTES, (hipStream_t)stream, p);
+  auto launch = [&](auto kern, int lds) -> int {
+    if (sdk_lds_optin(ctx, (const void*)kern, lds)) return 1;
+    hipLaunchKernelGGL(kern, dim3(B), dim3(RNT), lds, (hipStream_t)stream, p);
+    return 0;
+  };
+  int rc;
+  if (T <= 112) rc = packed ? launch(res2net_chain_kernel<7, true>, 2 * 112 * 256 + PAR_BYTES) : launch(res2net_chain_kernel<7, false>, 2 * 112 * 256 + PAR_BYTES);
+  else rc = packed ? launch(res2net_chain_kernel<13, true>, 2 * 208 * 256 + PAR_BYTES) : launch(res2net_chain_kernel<13, false>, 2 * 208 * 256 + PAR_BYTES);
+  if (rc) return rc;
   SDK_LAUNCH_CHECK();
   return 0;
+}
+
+extern "C" int sdk_res2net_chain(sdk_ctx* ctx, const uint16_t* U, int64_t ldu, uint16_t* R, int64_t ldr, const uint16_t* const* W,
+                                 const float* const* bias, const float* const* scale, const float* const* shift, int nconv,
+                                 int B, int T, int dil, void* stream) {
+  return res2net_chain_launch(ctx, U, ldu, R, ldr, W, nullptr, bias, scale, shift, nconv, B, T, dil, stream);
 }

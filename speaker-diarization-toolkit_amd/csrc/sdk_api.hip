@@ -79,6 +79,7 @@ extern "C" int sdk_get_device_info(sdk_ctx* ctx, sdk_device_info* out) {
 extern "C" int sdk_set_option(sdk_ctx* ctx, const char* name, int value) {
   SDK_REQUIRE(ctx && name, "sdk_set_option: null argument");
   if (strcmp(name, "res2net_chain_fusion") == 0) { ctx->no_chain_fusion = value == 0; return 0; }
+  if (strcmp(name, "res2net_packed_weights") == 0) { ctx->no_chain_packed = value == 0; return 0; }
   if (strcmp(name, "asp_per_segment") == 0) { ctx->no_asp_seg = value == 0; return 0; }
   if (strcmp(name, "gemm_variant") == 0) return sdk_set_gemm_variant(value);
   if (strcmp(name, "affinity_fast_path") == 0) { ctx->aff_fast = value; return 0; }
@@ -239,12 +240,13 @@ extern "C" int sdk_ecapa_forward(sdk_ctx* ctx, const void* wblob, const sdk_ecap
       // the seven dependent convolutions in ONE launch, the running tile resident in LDS per segment.  The chain runs
       // IN PLACE on the tdnn1 output: a workgroup has read u_c (into LDS / registers) before it writes y_c over it, and
       // segments do not overlap - so chunk 0 needs no copy
-      const uint16_t* Wp[7]; const float* bp[7]; const float* sp[7]; const float* tp[7];
+      const uint16_t* Wp[7]; const uint16_t* Wk[7]; const float* bp[7]; const float* sp[7]; const float* tp[7];
       for (int j = 0; j < d->scale - 1; ++j) {
         const int slot = base + EL_RES2NET(j);
         Wp[j] = P16(slot + EL_W); bp[j] = P32(slot + EL_B); sp[j] = P32(slot + EL_SCALE); tp[j] = P32(slot + EL_SHIFT);
+        Wk[j] = (i <= 4 && d->off[EL_CHAINPACK(i, j)] >= 0) ? P16(EL_CHAINPACK(i, j)) : nullptr;   // optional fragment-ordered copy
       }
-      if (int rc = sdk_res2net_chain(ctx, w.U, C, w.U, C, Wp, bp, sp, tp, d->scale - 1, B, T, dil, stream)) return rc;
+      if (int rc = res2net_chain_launch(ctx, w.U, C, w.U, C, Wp, Wk, bp, sp, tp, d->scale - 1, B, T, dil, stream)) return rc;
       r2out = w.U;
     } else {
       // separate launches: the running sum is produced by the previous conv's epilogue (S output), ping-ponging

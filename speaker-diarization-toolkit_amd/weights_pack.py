@@ -39,6 +39,28 @@ def tail_base(n_blocks: int) -> int:
     return 4 + n_blocks * 40
 
 
+def chainpack_slot(i: int, j: int) -> int:
+    """EL_CHAINPACK(i, j): optional fragment-ordered copy of block i's Res2Net conv j."""
+    return 160 + (i - 1) * 8 + j
+
+
+def chain_fragment_order(wk: np.ndarray) -> np.ndarray:
+    """[128, 3*128] bf16 bits (tap-major K) -> [tap 3][wq 4][h 2][ks 4][lane 64][8] (csrc/ecapa_layout.h): the 16 bytes lane l of
+    wave-column-block wq needs for column tile h, tap, k-step ks sit at a lane-contiguous address."""
+    assert wk.shape == (128, 384) and wk.dtype == np.uint16
+    lane = np.arange(64)
+    fr, fq = lane & 15, lane >> 4
+    out = np.empty((3, 4, 2, 4, 64, 8), dtype=np.uint16)
+    for tap in range(3):
+        for wq in range(4):
+            for h in range(2):
+                for ks in range(4):
+                    rows = 32 * wq + 16 * h + fr                                   # [64]
+                    cols = 128 * tap + 32 * ks + 8 * fq                             # [64]
+                    out[tap, wq, h, ks] = wk[rows[:, None], cols[:, None] + np.arange(8)[None, :]]
+    return out
+
+
 def f32_to_bf16_bits(x: np.ndarray) -> np.ndarray:
     """fp32 -> bf16 bit pattern, round-to-nearest-even (finite inputs)."""
     u = np.ascontiguousarray(x, dtype=np.float32).view(np.uint32).astype(np.uint64)
@@ -87,6 +109,8 @@ def pack_weights(weights: Dict[str, np.ndarray], cfg: EcapaConfig = DEFAULT_CONF
         tdnn(b + EL_TDNN1, f"blk{i}.tdnn1")
         for j in range(cfg.res2net_scale - 1):
             tdnn(b + res2net_slot(j), f"blk{i}.res2net.{j}")
+            if cfg.sub_channels == 128 and i <= 4 and j < 7:
+                put(chainpack_slot(i, j), chain_fragment_order(conv_weight_kmajor(weights[f"blk{i}.res2net.{j}.conv.w"])))
         tdnn(b + EL_TDNN2, f"blk{i}.tdnn2")
         put(b + EL_SE_W1T, weights[f"blk{i}.se.conv1.w"][:, :, 0].T.astype(np.float32))
         put(b + EL_SE_B1, weights[f"blk{i}.se.conv1.b"])

@@ -561,3 +561,10 @@ def test_res2net_chain_fusion_is_bit_identical(engine, B, T):
     engine.set_option("res2net_chain_fusion", 1)
     fused = engine.ecapa_forward(f, B, T).cpu()
     assert torch.equal(ref, fused), float((ref - fused).abs().max())
+    # ... and so must the chain when it reads the [128][384] weight matrices instead of their fragment-ordered copies (EL_CHAINPACK)
+    try:
+        engine.set_option("res2net_packed_weights", 0)
+        plain = engine.ecapa_forward(f, B, T).cpu()
+    finally:
+        engine.set_option("res2net_packed_weights", 1)
+    assert torch.equal(ref, plain), float((ref - plain).abs().max())
