@@ -64,12 +64,14 @@ int sdk_init(int device, sdk_ctx** out);
 int sdk_shutdown(sdk_ctx* ctx);
 const char* sdk_last_error(void);
 int sdk_get_device_info(sdk_ctx* ctx, sdk_device_info* out);
-/* A/B and test knobs: "res2net_chain_fusion" (1 default / 0 = seven conv_gemm launches), "asp_per_segment" (1 default /
- * 0 = one workgroup per (segment, 128 channels)), "gemm_variant" (see
- * sdk_set_gemm_variant).  Results do not depend on them. */
+/* A/B and test knobs: "res2net_chain_fusion" (1 default / 0 = seven conv_gemm launches), "res2net_packed_weights" (1 default /
+ * 0 = the chain ignores the blob's optional fragment-ordered weight copies, ecapa_layout.h EL_CHAINPACK), "asp_per_segment"
+ * (1 default / 0 = one workgroup per (segment, 128 channels)), "affinity_fast_path" / "affinity_variant" /
+ * "affinity_whole_groups" (k = 1 affinity kernel selection), "gemm_variant" (see sdk_set_gemm_variant).  Results do not
+ * depend on them. */
 int sdk_set_option(sdk_ctx* ctx, const char* name, int value);
-/* Diagnostics: "stamps" = device buffer [workgroups][64] of uint64 that the affinity kernel fills with in-kernel wall-clock
- * stamps (tools/aff_timeline.py); "gemm_clock" = [workgroups <= 4096][2] uint64 {shader cycles, 100 MHz ticks} of each
+/* Diagnostics: "stamps" = device buffer [workgroups][64] of uint64 that the affinity kernel (tools/aff_timeline.py) and the
+ * Res2Net chain (tools/res2net_timeline.py) fill with in-kernel wall-clock stamps; "gemm_clock" = [workgroups <= 4096][2] uint64 {shader cycles, 100 MHz ticks} of each
  * conv_gemm256 workgroup's lifetime (bench.py: the clock the chip holds inside the dominant kernel).  NULL (default) = off. */
 int sdk_debug_set_ptr(sdk_ctx* ctx, const char* name, void* device_ptr);
 
