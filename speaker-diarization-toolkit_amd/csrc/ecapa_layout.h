@@ -33,6 +33,9 @@
 #define EL_ASPBN_SHIFT 12
 #define EL_FC_WT 13                                 /* fp32 [2Cm][E]   */
 #define EL_FC_B 14
+#define EL_ASP_W2PACK 15                            /* OPTIONAL (-1 = absent): EL_ASP_W2 in MFMA fragment order for the per-segment ASP kernel:
+                                                      [channel block Cm/32][ks 8][lane 64][8] bf16, lane l holds
+                                                      W2[32 blk + (l & 31)][16 ks + 8 (l >> 5) + 0..7] */
 
 /* OPTIONAL (-1 = absent): the Res2Net chain's 128x128 k3 conv weights once more, in MFMA fragment order, so that a wave's
  * fragment load is 1 KiB contiguous instead of 16 row pieces of 64 B:

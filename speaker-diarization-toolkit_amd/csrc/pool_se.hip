@@ -573,6 +573,7 @@ typedef void __attribute__((address_space(3)))* seg_lptr_t;
 
 #define SEG_WAIT_VM(n) asm volatile("s_waitcnt vmcnt(" #n ")" ::: "memory")
 
+template <bool PACKED>
 __global__ __launch_bounds__(SEG_NT, 2) void asp_seg_kernel(const bf16_t* __restrict__ ah, int64_t ldah,
                                                            const bf16_t* __restrict__ w2, const bf16_t* __restrict__ h,
                                                            int64_t ldh, int T, int C, float* __restrict__ pooled) {
@@ -618,10 +619,15 @@ __global__ __launch_bounds__(SEG_NT, 2) void asp_seg_kernel(const bf16_t* __rest
 #pragma unroll
   for (int ks = 0; ks < 8; ++ks) aoff[ks] = col * 256 + (((ks * 2 + hh) ^ (col & 15)) << 4);
   bf16x8 bA[8], bB[8];                                       // W2 rows of this lane's channel, this block / next block
+  // PACKED: w2 is the host's fragment-ordered copy [block][ks 8][lane 64][8] (ecapa_layout.h EL_ASP_W2PACK): one 1-KiB contiguous
+  // load per k-step instead of 32 row pieces of 16 B - the row-major form touches every 128-byte line of W2 four times
+  // (3.1 GB of L2 line traffic per 1000 segments for 0.79 GB of weights)
   auto fetch_w2 = [&](int blk, bf16x8* dst) {
 #pragma unroll
-    for (int ks = 0; ks < 8; ++ks)
-      dst[ks] = *reinterpret_cast<const bf16x8*>(w2 + (int64_t)(blk * 32 + col) * 128 + ks * 16 + hh * 8);
+    for (int ks = 0; ks < 8; ++ks) {
+      if constexpr (PACKED) dst[ks] = *reinterpret_cast<const bf16x8*>(w2 + ((int64_t)(blk * 8 + ks) * 64 + lane) * 8);
+      else dst[ks] = *reinterpret_cast<const bf16x8*>(w2 + (int64_t)(blk * 32 + col) * 128 + ks * 16 + hh * 8);
+    }
   };
   const uint32_t slab_off = (uint32_t)(SEG_HID_BYTES + wid * SEG_SLAB_BYTES);
   // frame t = 32 rt + 8 (r >> 2) + (r & 3) + 4 hh sits at chunk (col >> 3) ^ ((t >> 2) & 3) = (col >> 3) ^ hh ^ (2 (r >> 2) & 3):
@@ -892,17 +898,23 @@ extern "C" int sdk_asp_pool(sdk_ctx* ctx, const float* logits, int64_t ldl, cons
 
 extern "C" int sdk_asp_fused_max_frames(void) { return 224; }
 
-extern "C" int sdk_asp_fused(sdk_ctx* ctx, const uint16_t* ah, int64_t ldah, const uint16_t* w2, const float* b2,
-                             const uint16_t* h, int64_t ldh, int B, int T, int C, int A, float* pooled, void* stream) {
+// Internal entry (sdk_ecapa_forward): w2p may be null, or the fragment-ordered copy of w2 (ecapa_layout.h EL_ASP_W2PACK).
+int asp_fused_launch(sdk_ctx* ctx, const uint16_t* ah, int64_t ldah, const uint16_t* w2, const uint16_t* w2p, const float* b2,
+                     const uint16_t* h, int64_t ldh, int B, int T, int C, int A, float* pooled, void* stream) {
   SDK_REQUIRE(ctx && ah && w2 && b2 && h && pooled, "sdk_asp_fused: null argument");
   SDK_REQUIRE(A == 128, "sdk_asp_fused: attention width %d, this build is specialised for 128", A);
   SDK_REQUIRE(B > 0 && T > 0 && T <= 224, "sdk_asp_fused: T=%d frames unsupported (1..224); use sdk_conv_gemm + sdk_asp_pool", T);
   SDK_REQUIRE(C % 128 == 0 && ldah % 8 == 0 && ldh % 8 == 0, "sdk_asp_fused: C=%d must be a multiple of 128", C);
   ProfScope ps(ctx, stream, SDK_K_ASP_FUSED, 2.0 * B * T * (double)A * C, 2.0 * B * T * ((double)C + A) + 8.0 * B * C);
   if (T > 96 && T <= SEG_ROWS && C % 256 == 0 && !ctx->no_asp_seg) {     // one workgroup per segment (hidden tile read once)
-    if (sdk_lds_optin(ctx, (const void*)asp_seg_kernel, SEG_LDS)) return 1;
-    hipLaunchKernelGGL(asp_seg_kernel, dim3(B), dim3(SEG_NT), SEG_LDS, (hipStream_t)stream, (const bf16_t*)ah, ldah, (const bf16_t*)w2,
-                       (const bf16_t*)h, ldh, T, C, pooled);
+    if (sdk_lds_optin(ctx, (const void*)asp_seg_kernel<false>, SEG_LDS)) return 1;
+    if (sdk_lds_optin(ctx, (const void*)asp_seg_kernel<true>, SEG_LDS)) return 1;
+    if (w2p && !ctx->no_asp_packed)
+      hipLaunchKernelGGL(asp_seg_kernel<true>, dim3(B), dim3(SEG_NT), SEG_LDS, (hipStream_t)stream, (const bf16_t*)ah, ldah, (const bf16_t*)w2p,
+                         (const bf16_t*)h, ldh, T, C, pooled);
+    else
+      hipLaunchKernelGGL(asp_seg_kernel<false>, dim3(B), dim3(SEG_NT), SEG_LDS, (hipStream_t)stream, (const bf16_t*)ah, ldah, (const bf16_t*)w2,
+                         (const bf16_t*)h, ldh, T, C, pooled);
     SDK_LAUNCH_CHECK();
     return 0;
   }
@@ -911,6 +923,11 @@ extern "C" int sdk_asp_fused(sdk_ctx* ctx, const uint16_t* ah, int64_t ldah, con
   else hipLaunchKernelGGL(asp_fused_kernel<7>, grid, dim3(NT), 0, (hipStream_t)stream, (const bf16_t*)ah, ldah, (const bf16_t*)w2, b2, (const bf16_t*)h, ldh, T, C, pooled);
   SDK_LAUNCH_CHECK();
   return 0;
+}
+
+extern "C" int sdk_asp_fused(sdk_ctx* ctx, const uint16_t* ah, int64_t ldah, const uint16_t* w2, const float* b2,
+                             const uint16_t* h, int64_t ldh, int B, int T, int C, int A, float* pooled, void* stream) {
+  return asp_fused_launch(ctx, ah, ldah, w2, nullptr, b2, h, ldh, B, T, C, A, pooled, stream);
 }
 
 extern "C" int sdk_l2norm(sdk_ctx* ctx, const float* X, int N, int d, float* E, uint16_t* Eb, float* resid,

@@ -80,6 +80,7 @@ extern "C" int sdk_set_option(sdk_ctx* ctx, const char* name, int value) {
   SDK_REQUIRE(ctx && name, "sdk_set_option: null argument");
   if (strcmp(name, "res2net_chain_fusion") == 0) { ctx->no_chain_fusion = value == 0; return 0; }
   if (strcmp(name, "res2net_packed_weights") == 0) { ctx->no_chain_packed = value == 0; return 0; }
+  if (strcmp(name, "asp_packed_weights") == 0) { ctx->no_asp_packed = value == 0; return 0; }
   if (strcmp(name, "asp_per_segment") == 0) { ctx->no_asp_seg = value == 0; return 0; }
   if (strcmp(name, "gemm_variant") == 0) return sdk_set_gemm_variant(value);
   if (strcmp(name, "affinity_fast_path") == 0) { ctx->aff_fast = value; return 0; }
@@ -297,7 +298,7 @@ extern "C" int sdk_ecapa_forward(sdk_ctx* ctx, const void* wblob, const sdk_ecap
     if (int rc = sdk_conv_gemm(ctx, &g, stream)) return rc;
     if (A == 128 && T <= sdk_asp_fused_max_frames()) {
       // logits GEMM + softmax pooling fused: no [M, Cm] fp32 logits round trip through HBM
-      if (int rc = sdk_asp_fused(ctx, w.AH, A, P16(tb + EL_ASP_W2), P32(tb + EL_ASP_B2), w.H, Cm, B, T, Cm, A, w.pooled, stream)) return rc;
+      if (int rc = asp_fused_launch(ctx, w.AH, A, P16(tb + EL_ASP_W2), P16(tb + EL_ASP_W2PACK), P32(tb + EL_ASP_B2), w.H, Cm, B, T, Cm, A, w.pooled, stream)) return rc;
     } else {
       memset(&g, 0, sizeof(g));
       g.A = w.AH; g.lda = A; g.W = P16(tb + EL_ASP_W2); g.C32 = w.logits; g.ldc32 = Cm; g.bias = P32(tb + EL_ASP_B2);

@@ -24,7 +24,7 @@ EL_BLK0 = 0
 EL_TDNN1, EL_TDNN2 = 0, 32
 EL_SE_W1T, EL_SE_B1, EL_SE_W2T, EL_SE_B2 = 36, 37, 38, 39
 EL_MFA, EL_ASP_WH, EL_ASP_WMS_T, EL_ASP_B, EL_ASP_SCALE, EL_ASP_SHIFT = 0, 4, 5, 6, 7, 8
-EL_ASP_W2, EL_ASP_B2, EL_ASPBN_SCALE, EL_ASPBN_SHIFT, EL_FC_WT, EL_FC_B = 9, 10, 11, 12, 13, 14
+EL_ASP_W2, EL_ASP_B2, EL_ASPBN_SCALE, EL_ASPBN_SHIFT, EL_FC_WT, EL_FC_B, EL_ASP_W2PACK = 9, 10, 11, 12, 13, 14, 15
 
 
 def block_base(i: int) -> int:
@@ -69,6 +69,21 @@ def f32_to_bf16_bits(x: np.ndarray) -> np.ndarray:
 
 def bf16_bits_to_f32(b: np.ndarray) -> np.ndarray:
     return (np.ascontiguousarray(b, dtype=np.uint16).astype(np.uint32) << 16).view(np.float32)
+
+
+def asp_w2_fragment_order(w2: np.ndarray) -> np.ndarray:
+    """[Cm, 128] bf16 bits -> [Cm/32][ks 8][lane 64][8] (csrc/ecapa_layout.h EL_ASP_W2PACK): lane l of a 32x32x16 fragment holds
+    W2[32 blk + (l & 31)][16 ks + 8 (l >> 5) + 0..7]."""
+    cm, a = w2.shape
+    assert a == 128 and cm % 32 == 0 and w2.dtype == np.uint16
+    lane = np.arange(64)
+    col, hh = lane & 31, lane >> 5
+    out = np.empty((cm // 32, 8, 64, 8), dtype=np.uint16)
+    for ks in range(8):
+        k0 = 16 * ks + 8 * hh                                                      # [64]
+        for blk in range(cm // 32):
+            out[blk, ks] = w2[(32 * blk + col)[:, None], k0[:, None] + np.arange(8)[None, :]]
+    return out
 
 
 def conv_weight_kmajor(w: np.ndarray, cin_pad: int | None = None) -> np.ndarray:
@@ -127,6 +142,8 @@ def pack_weights(weights: Dict[str, np.ndarray], cfg: EcapaConfig = DEFAULT_CONF
     put(t + EL_ASP_SCALE, s)
     put(t + EL_ASP_SHIFT, sh)
     put(t + EL_ASP_W2, f32_to_bf16_bits(weights["asp.conv.w"][:, :, 0]))
+    if cfg.attn_channels == 128 and m % 32 == 0:
+        put(t + EL_ASP_W2PACK, asp_w2_fragment_order(f32_to_bf16_bits(weights["asp.conv.w"][:, :, 0])))
     put(t + EL_ASP_B2, weights["asp.conv.b"])
     s, sh = bn_affine(weights, "asp_bn")
     put(t + EL_ASPBN_SCALE, s)
