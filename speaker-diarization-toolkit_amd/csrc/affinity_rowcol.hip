@@ -285,11 +285,7 @@ __global__ __launch_bounds__(256) void aff_rowcol_rescore_kernel(const float* __
   const int np = np_raw < MAXP ? np_raw : MAXP;
   const float re = resid_e[rc];
   float e24[24];
-#pragma unroll
-  for (int q = 0; q < 6; ++q) {     // plain loads: a non-temporal hint here cost 19 us (25.7 -> 44.6: E then comes from HBM instead of the Infinity Cache)
-    const f32x4 v = *reinterpret_cast<const f32x4*>(E + (int64_t)rc * D + 24 * j + 4 * q);
-    e24[4 * q] = v[0]; e24[4 * q + 1] = v[1]; e24[4 * q + 2] = v[2]; e24[4 * q + 3] = v[3];
-  }
+  load_row24(E + (int64_t)rc * D, j, e24);     // plain loads: a non-temporal hint here cost 19 us (25.7 -> 44.6: E then comes from HBM, not the Infinity Cache)
   // rigorous |exact - coarse| bound for this row (resid_p = max profile residual); the slack covers the tag bits
   // (2^-13 relative), the MFMA's fp32 accumulation and this formula's own rounding
   const float eps = (re + (1.0f + re) * resid_p[0]) * 1.0001f + 1.5e-4f;
@@ -419,11 +415,7 @@ __global__ __launch_bounds__(256) void aff_rowcol_rescore_kernel(const float* __
     for (int f = 0; f < nf; ++f) {                                  // workgroup-uniform
       const int frow = flist_s[f];
       float ef[24];
-#pragma unroll
-      for (int q = 0; q < 6; ++q) {
-        const f32x4 v = *reinterpret_cast<const f32x4*>(E + (int64_t)frow * D + 24 * j + 4 * q);
-        ef[4 * q] = v[0]; ef[4 * q + 1] = v[1]; ef[4 * q + 2] = v[2]; ef[4 * q + 3] = v[3];
-      }
+      load_row24(E + (int64_t)frow * D, j, ef);
       float fs = -INFINITY;
       int fi = 0x7fffffff;
       for (int p0 = g; p0 < P; p0 += 64) {                          // ascending per lane group, two rows in flight
@@ -507,11 +499,7 @@ __global__ __launch_bounds__(256) void aff_rescan4_kernel(const float* __restric
     for (int x = 0; x < RS_ROWS; ++x) {
       const int f = min(q * RS_ROWS + x, count - 1);
       const int row = flag_rows[f];
-#pragma unroll
-      for (int qq = 0; qq < 6; ++qq) {
-        const f32x4 v = *reinterpret_cast<const f32x4*>(E + (int64_t)row * D + 24 * j + 4 * qq);
-        e24[x][4 * qq] = v[0]; e24[x][4 * qq + 1] = v[1]; e24[x][4 * qq + 2] = v[2]; e24[x][4 * qq + 3] = v[3];
-      }
+      load_row24(E + (int64_t)row * D, j, e24[x]);
     }
     float bs[RS_ROWS];
     int bi[RS_ROWS];

@@ -214,11 +214,7 @@ __global__ __launch_bounds__(256) void affinity_rescore_kernel(const float* __re
   const bool live = row < N;
   const int rc = live ? row : N - 1;
   float e24[24];
-#pragma unroll
-  for (int q = 0; q < 6; ++q) {
-    const f32x4 v = *reinterpret_cast<const f32x4*>(E + (int64_t)rc * D + 24 * j + 4 * q);
-    e24[4 * q] = v[0]; e24[4 * q + 1] = v[1]; e24[4 * q + 2] = v[2]; e24[4 * q + 3] = v[3];
-  }
+  load_row24(E + (int64_t)rc * D, j, e24);
   const float re = resid_e[rc];
   // rigorous |exact - coarse| bound for this row (resid_p = max profile residual), small slack for fp32
   const float eps = (re + (1.0f + re) * resid_p[0]) * 1.0001f + 1.5e-4f;
@@ -300,11 +296,7 @@ __global__ __launch_bounds__(256) void affinity_rescan_kernel(const float* __res
     const int row = flag_rows[f];
     const int p0 = sl * SLICE, p1 = min(P, p0 + SLICE);
     float e24[24];
-#pragma unroll
-    for (int q = 0; q < 6; ++q) {
-      const f32x4 v = *reinterpret_cast<const f32x4*>(E + (int64_t)row * D + 24 * j + 4 * q);
-      e24[4 * q] = v[0]; e24[4 * q + 1] = v[1]; e24[4 * q + 2] = v[2]; e24[4 * q + 3] = v[3];
-    }
+    load_row24(E + (int64_t)row * D, j, e24);
     float bs[4] = {-INFINITY, -INFINITY, -INFINITY, -INFINITY};
     int bi[4] = {0x7fffffff, 0x7fffffff, 0x7fffffff, 0x7fffffff};
     for (int p = p0 + g; p < p1; p += 4 * 32) {             // four profile rows in flight per lane group

@@ -9,8 +9,21 @@ namespace sdk_exact {
 constexpr int D = 192;                 // embedding width
 
 // ---- exact fp32 dot product of two 192-vectors by a group of 8 consecutive lanes ---------------
-// lane j of the group owns elements [24 j, 24 j + 24); fixed order: sequential fma inside the lane,
-// then the xor-butterfly 1,2,4 (fp add is commutative, so all 8 lanes hold the same bits).
+// lane j of the group owns the elements {32 q + 4 j + 0..3 : q = 0..5}: for every q the group's 8 lanes read ONE 128-byte line
+// of the row (a wave-instruction then touches 8 lines; with "lane j owns [24 j, 24 j + 24)", as in round 1, it touched 48).
+// Fixed order: sequential fma inside the lane (q ascending), then the xor-butterfly 1,2,4 (fp add is commutative, so all
+// 8 lanes hold the same bits).  EVERY kernel loads its rows through load_row24 / load_prow, so the order is one.
+__device__ __forceinline__ void load_prow(const float* __restrict__ prow, int j, f32x4* pv) {
+#pragma unroll
+  for (int q = 0; q < 6; ++q) pv[q] = *reinterpret_cast<const f32x4*>(prow + 32 * q + 4 * j);
+}
+__device__ __forceinline__ void load_row24(const float* __restrict__ row, int j, float* e24) {
+#pragma unroll
+  for (int q = 0; q < 6; ++q) {
+    const f32x4 v = *reinterpret_cast<const f32x4*>(row + 32 * q + 4 * j);
+    e24[4 * q] = v[0]; e24[4 * q + 1] = v[1]; e24[4 * q + 2] = v[2]; e24[4 * q + 3] = v[3];
+  }
+}
 __device__ __forceinline__ float dot192_regs(const float* __restrict__ e24, const f32x4* __restrict__ pv) {
   float a = 0.f;
 #pragma unroll
@@ -25,11 +38,6 @@ __device__ __forceinline__ float dot192_regs(const float* __restrict__ e24, cons
   a += __shfl_xor(a, 2, 64);
   a += __shfl_xor(a, 4, 64);
   return a;
-}
-__device__ __forceinline__ void load_prow(const float* __restrict__ prow, int j, f32x4* pv) {
-  const f32x4* p = reinterpret_cast<const f32x4*>(prow + 24 * j);
-#pragma unroll
-  for (int q = 0; q < 6; ++q) pv[q] = p[q];
 }
 __device__ __forceinline__ float dot192_group8(const float* __restrict__ e24, const float* __restrict__ prow, int j) {
   f32x4 pv[6];
