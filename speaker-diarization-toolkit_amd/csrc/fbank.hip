@@ -54,10 +54,14 @@ struct FbankTables {
 // The folded, split sample images are built once per tile in LDS (rows of 432 B), so an A fragment is one
 // ds_read_b128; wave w owns bins 32w..32w+31 and keeps cos and sin accumulators in the same lane/register
 // positions, so |X|^2 forms in registers.
-__global__ __launch_bounds__(NW * 64) void fbank_tile_kernel(const int16_t* __restrict__ pcm, int S, int T,
+__global__ __launch_bounds__(NW * 64) __attribute__((amdgpu_waves_per_eu(4, 4))) void fbank_tile_kernel(const int16_t* __restrict__ pcm, int S, int T,
                                                             int tiles_per_seg, const FbankTables* __restrict__ tab,
-                                                            float* __restrict__ L) {
+                                                            float* __restrict__ L, unsigned long long* __restrict__ dbg) {
   __shared__ __attribute__((aligned(16))) char lds[4 * FT * AROW * 2 + TILE_SAMPLES * 4];
+  // diagnostics only (tools/fbank_timeline.py): 100 MHz stamps of thread 0 of workgroups 0..255
+  int nstamp = 0;
+  auto stamp = [&]() { if (dbg && threadIdx.x == 0 && blockIdx.x < 256) dbg[blockIdx.x * 16 + nstamp++] = __builtin_amdgcn_s_memrealtime(); };
+  stamp();
   bf16_t* img = reinterpret_cast<bf16_t*>(lds);                       // [cos hi | cos lo | sin hi | sin lo][32][AROW]
   float* xs = reinterpret_cast<float*>(lds + 4 * FT * AROW * 2);      // raw samples of the tile
   float* pw = reinterpret_cast<float*>(lds);                          // power tile, overlays the images after the MFMAs
@@ -69,11 +73,25 @@ __global__ __launch_bounds__(NW * 64) void fbank_tile_kernel(const int16_t* __re
   const int64_t s0 = (int64_t)t0 * HOP - NFFT / 2;     // first sample of the tile (may be < 0)
   const int16_t* seg = pcm + (int64_t)b * S;
 
-  for (int q = tid; q < TILE_SAMPLES; q += NW * 64) {
-    const int64_t g = s0 + q;
-    xs[q] = (g >= 0 && g < S) ? (float)seg[g] * (1.0f / 32768.0f) : 0.f;
+  {
+    // every request of the thread first, then the conversions: rolled, this loop was load - wait - store twelve times over,
+    // i.e. twelve HBM round trips in a row at the head of every workgroup
+    constexpr int NLD = (TILE_SAMPLES + NW * 64 - 1) / (NW * 64);
+    int16_t raw[NLD];
+#pragma unroll
+    for (int i = 0; i < NLD; ++i) {
+      const int64_t g = s0 + tid + i * (NW * 64);
+      raw[i] = seg[g < 0 ? 0 : (g < S ? g : S - 1)];          // clamped address, value masked below
+    }
+#pragma unroll
+    for (int i = 0; i < NLD; ++i) {
+      const int q = tid + i * (NW * 64);
+      const int64_t g = s0 + q;
+      if (q < TILE_SAMPLES) xs[q] = (g >= 0 && g < S) ? (float)raw[i] * (1.0f / 32768.0f) : 0.f;
+    }
   }
   __syncthreads();
+  stamp();
   // folded, split sample images: two consecutive n per thread-iteration -> 4-byte LDS writes
   for (int e = tid; e < FT * (NSYM / 2); e += NW * 64) {
     const int i = e / (NSYM / 2), n = (e - i * (NSYM / 2)) * 2;
@@ -95,39 +113,52 @@ __global__ __launch_bounds__(NW * 64) void fbank_tile_kernel(const int16_t* __re
     dst[(3 * FT * AROW) / 2] = pack2(es[0] - bf16_to_f32(sh0), es[1] - bf16_to_f32(sh1));
   }
   __syncthreads();
+  stamp();
 
   f32x16 are, aim;
 #pragma unroll
   for (int r = 0; r < 16; ++r) { are[r] = 0.f; aim[r] = 0.f; }
   const int fi = lane & 31, kk = lane >> 5;
   const bf16_t* arow = img + fi * AROW + kk * 8;
-  const bf16x8* btab = reinterpret_cast<const bf16x8*>(&tab->dft[w][0][0][0][lane][0]);
-  // fragment (part p, step ks, hi/lo v) sits at btab[((p * KSTEPS + ks) * 2 + v) * 64]
-  bf16x8 bc[4], bn[4];                                  // cos hi, cos lo, sin hi, sin lo of the current / next k-step
-  bf16x8 ac[4], an[4];                                  // sample fragments (cos hi, cos lo, sin hi, sin lo images), likewise
+  // table fragments through buffer loads: ONE per-lane offset register (lane * 16), everything else - wave, part, k-step, hi/lo -
+  // in the scalar offset (the 53-KiB span of a wave's slice is far beyond a global load's immediate range, and flat addressing
+  // kept several 64-bit base pointers alive through the MFMA loop)
+  const __amdgpu_buffer_rsrc_t trs = __builtin_amdgcn_make_buffer_rsrc(const_cast<uint16_t*>(&tab->dft[0][0][0][0][0][0]), 0, (int)sizeof(tab->dft), 0x00020000);
+  const int wu = __builtin_amdgcn_readfirstlane(w);
+  // DFT-matrix fragments (cos hi, cos lo, sin hi, sin lo) travel TWO k-steps ahead of their MFMAs through a ring of three
+  // register sets: one step (6 MFMAs = 192 cycles) is far less than the L2 round trip they come from - with a single step of
+  // look-ahead every k-step ended in a wait for the table.  The sample fragments (LDS) stay one step ahead.  The loop is
+  // unrolled so that the ring indices are static; the scheduling fences keep hipcc from hoisting all 52 table loads at once.
+  bf16x8 bt[3][4];
+  bf16x8 ac[2][4];
+  auto load_b = [&](int ks, bf16x8* dst) {
 #pragma unroll
-  for (int v = 0; v < 2; ++v) { bc[v] = btab[(0 * KSTEPS * 2 + v) * 64]; bc[2 + v] = btab[(1 * KSTEPS * 2 + v) * 64]; }
-#pragma unroll
-  for (int q = 0; q < 4; ++q) ac[q] = *reinterpret_cast<const bf16x8*>(arow + (q * FT) * AROW);
-#pragma unroll 1
-  for (int ks = 0; ks < KSTEPS; ++ks) {
-    if (ks + 1 < KSTEPS) {                               // both operands of the NEXT k-step are requested before this step's MFMAs
-#pragma unroll
-      for (int v = 0; v < 2; ++v) {
-        bn[v] = btab[((0 * KSTEPS + ks + 1) * 2 + v) * 64];
-        bn[2 + v] = btab[((1 * KSTEPS + ks + 1) * 2 + v) * 64];
-      }
-#pragma unroll
-      for (int q = 0; q < 4; ++q) an[q] = *reinterpret_cast<const bf16x8*>(arow + (q * FT) * AROW + (ks + 1) * 16);
+    for (int v = 0; v < 2; ++v) {
+      dst[v] = __builtin_bit_cast(bf16x8, __builtin_amdgcn_raw_buffer_load_b128(trs, lane * 16, ((((wu * 2 + 0) * KSTEPS + ks) * 2 + v) * 64) * 16, 0));
+      dst[2 + v] = __builtin_bit_cast(bf16x8, __builtin_amdgcn_raw_buffer_load_b128(trs, lane * 16, ((((wu * 2 + 1) * KSTEPS + ks) * 2 + v) * 64) * 16, 0));
     }
-    are = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ac[1], bc[0], are, 0, 0, 0);     // small terms first
-    are = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ac[0], bc[1], are, 0, 0, 0);
-    are = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ac[0], bc[0], are, 0, 0, 0);
-    aim = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ac[3], bc[2], aim, 0, 0, 0);
-    aim = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ac[2], bc[3], aim, 0, 0, 0);
-    aim = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ac[2], bc[2], aim, 0, 0, 0);
+  };
+  auto load_a = [&](int ks, bf16x8* dst) {
 #pragma unroll
-    for (int v = 0; v < 4; ++v) { bc[v] = bn[v]; ac[v] = an[v]; }
+    for (int q = 0; q < 4; ++q) dst[q] = *reinterpret_cast<const bf16x8*>(arow + (q * FT) * AROW + ks * 16);
+  };
+  load_b(0, bt[0]);
+  load_b(1, bt[1]);
+  load_a(0, ac[0]);
+#pragma unroll
+  for (int ks = 0; ks < KSTEPS; ++ks) {
+    __builtin_amdgcn_sched_barrier(0);
+    if (ks + 2 < KSTEPS) load_b(ks + 2, bt[(ks + 2) % 3]);
+    if (ks + 1 < KSTEPS) load_a(ks + 1, ac[(ks + 1) & 1]);
+    __builtin_amdgcn_sched_barrier(0);
+    const bf16x8* bc = bt[ks % 3];
+    const bf16x8* aa = ac[ks & 1];
+    are = __builtin_amdgcn_mfma_f32_32x32x16_bf16(aa[1], bc[0], are, 0, 0, 0);     // small terms first
+    aim = __builtin_amdgcn_mfma_f32_32x32x16_bf16(aa[3], bc[2], aim, 0, 0, 0);
+    are = __builtin_amdgcn_mfma_f32_32x32x16_bf16(aa[0], bc[1], are, 0, 0, 0);
+    aim = __builtin_amdgcn_mfma_f32_32x32x16_bf16(aa[2], bc[3], aim, 0, 0, 0);
+    are = __builtin_amdgcn_mfma_f32_32x32x16_bf16(aa[0], bc[0], are, 0, 0, 0);
+    aim = __builtin_amdgcn_mfma_f32_32x32x16_bf16(aa[2], bc[2], aim, 0, 0, 0);
   }
   __syncthreads();                                       // every wave is done with the images: pw may overlay them
   // power tile -> LDS [frame][bin]
@@ -140,9 +171,20 @@ __global__ __launch_bounds__(NW * 64) void fbank_tile_kernel(const int16_t* __re
   // no longer need: the dot products below then read only LDS instead of walking global memory per term
   float* melw = xs;
   int* mtab = reinterpret_cast<int*>(xs + MELW_MAX);
-  for (int i = tid; i < MELW_MAX; i += NW * 64) melw[i] = tab->melw[i];
-  for (int i = tid; i < NMEL; i += NW * 64) { mtab[i] = tab->mstart[i]; mtab[NMEL + i] = tab->mlen[i]; mtab[2 * NMEL + i] = tab->moff[i]; }
+  {
+    constexpr int NLD = (MELW_MAX + NW * 64 - 1) / (NW * 64);  // all requests first (the rolled loops waited for each load in turn)
+    float wv[NLD];
+    int tv[3] = {0, 0, 0};
+#pragma unroll
+    for (int i = 0; i < NLD; ++i) wv[i] = tab->melw[min(tid + i * (NW * 64), MELW_MAX - 1)];
+    if (tid < NMEL) { tv[0] = tab->mstart[tid]; tv[1] = tab->mlen[tid]; tv[2] = tab->moff[tid]; }
+#pragma unroll
+    for (int i = 0; i < NLD; ++i)
+      if (tid + i * (NW * 64) < MELW_MAX) melw[tid + i * (NW * 64)] = wv[i];
+    if (tid < NMEL) { mtab[tid] = tv[0]; mtab[NMEL + tid] = tv[1]; mtab[2 * NMEL + tid] = tv[2]; }
+  }
   __syncthreads();
+  stamp();
   for (int o = tid; o < FT * NMEL; o += NW * 64) {
     const int frame = o / NMEL, m = o - frame * NMEL;
     const int t = t0 + frame;
@@ -150,9 +192,12 @@ __global__ __launch_bounds__(NW * 64) void fbank_tile_kernel(const int16_t* __re
       const int st = mtab[m], ln = mtab[NMEL + m], of = mtab[2 * NMEL + m];
       float acc = 0.f;
       for (int i = 0; i < ln; ++i) acc += pw[frame * PW_STRIDE + st + i] * melw[of + i];
-      L[((int64_t)b * T + t) * NMEL + m] = 10.0f * log10f(fmaxf(acc, 1e-10f));
+      // 10 log10(x) on the hardware log2 unit (v_log_f32, ~1 ulp of log2 - far below the bf16 rounding of the feature): libm's
+      // log10f was ~half of this phase (2560 calls per tile)
+      L[((int64_t)b * T + t) * NMEL + m] = 3.0102999566398120f * __log2f(fmaxf(acc, 1e-10f));
     }
   }
+  stamp();
 }
 
 __global__ __launch_bounds__(256) void fbank_norm_kernel(const float* __restrict__ L, int T, bf16_t* __restrict__ feats,
@@ -284,7 +329,7 @@ extern "C" int sdk_fbank(sdk_ctx* ctx, const int16_t* pcm, int B, int S, const v
   {
   ProfScope ps(ctx, stream, SDK_K_FBANK_TILE, 3 * 2.0 * B * T * (double)NSYM * 2 * (NW * 32) + 2.0 * B * T * NBIN * NMEL, 2.0 * B * S + 4.0 * B * T * NMEL);
   hipLaunchKernelGGL(fbank_tile_kernel, dim3(B * tps), dim3(NW * 64), 0, (hipStream_t)stream, pcm, S, T, tps,
-                     (const FbankTables*)tabs, (float*)ws);
+                     (const FbankTables*)tabs, (float*)ws, (unsigned long long*)ctx->dbg_ptr);
   }
   SDK_LAUNCH_CHECK();
   ProfScope ps2(ctx, stream, SDK_K_FBANK_NORM, 3.0 * B * T * NMEL, 4.0 * B * T * NMEL + 2.0 * B * T * ldf);
