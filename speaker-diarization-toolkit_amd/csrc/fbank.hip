@@ -239,6 +239,65 @@ __global__ __launch_bounds__(256) void fbank_norm_kernel(const float* __restrict
   }
 }
 
+// The same per-segment normalisation with the segment's [T x 80] log-mel tile held in LDS: ONE sweep over HBM (16-byte loads, eight in
+// flight per thread), the maximum / the means / the output all come from LDS.  The streaming form above walks global memory three
+// times with a load - wait - use loop (63 dependent round trips per sweep at T = 201); it stays for segments whose tile exceeds LDS.
+// Arithmetic (and its order per mel bin: frames g, g + 3, ... per thread, three partial sums) is the streaming form's, so the
+// features are bit-identical.
+constexpr int NORM_LDS_MAX_T = 480;                      // 480 x 80 x 4 B = 150 KiB
+__global__ __launch_bounds__(256) void fbank_norm_lds_kernel(const float* __restrict__ L, int T, bf16_t* __restrict__ feats,
+                                                            int ldf) {
+  extern __shared__ __attribute__((aligned(16))) float tile[];
+  __shared__ float red[256];
+  __shared__ float mean[NMEL];
+  const int tid = threadIdx.x;
+  const int n4 = T * (NMEL / 4);
+  const f32x4* Ls = reinterpret_cast<const f32x4*>(L + (int64_t)blockIdx.x * T * NMEL);
+  float mx = -INFINITY;
+  constexpr int UN = 8;
+  for (int i0 = tid; i0 < n4; i0 += 256 * UN) {
+    f32x4 v[UN];
+#pragma unroll
+    for (int u = 0; u < UN; ++u) v[u] = Ls[min(i0 + 256 * u, n4 - 1)];
+#pragma unroll
+    for (int u = 0; u < UN; ++u) {
+      const int i = i0 + 256 * u;
+      if (i < n4) {
+        reinterpret_cast<f32x4*>(tile)[i] = v[u];
+        mx = fmaxf(fmaxf(mx, fmaxf(v[u][0], v[u][1])), fmaxf(v[u][2], v[u][3]));
+      }
+    }
+  }
+  red[tid] = mx;
+  __syncthreads();
+  for (int o = 128; o > 0; o >>= 1) {
+    if (tid < o) red[tid] = fmaxf(red[tid], red[tid + o]);
+    __syncthreads();
+  }
+  const float flo = red[0] - 80.0f;
+  __syncthreads();
+  const int m = tid % NMEL, g = tid / NMEL;
+  float s = 0.f;
+  if (g < 3)
+    for (int t = g; t < T; t += 3) s += fmaxf(tile[t * NMEL + m], flo);
+  red[tid] = s;
+  __syncthreads();
+  if (tid < NMEL) mean[tid] = (red[tid] + red[tid + NMEL] + red[tid + 2 * NMEL]) / (float)T;
+  __syncthreads();
+  const int c8n = ldf >> 3;
+  bf16_t* out = feats + (int64_t)blockIdx.x * T * ldf;
+  for (int i = tid; i < T * c8n; i += 256) {
+    const int t = i / c8n, c8 = i - t * c8n;
+    float f[8];
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+      const int c = c8 * 8 + e;
+      f[e] = c < NMEL ? fmaxf(tile[t * NMEL + c], flo) - mean[c] : 0.f;
+    }
+    *reinterpret_cast<u32x4*>(out + (int64_t)t * ldf + c8 * 8) = pack8(f);
+  }
+}
+
 }  // namespace
 
 extern "C" size_t sdk_fbank_tables_bytes(void) { return sizeof(FbankTables); }
@@ -333,8 +392,13 @@ extern "C" int sdk_fbank(sdk_ctx* ctx, const int16_t* pcm, int B, int S, const v
   }
   SDK_LAUNCH_CHECK();
   ProfScope ps2(ctx, stream, SDK_K_FBANK_NORM, 3.0 * B * T * NMEL, 4.0 * B * T * NMEL + 2.0 * B * T * ldf);
-  hipLaunchKernelGGL(fbank_norm_kernel, dim3(B), dim3(256), 0, (hipStream_t)stream, (const float*)ws, T,
-                     (bf16_t*)feats, ldf);
+  if (T <= NORM_LDS_MAX_T) {
+    const int lds = T * NMEL * 4;
+    if (sdk_lds_optin(ctx, (const void*)fbank_norm_lds_kernel, NORM_LDS_MAX_T * NMEL * 4)) return 1;   // (opt-in is per function: the maximum)
+    hipLaunchKernelGGL(fbank_norm_lds_kernel, dim3(B), dim3(256), lds, (hipStream_t)stream, (const float*)ws, T, (bf16_t*)feats, ldf);
+  } else {
+    hipLaunchKernelGGL(fbank_norm_kernel, dim3(B), dim3(256), 0, (hipStream_t)stream, (const float*)ws, T, (bf16_t*)feats, ldf);
+  }
   SDK_LAUNCH_CHECK();
   return 0;
 }

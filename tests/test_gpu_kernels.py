@@ -225,7 +225,7 @@ def _pcm(B, S, seed):
     return np.clip(np.round(x * 32768), -32768, 32767).astype(np.int16)
 
 
-@pytest.mark.parametrize("B,S", [(3, 32000), (2, 16000), (1, 4805), (2, 800)])
+@pytest.mark.parametrize("B,S", [(3, 32000), (2, 16000), (1, 4805), (2, 800), (2, 80000)])   # 80000 samples: T = 501 > the LDS-tile normaliser's limit
 def test_fbank(engine, B, S):
     pcm = _pcm(B, S, 11)
     feats = engine.fbank(torch.from_numpy(pcm).cuda())
