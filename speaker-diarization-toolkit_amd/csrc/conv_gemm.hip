@@ -472,8 +472,16 @@ __global__ __launch_bounds__(NT2, 2) void conv_gemm256_kernel(Params p) {
       mma_half(a0, b1, 0, 1);
       __builtin_amdgcn_sched_barrier(0);
       if (t + 1 < nk) {
+        // diagnostics (tune bit 7 = gemm_variant 2050, tools/gemm_kstep.py): where a K-step waits.  Measured: MFMA time 1.02-1.14 us of a
+        // 1.56-1.64-us step; ~0.3 us waiting for the wave's own DMA of the next step and ~0.1-0.2 us at the barrier.  Pulling the A lines
+        // into L2 two steps early (one 4-byte LDS-DMA "touch" per row and wave, younger than the DMA pieces so the counted wait leaves it
+        // in flight) moved the wait from the vmcnt to the barrier - their sum stayed ~0.5 us - and cost 2-4 % wall time: what the
+        // step waits for is the slowest wave's eight LDS-DMA issues (100-185 cycles each beside ds_reads), not HBM latency.
+        if (p.tune & 128) stamp();
         asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+        if (p.tune & 128) stamp();
         __builtin_amdgcn_s_barrier();
+        if (p.tune & 128) stamp();
         if (dma_early && t + 2 < nk) issue(t + 2, t & 1);
         const char* sn = smem + ((t + 1) & 1) * STAGE2;
         ldB(sn, b0, c0);
