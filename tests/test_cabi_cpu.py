@@ -110,6 +110,39 @@ def test_weight_packing_layout():
     assert W.DEFAULT_CONFIG.param_count() == 20_767_552 and W.DEFAULT_CONFIG.macs_per_frame() == 18_743_296
 
 
+def test_fragment_ordered_weight_copies():
+    """The optional blob slots that hold weights a second time in MFMA fragment order (ecapa_layout.h EL_CHAINPACK, EL_ASP_W2PACK):
+    every 16-byte piece must be exactly the piece of the row-major matrix the kernels' strided loads would fetch."""
+    W, WP = sub("weights"), sub("weights_pack")
+    rng = np.random.default_rng(3)
+    wk = rng.integers(0, 65536, (128, 384), dtype=np.uint16)
+    o = WP.chain_fragment_order(wk)
+    assert o.shape == (3, 4, 2, 4, 64, 8)
+    for tap, wq, h, ks, lane in ((0, 0, 0, 0, 0), (2, 3, 1, 2, 37), (1, 2, 0, 3, 63), (2, 0, 1, 1, 16)):
+        row, k0 = 32 * wq + 16 * h + (lane & 15), 128 * tap + 32 * ks + 8 * (lane >> 4)
+        assert np.array_equal(o[tap, wq, h, ks, lane], wk[row, k0:k0 + 8])
+    assert np.array_equal(np.sort(o.reshape(-1)), np.sort(wk.reshape(-1)))            # a permutation of the matrix
+    w2 = rng.integers(0, 65536, (3072, 128), dtype=np.uint16)
+    q = WP.asp_w2_fragment_order(w2)
+    assert q.shape == (96, 8, 64, 8)
+    for blk, ks, lane in ((0, 0, 0), (95, 7, 63), (17, 3, 40), (50, 5, 31)):
+        assert np.array_equal(q[blk, ks, lane], w2[32 * blk + (lane & 31), 16 * ks + 8 * (lane >> 5):16 * ks + 8 * (lane >> 5) + 8])
+    assert np.array_equal(np.sort(q.reshape(-1)), np.sort(w2.reshape(-1)))
+    # ... and the packer fills the slots for the full-size configuration
+    cfg = W.DEFAULT_CONFIG
+    blob, f = WP.pack_weights(W.synthetic_weights(1, cfg), cfg)
+    off = f["off"]
+    for i in range(1, 4):
+        for j in range(7):
+            a = off[WP.chainpack_slot(i, j)]
+            assert a >= 0
+            plain = blob[off[WP.block_base(i) + WP.res2net_slot(j) + WP.EL_W]:][:128 * 384 * 2].view(np.uint16).reshape(128, 384)
+            assert np.array_equal(blob[a:a + 98304].view(np.uint16).reshape(3, 4, 2, 4, 64, 8), WP.chain_fragment_order(plain))
+    t = WP.tail_base(3)
+    plain = blob[off[t + WP.EL_ASP_W2]:][:3072 * 128 * 2].view(np.uint16).reshape(3072, 128)
+    assert np.array_equal(blob[off[t + WP.EL_ASP_W2PACK]:][:3072 * 128 * 2].view(np.uint16).reshape(96, 8, 64, 8), WP.asp_w2_fragment_order(plain))
+
+
 def test_bf16_bits_roundtrip():
     WP = sub("weights_pack")
     import torch

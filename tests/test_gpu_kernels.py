@@ -363,6 +363,30 @@ def test_affinity_near_duplicates_force_rescan(engine):
     assert cnt >= 30, f"only {cnt} rows took the exact rescan; the construction should force ~40"
 
 
+def test_affinity_rescan_is_deterministic_and_sliced(engine):
+    """The k = 1 exact rescan splits the profiles of a flagged row quad into slices that meet through agent-scope atomics (64-bit
+    (score, index) keys + an arrival counter): whichever slice arrives last, the answer must be the oracle's - many flagged rows,
+    several slices per quad, repeated runs."""
+    P = 1024
+    base = _unit(64, 192, 7)
+    Pm = np.concatenate([base + (1e-4 * q) * _unit(64, 192, 200 + q) for q in range(P // 64)], 0)   # 16 near-copies of every direction
+    E = _unit(3000, 192, 8)
+    E[:1500] = base[np.arange(1500) % 64] + 0.05 * _unit(1500, 192, 9)
+    ref = None
+    for rep in range(6):
+        idx, sc, cnt, En, Pn = _score_gpu(engine, E, Pm, 1)
+        if ref is None:
+            ref = (idx.copy(), sc.copy())
+            oidx, osc = oscoring.affinity_topk(En, Pn, 1)
+            full = (En.astype(np.float64) @ Pn.astype(np.float64).T)
+            assert np.abs(sc - osc).max() <= 1e-5
+            for n in np.argwhere(idx[:, 0] != oidx[:, 0]).flatten():
+                assert abs(full[n, idx[n, 0]] - full[n, oidx[n, 0]]) <= 2e-7, n
+            assert cnt >= 1000, f"only {cnt} rows took the exact rescan"
+        else:
+            assert np.array_equal(idx, ref[0]) and np.array_equal(sc, ref[1]), f"run {rep} differs"
+
+
 def test_affinity_threshold_assignment(engine):
     """Config #2 shape: 1000 segments x 100 profiles, threshold 0.354 (the ABC default)."""
     E, Pm = _unit(1000, 192, 0), _unit(100, 192, 1)
