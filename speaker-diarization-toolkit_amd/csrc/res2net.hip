@@ -10,9 +10,11 @@
 //   LDS: two [TP rows][128 ch] bf16 images (256-B rows, 16-B chunk index XOR (row & 15): the 16 rows of a
 //        ds_read_b128 lane group land on 16 distinct slots whatever the tap shift).
 //   MFMA: 2 x 4 waves: half of the MT row tiles x 32 output channels each, so a frame fragment read from LDS
-//        feeds two MFMAs; weight fragments (L2-resident) are prefetched one whole tap (4 k-steps) ahead;
-//        the weight fragment is the row operand, so the epilogue packs 4 channels into one 8-byte LDS write;
-//        the next chunk of u is prefetched into registers across the conv.
+//        feeds two MFMAs; weight fragments (L2-resident; from the blob's fragment-ordered copy when present: one
+//        contiguous KiB per load) are prefetched one whole tap (4 k-steps) ahead; the weight fragment is the row
+//        operand, so the epilogue packs 4 channels into one 8-byte LDS write; the next chunk of u is requested
+//        BEHIND the conv's last weight prefetch (vmcnt retires in order) and waited for after the epilogue.
+//   u and y move through buffer instructions (uniform resource + one 32-bit lane offset + scalar pass offset).
 //   Arithmetic order is identical to seven conv_gemm launches (tap-major, 32-wide k-steps, fp32 epilogue,
 //   bf16 rounding points), so results are bit-identical to the unfused schedule.
 #include "common.hpp"
