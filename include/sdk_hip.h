@@ -65,7 +65,8 @@ int sdk_shutdown(sdk_ctx* ctx);
 const char* sdk_last_error(void);
 int sdk_get_device_info(sdk_ctx* ctx, sdk_device_info* out);
 /* A/B and test knobs: "res2net_chain_fusion" (1 default / 0 = seven conv_gemm launches), "res2net_packed_weights" (1 default /
- * 0 = the chain ignores the blob's optional fragment-ordered weight copies, ecapa_layout.h EL_CHAINPACK), "asp_packed_weights"
+ * 0 = the chain ignores the blob's optional fragment-ordered weight copies, ecapa_layout.h EL_CHAINPACK), "res2net_two_per_cu" (1 default /
+ * 0 = 8-wave workgroups, one segment per CU), "asp_packed_weights"
  * (likewise for the ASP logit weights, EL_ASP_W2PACK), "asp_per_segment"
  * (1 default / 0 = one workgroup per (segment, 128 channels)), "affinity_fast_path" / "affinity_variant" /
  * "affinity_whole_groups" (k = 1 affinity kernel selection), "gemm_variant" (see sdk_set_gemm_variant).  Results do not

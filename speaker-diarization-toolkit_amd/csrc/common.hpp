@@ -29,6 +29,7 @@ struct sdk_ctx {
   hipDeviceProp_t prop;
   bool prof_on = false;
   bool no_chain_fusion = false;   // A/B + test knob: run the Res2Net chain as separate conv_gemm launches
+  bool no_chain_two_per_cu = false;   // A/B + test knob: the Res2Net chain as 8-wave workgroups, one segment per CU ("res2net_two_per_cu" 0)
   bool no_chain_packed = false;   // A/B + test knob: ignore the fragment-ordered copies of the Res2Net chain weights (EL_CHAINPACK)
   bool no_asp_packed = false;     // A/B + test knob: ignore the fragment-ordered copy of the ASP logit weights (EL_ASP_W2PACK)
   bool no_asp_seg = false;        // A/B + test knob: ASP by (segment, 128-channel) workgroups instead of one per segment

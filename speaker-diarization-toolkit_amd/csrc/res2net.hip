@@ -251,6 +251,185 @@ __global__ __launch_bounds__(RNT, 2) void res2net_chain_kernel(ChainParams p) {
   if (p.dbg && tid == 0 && blockIdx.x < 256) p.dbg[blockIdx.x * 64 + 1] = nstamp;
 }
 
+
+// ---- The same chain with TWO segments per CU --------------------------------------------------------------------------------
+// The kernel above spends 43 % of a conv outside the taps (epilogue, a barrier, the y pass), with one workgroup per CU: the matrix
+// pipe idles meanwhile.  Here a workgroup is 4 waves (one per SIMD, 256 registers each) and keeps ONE image, written in place, so
+// two workgroups (two segments) fit a CU and one's epilogue / y pass / barriers run under the other's taps.
+//   wave wq owns output channels [32 wq, 32 wq + 32) of ALL MT row tiles (a frame fragment still feeds two MFMAs);
+//   in place: the taps read s_c (halo included) from the image, a barrier, the epilogue writes y_c over it, a barrier, the y pass
+//   stores y_c and writes s_{c+1} = bf16(y_c + u_{c+1}) - three barriers per conv instead of two, hidden by the other workgroup;
+//   u_{c+1} is requested at the top of the epilogue (behind the next conv's tap-0 weights, which are pinned first).
+// Same arithmetic order: bit-identical to the 8-wave kernel and to seven conv_gemm launches.
+constexpr int RNT4 = 256;
+template <int MT, bool PACKED>
+__global__ __launch_bounds__(RNT4, 2) void res2net_chain4_kernel(ChainParams p) {
+  constexpr int TP = MT * 16;
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  const int tid = threadIdx.x, lane = tid & 63, wq = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int fr = lane & 15, fq = lane >> 4;
+  const int T = p.T;
+  const int64_t base = (int64_t)blockIdx.x * T;
+  constexpr int NPASS = (TP * 16 + RNT4 - 1) / RNT4;  // 16-byte chunks per thread per tile pass (13 at MT = 13)
+  auto lds_off = [](int row, int ch16) { return row * 256 + ((ch16 ^ (row & 15)) << 4); };
+  char* img = smem;
+  float* par = reinterpret_cast<float*>(smem + TP * 256);
+  // epilogue parameters: wave w fetches convs w and w + 4 (uniform pointers, 2 floats per lane)
+  float2 pv[2][3] = {};
+#pragma unroll
+  for (int q = 0; q < 2; ++q) {
+    const int cc = wq + 4 * q;
+    if (cc < p.nconv) {
+      pv[q][0] = reinterpret_cast<const float2*>(p.bias[cc])[lane];
+      pv[q][1] = reinterpret_cast<const float2*>(p.scale[cc])[lane];
+      pv[q][2] = reinterpret_cast<const float2*>(p.shift[cc])[lane];
+    }
+  }
+  // tile passes: thread -> (row r0 + 16 i, 16-byte chunk c16): 16 i leaves row & 15 alone -> one LDS / u / y offset per lane
+  const int r0 = tid >> 4, c16 = tid & 15;
+  const int nrow = (T - r0 + 15) >> 4;                      // passes with row < T
+  const int loff = lds_off(r0, c16);
+  const uint32_t uoff = ((uint32_t)r0 * (uint32_t)p.ldu + (uint32_t)c16 * 8u) * 2u, ustride = 32u * (uint32_t)p.ldu;
+  const uint32_t ulast = ((uint32_t)(T - 1) * (uint32_t)p.ldu + (uint32_t)c16 * 8u) * 2u;
+  const uint32_t yoff = ((uint32_t)r0 * (uint32_t)p.ldr + (uint32_t)c16 * 8u) * 2u, ystride = 32u * (uint32_t)p.ldr;
+  const __amdgpu_buffer_rsrc_t urs = __builtin_amdgcn_make_buffer_rsrc(const_cast<bf16_t*>(p.U + base * p.ldu), 0, (int)((uint32_t)T * (uint32_t)p.ldu * 2u), 0x00020000);
+  const __amdgpu_buffer_rsrc_t yrs = __builtin_amdgcn_make_buffer_rsrc(p.R + base * p.ldr, 0, (int)((uint32_t)T * (uint32_t)p.ldr * 2u), 0x00020000);
+  auto uload = [&](int i, int ch) -> u32x4 {
+    return __builtin_amdgcn_raw_buffer_load_b128(urs, i < nrow ? uoff : ulast - (uint32_t)i * ustride, (uint32_t)i * ustride + (uint32_t)(ch * RS * 2), 0);
+  };
+  {
+    u32x4 v[NPASS];
+#pragma unroll
+    for (int i = 0; i < NPASS; ++i) v[i] = uload(i, 1);
+#pragma unroll
+    for (int q = 0; q < 2; ++q) {
+      const int cc = wq + 4 * q;
+      if (cc < p.nconv) {
+#pragma unroll
+        for (int w = 0; w < 3; ++w) reinterpret_cast<float2*>(par + cc * (3 * RS) + w * RS)[lane] = pv[q][w];
+      }
+    }
+#pragma unroll
+    for (int i = 0; i < NPASS; ++i)
+      if (r0 + 16 * i < TP) *reinterpret_cast<u32x4*>(img + loff + i * (16 * 256)) = i < nrow ? v[i] : u32x4{0u, 0u, 0u, 0u};
+  }
+  const int64_t wofs0 = (int64_t)(wq * 32 + fr) * (3 * RS) + fq * 8;
+  const int64_t wofs1 = wofs0 + (int64_t)16 * (3 * RS);
+  int ebase[2];
+#pragma unroll
+  for (int h = 0; h < 2; ++h) ebase[h] = lds_off(fr, wq * 4 + h * 2 + (fq >> 1)) + (fq & 1) * 8;
+  auto wfrag = [&](int cc, int tap, int h, int ks) -> bf16x8 {
+    if constexpr (PACKED)
+      return *reinterpret_cast<const bf16x8*>(p.Wpk[cc] + ((((tap * 4 + wq) * 2 + h) * 4 + ks) * 64 + lane) * 8);
+    else
+      return *reinterpret_cast<const bf16x8*>(p.W[cc] + tap * RS + (h ? wofs1 : wofs0) + ks * 32);
+  };
+  bf16x8 bcur[2][4];
+#pragma unroll
+  for (int ks = 0; ks < 4; ++ks) {
+    bcur[0][ks] = wfrag(0, 0, 0, ks);
+    bcur[1][ks] = wfrag(0, 0, 1, ks);
+  }
+#pragma unroll
+  for (int ks = 0; ks < 4; ++ks) {
+    asm volatile("" : "+v"(bcur[0][ks]));
+    asm volatile("" : "+v"(bcur[1][ks]));
+  }
+  for (int c = 1; c <= p.nconv; ++c) {
+    __syncthreads();                                        // s_c complete in the image
+    f32x4 acc[MT][2];
+#pragma unroll
+    for (int mi = 0; mi < MT; ++mi) acc[mi][0] = acc[mi][1] = f32x4{0.f, 0.f, 0.f, 0.f};
+    bf16x8 bnext[2][4];
+    auto tap = [&](const int j) {
+      const int off = (j - 1) * p.dil;
+      const int ncc = j < 2 ? c - 1 : min(c, p.nconv - 1), ntap = j < 2 ? j + 1 : 0;
+#pragma unroll
+      for (int ks = 0; ks < 4; ++ks) {
+        bnext[0][ks] = wfrag(ncc, ntap, 0, ks);
+        bnext[1][ks] = wfrag(ncc, ntap, 1, ks);
+      }
+      int rr[MT];
+#pragma unroll
+      for (int mi = 0; mi < MT; ++mi) rr[mi] = reflect_idx(min(mi * 16 + fr, TP - 1) + off, T);
+      constexpr int RING = 5, NSTEP = 4 * MT;
+      bf16x8 af[RING];
+      auto rd = [&](int s) {
+        const int ks = s / MT, mi = s % MT;
+        af[s % RING] = *reinterpret_cast<const bf16x8*>(img + rr[mi] * 256 + (((ks * 4 + fq) ^ (rr[mi] & 15)) << 4));
+      };
+#pragma unroll
+      for (int s = 0; s < RING - 1; ++s) rd(s);
+#pragma unroll
+      for (int s = 0; s < NSTEP; ++s) {
+        __builtin_amdgcn_sched_barrier(0);
+        if (s + RING - 1 < NSTEP) rd(s + RING - 1);
+        const int ks = s / MT, mi = s % MT;
+        acc[mi][0] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(bcur[0][ks], af[s % RING], acc[mi][0], 0, 0, 0);
+        acc[mi][1] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(bcur[1][ks], af[s % RING], acc[mi][1], 0, 0, 0);
+      }
+      __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+      for (int ks = 0; ks < 4; ++ks) { bcur[0][ks] = bnext[0][ks]; bcur[1][ks] = bnext[1][ks]; }
+    };
+#pragma unroll 1
+    for (int j = 0; j < 3; ++j) tap(j);
+    // the next conv's tap-0 weights have arrived (pinned: no later wait may sit behind the u loads or the y stores)
+#pragma unroll
+    for (int ks = 0; ks < 4; ++ks) {
+      asm volatile("" : "+v"(bcur[0][ks]));
+      asm volatile("" : "+v"(bcur[1][ks]));
+    }
+    u32x4 upre[NPASS];
+#pragma unroll
+    for (int i = 0; i < NPASS; ++i) upre[i] = uload(i, min(c + 1, p.nconv));   // has the epilogue and two barriers to arrive
+    __syncthreads();                                        // every wave has read s_c for good: the image may be overwritten
+    f32x4 cb[2], cs[2], ct[2];
+#pragma unroll
+    for (int h = 0; h < 2; ++h) {
+      const float* q = par + (c - 1) * (3 * RS) + wq * 32 + h * 16 + fq * 4;
+      cb[h] = *reinterpret_cast<const f32x4*>(q);
+      cs[h] = *reinterpret_cast<const f32x4*>(q + RS);
+      ct[h] = *reinterpret_cast<const f32x4*>(q + 2 * RS);
+    }
+#pragma unroll
+    for (int mi = 0; mi < MT; ++mi) {
+      if (mi * 16 + fr < T) {
+#pragma unroll
+        for (int h = 0; h < 2; ++h) {
+          f32x4 v = acc[mi][h] + cb[h];
+#pragma unroll
+          for (int e = 0; e < 4; ++e) v[e] = fmaxf(v[e], 0.f);
+          v = v * cs[h] + ct[h];
+          uint2 pk;
+          pk.x = pack2(v[0], v[1]);
+          pk.y = pack2(v[2], v[3]);
+          *reinterpret_cast<uint2*>(img + ebase[h] + mi * (16 * 256)) = pk;
+        }
+      }
+    }
+    __syncthreads();                                        // y_c complete in the image
+#pragma unroll
+    for (int i = 0; i < NPASS; ++i) asm volatile("" : "+v"(upre[i]));
+#pragma unroll
+    for (int i = 0; i < NPASS; ++i) {
+      if (i < nrow) {
+        char* q = img + loff + i * (16 * 256);
+        const u32x4 y = *reinterpret_cast<const u32x4*>(q);
+        __builtin_amdgcn_raw_buffer_store_b128(y, yrs, yoff, (uint32_t)i * ystride + (uint32_t)(c * RS * 2), 0);
+        if (c < p.nconv) {
+          float fy[8], fu[8];
+          unpack8(y, fy);
+          unpack8(upre[i], fu);
+#pragma unroll
+          for (int e = 0; e < 8; ++e) fy[e] += fu[e];
+          *reinterpret_cast<u32x4*>(q) = pack8(fy);
+        }
+      }
+    }
+  }
+}
+
 }  // namespace
 
 extern "C" int sdk_res2net_chain_max_frames(void) { return 208; }
@@ -283,6 +462,13 @@ int res2net_chain_launch(sdk_ctx* ctx, const uint16_t* U, int64_t ldu, uint16_t*
     return 0;
   };
   int rc;
+  if (T > 112 && !ctx->no_chain_two_per_cu) {             // two segments per CU (4-wave workgroups, one image in place)
+    const int lds4 = 208 * 256 + PAR_BYTES;
+    rc = packed ? [&] { if (sdk_lds_optin(ctx, (const void*)res2net_chain4_kernel<13, true>, lds4)) return 1;
+                        hipLaunchKernelGGL((res2net_chain4_kernel<13, true>), dim3(B), dim3(RNT4), lds4, (hipStream_t)stream, p); return 0; }()
+                : [&] { if (sdk_lds_optin(ctx, (const void*)res2net_chain4_kernel<13, false>, lds4)) return 1;
+                        hipLaunchKernelGGL((res2net_chain4_kernel<13, false>), dim3(B), dim3(RNT4), lds4, (hipStream_t)stream, p); return 0; }();
+  } else
   if (T <= 112) rc = packed ? launch(res2net_chain_kernel<7, true>, 2 * 112 * 256 + PAR_BYTES) : launch(res2net_chain_kernel<7, false>, 2 * 112 * 256 + PAR_BYTES);
   else rc = packed ? launch(res2net_chain_kernel<13, true>, 2 * 208 * 256 + PAR_BYTES) : launch(res2net_chain_kernel<13, false>, 2 * 208 * 256 + PAR_BYTES);
   if (rc) return rc;

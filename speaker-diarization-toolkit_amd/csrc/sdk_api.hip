@@ -80,6 +80,7 @@ extern "C" int sdk_set_option(sdk_ctx* ctx, const char* name, int value) {
   SDK_REQUIRE(ctx && name, "sdk_set_option: null argument");
   if (strcmp(name, "res2net_chain_fusion") == 0) { ctx->no_chain_fusion = value == 0; return 0; }
   if (strcmp(name, "res2net_packed_weights") == 0) { ctx->no_chain_packed = value == 0; return 0; }
+  if (strcmp(name, "res2net_two_per_cu") == 0) { ctx->no_chain_two_per_cu = value == 0; return 0; }
   if (strcmp(name, "asp_packed_weights") == 0) { ctx->no_asp_packed = value == 0; return 0; }
   if (strcmp(name, "asp_per_segment") == 0) { ctx->no_asp_seg = value == 0; return 0; }
   if (strcmp(name, "gemm_variant") == 0) return sdk_set_gemm_variant(value);

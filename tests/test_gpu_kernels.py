@@ -592,6 +592,13 @@ def test_res2net_chain_fusion_is_bit_identical(engine, B, T):
     finally:
         engine.set_option("res2net_packed_weights", 1)
     assert torch.equal(ref, plain), float((ref - plain).abs().max())
+    # ... and the 8-wave one-segment-per-CU form of the chain (the default for T > 112 is two 4-wave workgroups per CU, one image in place)
+    try:
+        engine.set_option("res2net_two_per_cu", 0)
+        plain = engine.ecapa_forward(f, B, T).cpu()
+    finally:
+        engine.set_option("res2net_two_per_cu", 1)
+    assert torch.equal(ref, plain), float((ref - plain).abs().max())
     # ... and the per-segment ASP kernel with the row-major logit weights instead of their fragment-ordered copy (EL_ASP_W2PACK)
     try:
         engine.set_option("asp_packed_weights", 0)

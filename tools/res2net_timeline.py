@@ -9,6 +9,7 @@ ops = importlib.import_module("speaker-diarization-toolkit_amd.ops")
 eng = ops.get_engine(0)
 B, T = 1000, 201
 feats = (torch.randn(B * T, 128, device="cuda") * 0.5).bfloat16()
+eng.set_option("res2net_two_per_cu", 0)      # the stamps live in the 8-wave kernel
 for _ in range(3): eng.ecapa_forward(feats, B, T)
 buf = torch.zeros(256 * 64, dtype=torch.int64, device="cuda")
 eng.debug_ptr("stamps", buf)
