@@ -271,6 +271,11 @@ __global__ __launch_bounds__(RNT4, 2) void res2net_chain4_kernel(ChainParams p) 
   const int T = p.T;
   const int64_t base = (int64_t)blockIdx.x * T;
   constexpr int NPASS = (TP * 16 + RNT4 - 1) / RNT4;  // 16-byte chunks per thread per tile pass (13 at MT = 13)
+  int nstamp = 2;
+  auto stamp = [&]() {
+    if (p.dbg && tid == 0 && blockIdx.x < 256 && nstamp < 64) p.dbg[blockIdx.x * 64 + nstamp++] = __builtin_amdgcn_s_memrealtime();
+  };
+  if (p.dbg && tid == 0 && blockIdx.x < 256) p.dbg[blockIdx.x * 64] = __builtin_amdgcn_s_memrealtime();
   auto lds_off = [](int row, int ch16) { return row * 256 + ((ch16 ^ (row & 15)) << 4); };
   char* img = smem;
   float* par = reinterpret_cast<float*>(smem + TP * 256);
@@ -337,6 +342,7 @@ __global__ __launch_bounds__(RNT4, 2) void res2net_chain4_kernel(ChainParams p) 
   }
   for (int c = 1; c <= p.nconv; ++c) {
     __syncthreads();                                        // s_c complete in the image
+    stamp();
     f32x4 acc[MT][2];
 #pragma unroll
     for (int mi = 0; mi < MT; ++mi) acc[mi][0] = acc[mi][1] = f32x4{0.f, 0.f, 0.f, 0.f};
@@ -373,17 +379,13 @@ __global__ __launch_bounds__(RNT4, 2) void res2net_chain4_kernel(ChainParams p) 
       for (int ks = 0; ks < 4; ++ks) { bcur[0][ks] = bnext[0][ks]; bcur[1][ks] = bnext[1][ks]; }
     };
 #pragma unroll 1
-    for (int j = 0; j < 3; ++j) tap(j);
-    // the next conv's tap-0 weights have arrived (pinned: no later wait may sit behind the u loads or the y stores)
-#pragma unroll
-    for (int ks = 0; ks < 4; ++ks) {
-      asm volatile("" : "+v"(bcur[0][ks]));
-      asm volatile("" : "+v"(bcur[1][ks]));
-    }
+    for (int j = 0; j < 3; ++j) { tap(j); stamp(); }
     u32x4 upre[NPASS];
 #pragma unroll
     for (int i = 0; i < NPASS; ++i) upre[i] = uload(i, min(c + 1, p.nconv));   // has the epilogue and two barriers to arrive
+    stamp();
     __syncthreads();                                        // every wave has read s_c for good: the image may be overwritten
+    stamp();
     f32x4 cb[2], cs[2], ct[2];
 #pragma unroll
     for (int h = 0; h < 2; ++h) {
@@ -408,7 +410,16 @@ __global__ __launch_bounds__(RNT4, 2) void res2net_chain4_kernel(ChainParams p) 
         }
       }
     }
+    // the next conv's tap-0 weights (requested at the top of tap 2, OLDER than the u requests) are pinned here, behind the epilogue
+    // they had to arrive under: a counted wait that leaves the u loads in flight, and no later wait can sit behind the y stores
+#pragma unroll
+    for (int ks = 0; ks < 4; ++ks) {
+      asm volatile("" : "+v"(bcur[0][ks]));
+      asm volatile("" : "+v"(bcur[1][ks]));
+    }
+    stamp();
     __syncthreads();                                        // y_c complete in the image
+    stamp();
 #pragma unroll
     for (int i = 0; i < NPASS; ++i) asm volatile("" : "+v"(upre[i]));
 #pragma unroll
@@ -427,7 +438,9 @@ __global__ __launch_bounds__(RNT4, 2) void res2net_chain4_kernel(ChainParams p) 
         }
       }
     }
+    stamp();
   }
+  if (p.dbg && tid == 0 && blockIdx.x < 256) p.dbg[blockIdx.x * 64 + 1] = nstamp;
 }
 
 }  // namespace
