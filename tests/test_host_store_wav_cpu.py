@@ -71,6 +71,40 @@ def test_cut_ranges_never_leaves_a_sentence():
     assert spans == [(0.0, 2.0), (1.0, 3.0), (2.0, 4.0), (2.5, 4.5), (6.0, 8.0)]
 
 
+def test_cut_ranges_properties_on_random_ranges():
+    """Property form of the rule above on arbitrary (also overlapping, out-of-file, tiny) ranges: every window is a true-length bucket,
+    lies inside its range clipped to the file, the windows of a range cover it end to end without gaps, rows of the per-length
+    batches are the file's samples, and exactly the ranges shorter than the smallest bucket are dropped."""
+    from hypothesis import given, settings, strategies as st
+    rate, n = 16000, 16000 * 20
+    x = (np.arange(n, dtype=np.int64) * 7919 % 65536 - 32768).astype(np.int16)
+    rng = st.tuples(st.floats(-1.0, 21.0, allow_nan=False), st.floats(0.0, 9.0, allow_nan=False)).map(lambda t: (t[0], t[0] + t[1]))
+
+    @settings(max_examples=150, deadline=None)
+    @given(st.lists(rng, min_size=0, max_size=12))
+    def check(ranges):
+        pcm_by_len, wins, dropped = wav.cut_ranges(x, ranges)
+        assert set(pcm_by_len) <= {8000, 16000, 24000, 32000}
+        assert sum(len(v) for v in pcm_by_len.values()) == len(wins)
+        by_range = {}
+        for ri, S, row, a, b in wins:
+            lo, hi = max(0, round(ranges[ri][0] * rate)), min(n, round(ranges[ri][1] * rate))
+            ia = round(a * rate)
+            assert lo <= ia and ia + S <= hi and abs((b - a) * rate - S) < 1e-6
+            assert S == max(q for q in (8000, 16000, 24000, 32000) if q <= hi - lo)
+            assert np.array_equal(pcm_by_len[S][row], x[ia:ia + S])
+            by_range.setdefault(ri, []).append((ia, ia + S))
+        for ri, (s0, e0) in enumerate(ranges):
+            lo, hi = max(0, round(s0 * rate)), min(n, round(e0 * rate))
+            if hi - lo < 8000:
+                assert ri in dropped and ri not in by_range
+            else:
+                spans = sorted(by_range[ri])
+                assert ri not in dropped and spans[0][0] == lo and spans[-1][1] == hi
+                assert all(spans[k + 1][0] <= spans[k][1] for k in range(len(spans) - 1))     # no gap between consecutive windows
+    check()
+
+
 def _profile(sid, recs):
     return {"id": sid, "names": {"default": sid.title()}, "embeddings": {"mi355x": recs}}
 
