@@ -336,6 +336,7 @@ __global__ __launch_bounds__(NT2, 2) void conv_gemm256_kernel(Params p) {
   const int rin = lane >> 3, pos = lane & 7;
   const int gch = (pos ^ rin) * 8;                   // source chunk (elements) for this lane's LDS position
   const int wu = __builtin_amdgcn_readfirstlane(wid);
+  const bool a_nt = !TAPS && nbn <= 4 && !(p.tune & 256);      // (gemm_variant 4098 switches the hint off: A/B)
   uint32_t aoff[4];                                  // !TAPS: byte offset of this lane's chunk in each of its 4 A rows (rows step by 8)
   int aseg0 = 0, atl0 = 0;                           // TAPS: segment base row and in-segment frame of the first row
   uint32_t woff;
@@ -366,6 +367,14 @@ __global__ __launch_bounds__(NT2, 2) void conv_gemm256_kernel(Params p) {
         const uint32_t src = (uint32_t)min(sb + reflect_idx(tl + off, p.T), p.M - 1);
         __builtin_amdgcn_global_load_lds((gptr_t)(abase + (size_t)((src * (uint32_t)p.lda + (uint32_t)gch) * 2u)), (lptr_t)(sA + i * 1024), 16, 0, 0);
       }
+    } else if (a_nt) {
+      // A is read exactly ONCE per XCD when the layer has a single n-chunk (N = 1024): fetched non-temporal, its 4 MB per round no
+      // longer push the 2 MB of weights out of the 4-MiB L2, which were re-fetched by every XCD in every round (PMC, tools/pmc_gemm.sh:
+      // 619 -> 429 MB read per launch = 1.04 x A + W; the four readers of a block still hit each other's lines).  Not for wider layers:
+      // on 3072^2 the m-group's A is re-read by three n-chunks from the Infinity Cache, and the hint costs 10 % there.
+#pragma unroll
+      for (int i = 0; i < 4; ++i)
+        __builtin_amdgcn_global_load_lds((gptr_t)(abase + (size_t)aoff[i]), (lptr_t)(sA + i * 1024), 16, 0, 2);
     } else {
 #pragma unroll
       for (int i = 0; i < 4; ++i)
