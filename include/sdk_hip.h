@@ -73,8 +73,10 @@ int sdk_get_device_info(sdk_ctx* ctx, sdk_device_info* out);
  * depend on them. */
 int sdk_set_option(sdk_ctx* ctx, const char* name, int value);
 /* Diagnostics: "stamps" = device buffer [workgroups][64] of uint64 that the affinity kernel (tools/aff_timeline.py) and the
- * Res2Net chain (tools/res2net_timeline.py) fill with in-kernel wall-clock stamps; "gemm_clock" = [workgroups <= 4096][2] uint64 {shader cycles, 100 MHz ticks} of each
- * conv_gemm256 workgroup's lifetime (bench.py: the clock the chip holds inside the dominant kernel).  NULL (default) = off. */
+ * Res2Net chain (tools/res2net_timeline.py) fill with in-kernel wall-clock stamps; "gemm_clock" = EXACTLY [4096][2] uint64 {shader cycles, 100 MHz ticks} of each
+ * conv_gemm256 workgroup's lifetime (bench.py: the clock the chip holds inside the dominant kernel; workgroups >= 4096 do not write);
+ * "gemm_stamps" = EXACTLY [4096] uint64 wall-clock stamps of conv_gemm256 workgroup 0's tile phases (tools/gemm_timeline.py, gemm_kstep.py;
+ * a buffer of its own - the clock probe never writes outside its [4096][2]).  NULL (default) = off. */
 int sdk_debug_set_ptr(sdk_ctx* ctx, const char* name, void* device_ptr);
 
 /* ---- measurement: per-kernel-family HIP-event timing on the launch stream (bench.py roofline) -- */
@@ -247,7 +249,9 @@ int sdk_affinity_topk(sdk_ctx* ctx, const float* E, const uint16_t* Eb, const fl
  *   sdk_rows_gram       : G [k,k] = X^T Y over n rows (order-fixed two-stage reduction)
  *   sdk_rows_apply      : Y[i,:] = scale[i] * (X[i,:] @ R),  R [k,k] row-major, scale may be NULL
  *   sdk_chol_inverse    : Rinv [k,k] = (L^T)^-1 with (G + G^T)/2 = L L^T, float64 inside (CholeskyQR without leaving the stream);
- *                         *not_spd (device, may be NULL) is set to 1 if a pivot was not positive
+ *                         *not_spd (device int32, may be NULL) is SET to 1 if a pivot was not positive or not a number (never cleared:
+ *                         zero it once, run any number of passes, read it at the next host synchronisation); the offending pivot is
+ *                         replaced by 1 so the stream keeps running, the result is then meaningless
  *   sdk_rows_unit       : rows scaled to unit length
  *   sdk_kmeans_mindist  : d2[i] = (first ? : min(d2[i],)) |R[i] - centre|^2      (maximin initialisation)
  *   sdk_kmeans_assign   : label[i] = nearest of kc centres (ties -> lowest), dist2, optional per-256-row-block

@@ -165,6 +165,10 @@ class Backend(EmbeddingBackend):
         batch = load_profile_batch(candidates, self.name, model_prefix=f"{self.name}-", model_version=self.model_version)
         for why in batch.skipped:
             print(f"mi355x backend: skipped embedding {why}", file=sys.stderr)
+        if batch.all_skipped_message():
+            # candidates exist but none is comparable: "no match" would be a lie.  The CLI prints "Error during identification: ..."
+            # and exits 1 (speaker_detection:1072-1074); speaker-assign then records no embedding signal (speaker-assign:296)
+            raise ValueError(batch.all_skipped_message())
         if len(batch) == 0:
             return []
         pcm, spans = self._windows(audio_path, None)

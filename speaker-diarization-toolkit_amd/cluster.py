@@ -93,7 +93,9 @@ def spectral_cluster(provider, E_local: torch.Tensor, Eb_local: torch.Tensor, n_
     # seeded start, same gaussian as the oracle (numpy PCG64), orthonormalised across ranks
     G0 = np.random.default_rng(seed).standard_normal((n_total, k))
     V = torch.from_numpy(G0[lo:hi].astype(np.float32)).to(dev)
-    V = _orth(provider, comm, V, k)
+    # not-positive-definite flag of every CholeskyQR pass (sticky, device side): read once, at the Ritz step's host synchronisation
+    spd_flag = torch.zeros((1,), dtype=torch.int32, device=dev)
+    V = _orth(provider, comm, V, k, spd_flag)
     mark("init")
 
     eye = torch.eye(k, dtype=torch.float32, device=dev)
@@ -106,11 +108,16 @@ def spectral_cluster(provider, E_local: torch.Tensor, Eb_local: torch.Tensor, n_
     for _ in range(n_iter):
         Y = apply_S(V)
         mark("apply_S")
-        V = _orth(provider, comm, Y, k)
+        V = _orth(provider, comm, Y, k, spd_flag)
         mark("orth")
     SV = apply_S(V)
     mark("apply_S")
     H = comm.sum_(provider.rows_gram(V, SV)).double().cpu().numpy()
+    if int(spd_flag.item()) or not np.isfinite(H).all():
+        # a Gram matrix of the iteration was not positive definite: k exceeds the rank of the embeddings (duplicated rows, fewer
+        # distinct segments than clusters) or the input holds NaN.  The host-side CholeskyQR of round 1 raised here too.
+        raise np.linalg.LinAlgError(f"spectral_cluster: the k = {k} subspace lost rank (Gram matrix not positive definite): "
+                                    "fewer than k independent directions in the embeddings, or non-finite input")
     H = 0.5 * (H + H.T)
     lam, Q = np.linalg.eigh(H)
     order = np.argsort(-lam)
@@ -127,12 +134,12 @@ def spectral_cluster(provider, E_local: torch.Tensor, Eb_local: torch.Tensor, n_
     return SpectralResult(labels, lam[order], n_iter, timing)
 
 
-def _orth(provider, comm: _Comm, Y: torch.Tensor, k: int) -> torch.Tensor:
+def _orth(provider, comm: _Comm, Y: torch.Tensor, k: int, spd_flag: Optional[torch.Tensor] = None) -> torch.Tensor:
     """CholeskyQR2: Q = Y R^-1 with R^T R = sum_ranks Y^T Y; applied twice for fp32 stability.  Nothing here synchronises with the
     host: Gram (two-stage, order-fixed) -> all-reduce -> k x k Cholesky + triangular inverse in float64 on the device -> apply."""
     for _ in range(2):
         G = comm.sum_(provider.rows_gram(Y, Y))
-        Y = provider.rows_apply(Y, provider.chol_inverse(G))
+        Y = provider.rows_apply(Y, provider.chol_inverse(G, spd_flag))
     return Y
 
 

@@ -540,6 +540,14 @@ __global__ __launch_bounds__(256) void aff_rescan4_kernel(const float* __restric
       // this kernel 2-3x slower): every slice folds its four winners into the rows' 64-bit (score, index) keys with
       // atomic max, waits for those to be performed (s_waitcnt vmcnt(0)), then counts itself in; whoever
       // counts in last reads the four keys back with atomic loads and writes the answers.
+      // ASSUMPTION (gfx950 only; sdk_init refuses every other device, so this path cannot run elsewhere): the ordering between the key
+      // atomics and the counter add is NOT expressed in the HIP/LLVM memory model (all four operations are relaxed).  It rests on two
+      // hardware facts measured on MI355X / ROCm 7.2 (MI355X_MICROARCH.md, 'Valid forms': "8-B agent atomics both sides"): a no-return
+      // agent-scope atomic is counted in vmcnt until it has been performed at the device coherence point (memory side, past the 8 XCD
+      // L2s), and inline asm is opaque to the compiler, so neither it nor the hardware can move the counter add ahead of the wait.
+      // The answers (idx / score, plain stores by the last arriver) are read by no one inside this launch.  A port to another
+      // architecture must replace this by the two-launch merge or by an acq_rel counter RMW; the determinism test
+      // (tests/test_gpu_kernels.py::test_affinity_rescan_is_deterministic_and_sliced) covers this architecture and build only.
       asm volatile("s_waitcnt vmcnt(0)" ::: "memory");                // (a workgroup-scope fence compiles to no vmcnt wait at all)
       __syncthreads();
       if (tid == 0) last_s = __hip_atomic_fetch_add(quad_done + q, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == nsl - 1;

@@ -35,7 +35,8 @@ struct sdk_ctx {
   bool no_asp_seg = false;        // A/B + test knob: ASP by (segment, 128-channel) workgroups instead of one per segment
   int aff_fast = 1;               // k = 1 affinity: 1 = row/column-maxima kernel (affinity_rowcol.hip), 0 = general sorted-list kernel
   void* dbg_ptr = nullptr;         // diagnostics only: device buffer for the affinity kernel's time stamps (sdk_debug_set_ptr "stamps")
-  void* gemm_clk_ptr = nullptr;    // diagnostics only: [workgroup][2] uint64 {shader cycles, 100 MHz ticks} of conv_gemm256_kernel ("gemm_clock")
+  void* gemm_clk_ptr = nullptr;    // diagnostics only: [4096][2] uint64 {shader cycles, 100 MHz ticks} of conv_gemm256_kernel ("gemm_clock")
+  void* gemm_stamps_ptr = nullptr; // diagnostics only: [4096] uint64 phase stamps of conv_gemm256 workgroup 0 ("gemm_stamps"; tools/gemm_timeline.py)
   int aff_whole_groups = 0;       // A/B knob: allow "one whole group per workgroup" when sweeps are short (affinity_rowcol.hip plan_geometry).
                                   // Off: at config #3 it takes 2.3 us off the coarse pass (49.0 -> 46.7) and adds 3.8 us to the rescan (one part per
                                   // group = a weaker certificate: 202 instead of 88 uncertain rows), 87.2 vs 84.9 us end to end

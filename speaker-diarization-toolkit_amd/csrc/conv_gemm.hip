@@ -44,6 +44,7 @@ struct Params {
   float* stats_part; int stats_mode;   // fused per-segment column statistics (256^2 kernel only)
   const bf16_t* A2; int64_t lda2;      // optional addend of the A operand (128^2 kernel only): A := bf16(A + A2)
   unsigned long long* clk;             // diagnostics (256^2 kernel): per workgroup {shader cycles, 100 MHz ticks} of its lifetime, or null
+  unsigned long long* stamps;          // diagnostics (256^2 kernel): [4096] wall-clock stamps of workgroup 0's phases (own buffer: "gemm_stamps"), or null
 };
 
 __global__ __launch_bounds__(NT, 2) void conv_gemm_kernel(Params p) {
@@ -398,7 +399,7 @@ __global__ __launch_bounds__(NT2, 2) void conv_gemm256_kernel(Params p) {
 
   int nst = 0;
   auto stamp = [&]() {
-    if (p.clk && blockIdx.x == 0 && tid == 0 && nst < 4000) p.clk[8192 + nst++] = __builtin_amdgcn_s_memrealtime();
+    if (p.stamps && blockIdx.x == 0 && tid == 0 && nst < 4096) p.stamps[nst++] = __builtin_amdgcn_s_memrealtime();
   };
   // Persistent workgroups (one per CU; the grid is a multiple of 8 so a workgroup keeps its XCD class) walk
   // their tiles back to back.
@@ -691,10 +692,10 @@ __global__ __launch_bounds__(NT2, 2) void conv_gemm256_v3_kernel(Params p) {
   const bool dma_early = wu < 4;
   const bool relu = p.flags & SDK_GEMM_RELU;
 
-  // diagnostics: wall-clock stamps (100 MHz) of workgroup 0's tile phases, behind the clock probe's buffer
+  // diagnostics: wall-clock stamps (100 MHz) of workgroup 0's tile phases (debug buffer "gemm_stamps", [4096])
   int nst = 0;
   auto stamp = [&]() {
-    if (p.clk && blockIdx.x == 0 && tid == 0 && nst < 4000) p.clk[8192 + nst++] = __builtin_amdgcn_s_memrealtime();
+    if (p.stamps && blockIdx.x == 0 && tid == 0 && nst < 4096) p.stamps[nst++] = __builtin_amdgcn_s_memrealtime();
   };
   if (blockIdx.x >= ntiles) return;
   for (int i = tid; i < 2 * 3 * BN2; i += NT2)                          // parameter defaults (both buffers): bias 0, scale 1, shift 0
@@ -1005,6 +1006,7 @@ extern "C" int sdk_conv_gemm(sdk_ctx* ctx, const sdk_conv_gemm_args* a, void* st
   p.stats_part = nullptr; p.stats_mode = 0;
   p.A2 = (const bf16_t*)a->A2; p.lda2 = a->lda2;
   p.clk = (unsigned long long*)ctx->gemm_clk_ptr;
+  p.stamps = (unsigned long long*)ctx->gemm_stamps_ptr;
   if (a->A2) SDK_REQUIRE(a->lda2 % 8 == 0 && a->lda2 >= a->Cin && ((uintptr_t)a->A2 % 16) == 0, "sdk_conv_gemm: bad A2/lda2");
 
   const double kk = (double)a->taps * a->Cin;

@@ -41,6 +41,7 @@
  * fragment load is 1 KiB contiguous instead of 16 row pieces of 64 B:
  *   [tap 3][channel block wq 4][column tile h 2][k-step ks 4][lane 64][8] bf16,
  *   lane l holds W[out = 32 wq + 16 h + (l & 15)][k = 128 tap + 32 ks + 8 (l >> 4) + 0..7]   (tap-major K as in the W slot) */
-#define EL_CHAINPACK(i, j) (160 + ((i) - 1) * 8 + (j))   /* block i = 1..n_blocks (<= 4), conv j = 0..6 */
+#define EL_CHAINPACK(i, j) (200 + ((i) - 1) * 8 + (j))   /* block i = 1..n_blocks (<= 4), conv j = 0..6: slots 200..231, clear of every legal
+                                                            tail (EL_TAIL_BASE(4) + 15 = 179; round 2 had them at 160.., inside the 4-block tail) */
 
 #endif

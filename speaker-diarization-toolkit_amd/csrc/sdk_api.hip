@@ -95,6 +95,7 @@ extern "C" int sdk_debug_set_ptr(sdk_ctx* ctx, const char* name, void* p) {
   SDK_REQUIRE(ctx && name, "sdk_debug_set_ptr: null argument");
   if (strcmp(name, "stamps") == 0) { ctx->dbg_ptr = p; return 0; }
   if (strcmp(name, "gemm_clock") == 0) { ctx->gemm_clk_ptr = p; return 0; }
+  if (strcmp(name, "gemm_stamps") == 0) { ctx->gemm_stamps_ptr = p; return 0; }
   sdk_set_error("sdk_debug_set_ptr: unknown name '%s'", name);
   return 2;
 }

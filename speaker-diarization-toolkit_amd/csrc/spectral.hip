@@ -263,7 +263,11 @@ __global__ __launch_bounds__(64) void chol_inverse_kernel(const float* __restric
       if (i == j) a += 1e-30;
       for (int q = 0; q < j; ++q) a -= L[i][q] * L[j][q];
       if (i == j) {
-        if (!(a > 0.0)) { fail = 1; a = 1.0; }
+        // a pivot at or below 1e-6 of its diagonal entry is rounding noise of the fp32 Gram matrix (cond(Y) > 1e3: the subspace
+        // has lost rank) - flagged like a non-positive or NaN one; only an unusable pivot is replaced
+        const double dii = (double)G[i * k + i];
+        if (!(a > 1e-6 * dii)) fail = 1;
+        if (!(a > 0.0)) a = 1.0;
         L[i][i] = sqrt(a);
       } else {
         L[i][j] = a / L[j][j];
@@ -279,7 +283,7 @@ __global__ __launch_bounds__(64) void chol_inverse_kernel(const float* __restric
     }
   for (int i = 0; i < k; ++i)
     for (int j = 0; j < k; ++j) Rinv[i * k + j] = (float)X[i][j];
-  if (bad) *bad = fail;
+  if (bad && fail) *bad = 1;   // sticky: the caller zeroes it once and reads it once, after any number of passes (cluster._orth)
 }
 
 }  // namespace

@@ -66,13 +66,19 @@ def make_rows_fn(audio_path: Path, tags: Optional[List[str]] = None, per_label: 
         print(f"No speakers with {be.name} embeddings.", file=sys.stderr)
         return lambda label, segs: []
     if not per_label:
-        rows = rows_with_trust(be.identify_speaker(audio_path, cands, threshold), by_id, be.name)
+        try:
+            rows = rows_with_trust(be.identify_speaker(audio_path, cands, threshold), by_id, be.name)
+        except ValueError as exc:             # cmd_identify's `except Exception` -> stderr + rc 1 -> "no signals" upstream (speaker-assign:296)
+            print(f"Error during identification: {exc}", file=sys.stderr)
+            return lambda label, segs: []
         return lambda label, segs: rows
 
     from .wav import decode_to_profile
     batch = load_profile_batch(cands, be.name, model_prefix=f"{be.name}-", model_version=be.model_version)
     for why in batch.skipped:
         print(f"mi355x backend: skipped embedding {why}", file=sys.stderr)
+    if batch.all_skipped_message():           # loud, once: the in-process counterpart of the CLI's rc 1 (Backend.identify_speaker raises)
+        print(f"Error during identification: {batch.all_skipped_message()}", file=sys.stderr)
     if len(batch) == 0:
         return lambda label, segs: []
     samples = decode_to_profile(Path(audio_path), be.engine(), be.get_audio_profile())

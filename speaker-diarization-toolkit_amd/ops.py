@@ -334,11 +334,15 @@ class Engine:
         check(self.lib.sdk_rows_apply(self.ctx, X.data_ptr(), R.contiguous().data_ptr(), _ptr(scale), n, k, Y.data_ptr(), _stream()), "sdk_rows_apply")
         return Y
 
-    def chol_inverse(self, G):
-        """Rinv [k,k] with (G+G^T)/2 = L L^T, Rinv = (L^T)^-1 (float64 inside, stays on the stream)."""
+    def chol_inverse(self, G, flag: Optional[torch.Tensor] = None):
+        """Rinv [k,k] with (G+G^T)/2 = L L^T, Rinv = (L^T)^-1 (float64 inside, stays on the stream).  `flag` (device int32 [1], zeroed
+        by the caller) is set to 1 when G is not positive definite (rank-deficient or NaN input); it is sticky, so one flag can watch a
+        whole iteration and be read at the caller's next host synchronisation."""
         k = G.shape[0]
+        if flag is not None:
+            _need(flag, torch.int32, "flag")
         Rinv = torch.empty((k, k), dtype=torch.float32, device=self.device)
-        check(self.lib.sdk_chol_inverse(self.ctx, G.contiguous().data_ptr(), k, Rinv.data_ptr(), None, _stream()), "sdk_chol_inverse")
+        check(self.lib.sdk_chol_inverse(self.ctx, G.contiguous().data_ptr(), k, Rinv.data_ptr(), _ptr(flag), _stream()), "sdk_chol_inverse")
         return Rinv
 
     def rows_unit(self, X):

@@ -97,6 +97,16 @@ class ProfileBatch:
     def __len__(self) -> int:
         return len(self.speaker_ids)
 
+    def all_skipped_message(self) -> Optional[str]:
+        """One summary line when candidates were offered and NOT ONE of their vectors is usable (typically: every vector was
+        enrolled under other weights) - the caller must make that loud instead of reporting "no match"."""
+        if len(self) or not self.skipped:
+            return None
+        stale = sum("re-enroll" in why for why in self.skipped)
+        return (f"{len(self.skipped)} of {len(self.skipped)} enrolled embeddings are unusable"
+                + (f" ({stale} enrolled under other weights: re-enroll those speakers with the current model)" if stale else "")
+                + f"; first: {self.skipped[0]}")
+
 
 def load_profile_batch(candidates: List[Dict[str, Any]], backend_name: str, model_prefix: Optional[str] = None,
                        root: Optional[Path] = None, link: bool = True, model_version: Optional[str] = None) -> ProfileBatch:

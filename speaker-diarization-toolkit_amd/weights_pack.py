@@ -41,7 +41,7 @@ def tail_base(n_blocks: int) -> int:
 
 def chainpack_slot(i: int, j: int) -> int:
     """EL_CHAINPACK(i, j): optional fragment-ordered copy of block i's Res2Net conv j."""
-    return 160 + (i - 1) * 8 + j
+    return 200 + (i - 1) * 8 + j
 
 
 def chain_fragment_order(wk: np.ndarray) -> np.ndarray:
@@ -106,6 +106,7 @@ def pack_weights(weights: Dict[str, np.ndarray], cfg: EcapaConfig = DEFAULT_CONF
         nonlocal cur
         a = np.ascontiguousarray(arr)
         assert a.dtype in (np.uint16, np.float32), a.dtype
+        assert 0 <= slot < 256 and off[slot] == -1, f"weight slot {slot} written twice (ecapa_layout.h index space)"
         off[slot] = cur
         chunks.append((cur, a.view(np.uint8).reshape(-1)))
         cur += (a.nbytes + ALIGN - 1) // ALIGN * ALIGN

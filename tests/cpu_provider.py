@@ -24,9 +24,11 @@ class CpuProvider:
             Z = Z * scale.double()[:, None]
         return Z.float()
 
-    def chol_inverse(self, G):
+    def chol_inverse(self, G, flag=None):       # raises LinAlgError itself; the GPU provider sets `flag` instead and cluster.py raises
         g = G.double().numpy()
         L = np.linalg.cholesky(0.5 * (g + g.T) + 1e-30 * np.eye(g.shape[0]))
+        if not (np.diag(L) ** 2 > 1e-6 * np.diag(g)).all():            # same rank rule as chol_inverse_kernel (csrc/spectral.hip)
+            raise np.linalg.LinAlgError("Gram matrix numerically rank deficient")
         return torch.from_numpy(np.ascontiguousarray(np.linalg.inv(L.T)).astype(np.float32))
 
     def rows_unit(self, X):

@@ -143,6 +143,37 @@ def test_fragment_ordered_weight_copies():
     assert np.array_equal(blob[off[t + WP.EL_ASP_W2PACK]:][:3072 * 128 * 2].view(np.uint16).reshape(96, 8, 64, 8), WP.asp_w2_fragment_order(plain))
 
 
+def test_four_block_layout_has_no_slot_collisions():
+    """with n_blocks == 4 the tail occupies slots 164..179; the optional fragment-ordered copies must not land inside it (they
+    did at 160 + ...: the chain then read MFA / ASP weights as conv weights).  The packer refuses a slot written twice; here every slot of a
+    4-dilation model (small channels: the slot arithmetic does not depend on them) and of the full-size 3-block model is unique and in range."""
+    W, WP = sub("weights"), sub("weights_pack")
+    cfg4 = W.EcapaConfig(channels=1024, mfa_channels=4096, dilations=(2, 3, 4, 5))
+    # slot arithmetic only (packing 4 blocks of C = 1024 weights costs seconds, not needed for the index check)
+    used = set(range(4))
+    for i in range(1, 5):
+        b = WP.block_base(i)
+        used |= {b + k for k in range(40)}
+    t = WP.tail_base(4)
+    tail = {t + k for k in range(16)}
+    assert not (used & tail) and max(tail) == 179
+    chain = {WP.chainpack_slot(i, j) for i in range(1, 5) for j in range(7)}
+    assert len(chain) == 28 and not (chain & (used | tail)) and max(chain) < 256 and min(chain) > max(tail)
+    # the real packer on a small 4-block model: every offset distinct, no assertion from the double-write guard
+    small = W.EcapaConfig(channels=1024, mfa_channels=4096, dilations=(2, 3, 4, 5))
+    blob, f = WP.pack_weights(W.synthetic_weights(2, small), small)
+    offs = [o for o in f["off"] if o >= 0]
+    assert len(offs) == len(set(offs)) and f["n_blocks"] == 4
+    for i in range(1, 5):
+        for j in range(7):
+            a = f["off"][WP.chainpack_slot(i, j)]
+            plain = blob[f["off"][WP.block_base(i) + WP.res2net_slot(j) + WP.EL_W]:][:128 * 384 * 2].view(np.uint16).reshape(128, 384)
+            assert np.array_equal(blob[a:a + 98304].view(np.uint16).reshape(3, 4, 2, 4, 64, 8), WP.chain_fragment_order(plain))
+    # the header's macro agrees with the packer
+    hdr = (ROOT / "speaker-diarization-toolkit_amd" / "csrc" / "ecapa_layout.h").read_text()
+    assert "#define EL_CHAINPACK(i, j) (200 + ((i) - 1) * 8 + (j))" in hdr
+
+
 def test_bf16_bits_roundtrip():
     WP = sub("weights_pack")
     import torch

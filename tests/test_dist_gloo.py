@@ -4,6 +4,7 @@ import os
 import socket
 
 import numpy as np
+import pytest
 import torch
 import torch.distributed as dist
 import torch.multiprocessing as mp
@@ -101,3 +102,32 @@ def test_spectral_cluster_single_process_cpu_provider():
     olab, olam = ospec.spectral_cluster(Eb.float().numpy(), 5, n_iter=20, n_kmeans=15)
     assert np.array_equal(res.labels, olab) and np.abs(res.eigenvalues - olam).max() < 1e-5
     assert ospec.adjusted_rand_index(res.labels, truth) == 1.0
+
+
+def test_spectral_cluster_raises_on_a_flagged_gram_matrix():
+    """cluster.py's side of the sync-free CholeskyQR: a provider that only SETS the sticky device flag (what ops.Engine
+    does) must still end in LinAlgError at the Ritz step, and a provider that raises by itself (the CPU stand-in) propagates."""
+    import importlib
+    import sys
+    sys.path.insert(0, str(ROOT / "tests"))
+    from cpu_provider import CpuProvider
+    CL = importlib.import_module(f"{PKG}.cluster")
+
+    class Flagging(CpuProvider):
+        def chol_inverse(self, G, flag=None):
+            try:
+                return super().chol_inverse(G)
+            except np.linalg.LinAlgError:
+                flag.fill_(1)
+                return torch.eye(G.shape[0])
+
+    rng = np.random.default_rng(0)
+    base = rng.standard_normal((3, 192)).astype(np.float32)
+    base /= np.linalg.norm(base, axis=1, keepdims=True)
+    E = np.repeat(base, 50, axis=0)
+    Eb = torch.from_numpy(E).to(torch.bfloat16)
+    for prov in (Flagging(), CpuProvider()):
+        with pytest.raises(np.linalg.LinAlgError):
+            CL.spectral_cluster(prov, torch.from_numpy(E), Eb, 150, 6, n_iter=4, n_kmeans=3)
+    res = CL.spectral_cluster(Flagging(), torch.from_numpy(E), Eb, 150, 3, n_iter=6, n_kmeans=3)
+    assert np.array_equal(res.labels, np.repeat(np.arange(3), 50))

@@ -467,6 +467,36 @@ def test_chol_inverse_on_device(engine, k):
     assert float((Q.T @ Q - torch.eye(k, dtype=torch.float64)).abs().max()) < 1e-3
 
 
+def test_chol_inverse_flags_a_rank_deficient_gram_matrix(engine):
+    """the device CholeskyQR must not swallow a non-SPD Gram matrix.  The flag is sticky (set, never cleared)."""
+    flag = torch.zeros(1, dtype=torch.int32, device="cuda")
+    g = torch.Generator().manual_seed(1)
+    Y = torch.randn(400, 6, generator=g, dtype=torch.float64)
+    engine.chol_inverse(dev((Y.T @ Y).float()), flag)
+    assert int(flag.item()) == 0
+    Y[:, 5] = Y[:, 0] + Y[:, 1]                               # rank 5
+    engine.chol_inverse(dev((Y.T @ Y).float()), flag)
+    assert int(flag.item()) == 1
+    engine.chol_inverse(dev(torch.eye(6)), flag)              # a good matrix afterwards does not clear it
+    assert int(flag.item()) == 1
+    flag.zero_()
+    Gn = torch.eye(6); Gn[2, 2] = float("nan")
+    engine.chol_inverse(dev(Gn), flag)
+    assert int(flag.item()) == 1
+
+
+def test_spectral_cluster_raises_when_k_exceeds_the_rank(engine):
+    """Duplicate embeddings, k greater than the number of distinct rows: the host-side CholeskyQR of round 1 raised LinAlgError; the
+    sync-free device form must too (checked once, at the Ritz step's host synchronisation), instead of returning plausible labels."""
+    base = _unit(3, 192, 5)
+    E = np.repeat(base, 200, axis=0)
+    En, Eb, _ = engine.l2norm(dev(E))
+    with pytest.raises(np.linalg.LinAlgError):
+        CL.spectral_cluster(engine, En, Eb, 600, 6, n_iter=5, n_kmeans=5, seed=0)
+    res = CL.spectral_cluster(engine, En, Eb, 600, 3, n_iter=8, n_kmeans=5, seed=0)     # k = rank works
+    assert np.array_equal(res.labels, np.repeat(np.arange(3), 200))
+
+
 @pytest.mark.parametrize("N,k", [(2000, 6), (5000, 16)])
 def test_spectral_cluster_matches_oracle(engine, N, k):
     """Config #5 scaled down: mixture-of-clusters embeddings, GPU pipeline vs the CPU oracle run on the

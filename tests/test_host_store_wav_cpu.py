@@ -172,8 +172,34 @@ def test_backend_identify_uses_the_exact_model_version(tmp_path, monkeypatch):
     be._digest = "bbbbbbbbbbbb"                                               # the loaded weights
     ext = store.save_vector(np.random.default_rng(3).standard_normal(192).astype(np.float32))
     cands = [_profile("alice", [{"id": "emb-a1", "external_id": ext, "model_version": "mi355x-ecapa1024-aaaaaaaaaaaa"}])]
-    assert be.identify_speaker(tmp_path / "missing.wav", cands) == []        # nothing usable -> [] like the reference's early exit
+    # nothing usable although candidates were offered: loud - the CLI turns the exception into "Error during
+    # identification: ..." + rc 1 (speaker_detection:1072-1074), not into an empty "no match"
+    with pytest.raises(ValueError, match="1 of 1 enrolled embeddings are unusable .*re-enroll"):
+        be.identify_speaker(tmp_path / "missing.wav", cands)
+    assert be.identify_speaker(tmp_path / "missing.wav", [{"id": "carol", "embeddings": {}}]) == []   # no candidates at all stays quiet
     assert be.check_embedding_compatibility(cands[0]["embeddings"]["mi355x"][0])["compatible"]   # the toolkit's own prefix rule still says yes
+
+
+def test_make_rows_fn_is_loud_when_every_vector_is_stale(tmp_path, monkeypatch, capsys):
+    """The in-process identify (identify.make_rows_fn) with a database enrolled under other weights: an empty rows_fn AND one
+    summary line on stderr, in both the whole-recording and the per-label mode - `assign` must not silently lose its signal."""
+    import json
+    identify = sub("identify")
+    monkeypatch.setenv("SPEAKERS_EMBEDDINGS_DIR", str(tmp_path))
+    (tmp_path / "db").mkdir()
+    ext = store.save_vector(np.random.default_rng(4).standard_normal(192).astype(np.float32))
+    prof = _profile("alice", [{"id": "emb-a1", "external_id": ext, "model_version": "mi355x-ecapa1024-aaaaaaaaaaaa", "trust_level": "high"}])
+    (tmp_path / "db" / "alice.json").write_text(json.dumps(prof))
+    wav_path = tmp_path / "a.wav"
+    wav_path.write_bytes(b"RIFF")                                            # only its existence is checked before the batch is loaded
+    be = backend.Backend()
+    be._digest = "bbbbbbbbbbbb"
+    for per_label in (False, True):
+        fn = identify.make_rows_fn(wav_path, per_label=per_label, backend=be)
+        assert fn("S1", [{"start": 0.0, "end": 2.0}]) == []
+        err = capsys.readouterr().err
+        assert "Error during identification: 1 of 1 enrolled embeddings are unusable" in err and "re-enroll" in err
+        assert "enrolled under mi355x-ecapa1024-aaaaaaaaaaaa" in err
 
 
 def test_aggregate_matches():

@@ -15,14 +15,14 @@ for N, K in ((1024, 1024), (3072, 3072)):
     bias = torch.randn(N, device="cuda")
     eng.lib.sdk_set_gemm_variant(variant)
     for _ in range(3): eng.conv_gemm(A, W, N, K, T=201, bias=bias, relu=True)
-    buf = torch.zeros(8192 + 4096, dtype=torch.int64, device="cuda")
-    eng.debug_ptr("gemm_clock", buf)
+    buf = torch.zeros(8192, dtype=torch.int64, device="cuda"); stamps = torch.zeros(4096, dtype=torch.int64, device="cuda")
+    eng.debug_ptr("gemm_clock", buf); eng.debug_ptr("gemm_stamps", stamps)
     eng.conv_gemm(A, W, N, K, T=201, bias=bias, relu=True)
     torch.cuda.synchronize()
-    eng.debug_ptr("gemm_clock", None)
+    eng.debug_ptr("gemm_clock", None); eng.debug_ptr("gemm_stamps", None)
     eng.lib.sdk_set_gemm_variant(2)
     t = buf.cpu().numpy()
-    st = t[8192:]; st = st[st > 0].astype(np.float64) / 100.0
+    st = stamps.cpu().numpy(); st = st[st > 0].astype(np.float64) / 100.0
     nk = K // 64
     per_tile = 1 + 3 * (nk - 1) + 1 + 1          # [K-step 0 landed] + 3 per K-step but the last + [K loop end] + [tile end]
     nt = len(st) // per_tile

@@ -13,13 +13,13 @@ bias = torch.randn(N, device="cuda"); sc = torch.rand(N, device="cuda") + 0.5; s
 for variant, name in ((258, "v3 overlapped boundary"), (2, "v2")):
     eng.lib.sdk_set_gemm_variant(variant)
     for _ in range(3): eng.conv_gemm(A, W, N, K, T=201, bias=bias, scale=sc, shift=sh, relu=True)
-    buf = torch.zeros(8192 + 4096, dtype=torch.int64, device="cuda")
-    eng.debug_ptr("gemm_clock", buf)
+    buf = torch.zeros(8192, dtype=torch.int64, device="cuda"); stamps = torch.zeros(4096, dtype=torch.int64, device="cuda")
+    eng.debug_ptr("gemm_clock", buf); eng.debug_ptr("gemm_stamps", stamps)
     eng.conv_gemm(A, W, N, K, T=201, bias=bias, scale=sc, shift=sh, relu=True)
     torch.cuda.synchronize()
-    eng.debug_ptr("gemm_clock", None)
+    eng.debug_ptr("gemm_clock", None); eng.debug_ptr("gemm_stamps", None)
     t = buf.cpu().numpy()
-    st = t[8192:]; st = st[st > 0].astype(np.float64) / 100.0
+    st = stamps.cpu().numpy(); st = st[st > 0].astype(np.float64) / 100.0
     n = len(st) // 3
     st = st[:3 * n].reshape(n, 3)
     wait = st[1:, 0] - st[:-1, 2]; loop = st[:, 1] - st[:, 0]; epi = st[:, 2] - st[:, 1]
