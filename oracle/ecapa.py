@@ -12,6 +12,12 @@ torch.nn.functional.conv1d with reflect padding).
           bf16 (RNE), accumulation in ``acc`` (float64 = ideal), fp32 epilogue, bf16 store.
   "fp32"  no rounding anywhere (the mathematical model; used to report how far the bf16
           model is from it, and as the timed CPU baseline with acc=float32).
+
+``sites`` (optional) overrides the mode with PER-SITE rounding switches, for the error budget of
+DESIGN.md section 3 (tools/error_budget.py, tests/test_error_budget_cpu.py): a dict
+{site: significand bits} (8 = bf16, 11 = fp16's, 16 = a bf16 hi+lo pair, 22 = an fp16 hi+lo pair)
+or an iterable of site names (bf16).  Sites = ROUNDING_SITES below: every place where the GPU
+path rounds a value that the fp32 model does not.
 """
 from __future__ import annotations
 
@@ -28,6 +34,34 @@ def _bf16(x: torch.Tensor) -> torch.Tensor:
     return x.to(torch.bfloat16).to(torch.float32)
 
 
+# every place where the bf16 layer-boundary model rounds
+ROUNDING_SITES = (
+    "w",            # weights of every MFMA GEMM (blk0, tdnn1, Res2Net convs, tdnn2, MFA, attention hidden, attention logits)
+    "feats",        # the normalised log-mel features as the first conv's A operand
+    "blk0",         # stored output of the first TDNN layer
+    "tdnn1",        # stored output u of a block's first 1x1 layer
+    "res2net",      # Res2Net: stored conv outputs y_c and the running sums bf16(u_c + y_{c-1})
+    "tdnn2",        # stored output z of a block's second 1x1 layer
+    "se_out",       # stored block output bf16(g * z + x)
+    "mfa",          # stored output h of the 3072 x 3072 layer
+    "attn_hidden",  # stored tanh output of the attention hidden layer
+)
+
+
+def round_significand(x: torch.Tensor, bits: int) -> torch.Tensor:
+    """Round fp32 values to `bits` significand bits (implicit bit included), nearest-even, exponent range of fp32 kept:
+    8 = bfloat16; 16 models a bf16 hi+lo operand pair, 22 an fp16 hi+lo pair; >= 24 is the identity."""
+    if bits >= 24:
+        return x
+    if bits == 8:
+        return _bf16(x)
+    drop = 24 - bits
+    u = x.contiguous().view(torch.int32).to(torch.int64) & 0xFFFFFFFF
+    r = (u + ((1 << (drop - 1)) - 1) + ((u >> drop) & 1)) >> drop << drop
+    r = torch.where(r >= (1 << 31), r - (1 << 32), r).to(torch.int32)
+    return r.view(torch.float32).reshape(x.shape)
+
+
 def reflect_index(t: torch.Tensor, T: int) -> torch.Tensor:
     """Reflect (no edge repeat) an index into [0, T): -1 -> 1, T -> T-2."""
     t = torch.where(t < 0, -t, t)
@@ -36,18 +70,26 @@ def reflect_index(t: torch.Tensor, T: int) -> torch.Tensor:
 
 class EcapaOracle:
     def __init__(self, weights: Dict[str, np.ndarray], mode: str = "bf16", acc=torch.float64,
-                 n_dilations=(2, 3, 4), scale: int = 8):
+                 n_dilations=(2, 3, 4), scale: int = 8, sites=None):
         assert mode in ("bf16", "fp32")
         self.mode = mode
         self.acc = acc
         self.dil = tuple(n_dilations)
         self.scale = scale
         self.w = {k: torch.from_numpy(np.ascontiguousarray(v)) for k, v in weights.items()}
+        if sites is None:
+            sites = {s: 8 for s in ROUNDING_SITES} if mode == "bf16" else {}
+        elif not isinstance(sites, dict):
+            sites = {s: 8 for s in sites}
+        unknown = set(sites) - set(ROUNDING_SITES)
+        assert not unknown, f"unknown rounding sites {sorted(unknown)}"
+        self.sites = dict(sites)
 
     # -- helpers ---------------------------------------------------------------------
-    def q(self, x: torch.Tensor) -> torch.Tensor:
-        """Round to bf16 at a layer boundary (identity in fp32 mode)."""
-        return _bf16(x) if self.mode == "bf16" else x
+    def q(self, x: torch.Tensor, site: str) -> torch.Tensor:
+        """Round at `site` (a member of ROUNDING_SITES) to that site's significand width; identity where the site is off."""
+        bits = self.sites.get(site)
+        return x if bits is None else round_significand(x, bits)
 
     def bn(self, name: str):
         g, b, m, v = (self.w[f"{name}.{f}"].double() for f in ("gamma", "beta", "mean", "var"))
@@ -59,7 +101,7 @@ class EcapaOracle:
         W = self.w[f"{name}.w"]                      # [Cout, Cin, k]
         Cout, Cin, k = W.shape
         B, T, _ = x.shape
-        Wq = self.q(W).to(self.acc)
+        Wq = self.q(W, "w").to(self.acc)
         xa = x.to(self.acc)
         out = torch.zeros(B, T, Cout, dtype=self.acc)
         t = torch.arange(T)
@@ -76,31 +118,31 @@ class EcapaOracle:
     # -- blocks ------------------------------------------------------------------------
     def se_res2net(self, x: torch.Tensor, i: int) -> torch.Tensor:
         d = self.dil[i - 1]
-        u = self.q(self.tdnn(x, f"blk{i}.tdnn1"))
+        u = self.q(self.tdnn(x, f"blk{i}.tdnn1"), "tdnn1")
         C = u.shape[-1]
         s = C // self.scale
         chunks = [u[..., c * s:(c + 1) * s] for c in range(self.scale)]
         ys = [chunks[0]]
         prev = None
         for c in range(1, self.scale):
-            inp = chunks[c] if c == 1 else self.q(chunks[c] + prev)
-            prev = self.q(self.tdnn(inp, f"blk{i}.res2net.{c - 1}", d))
+            inp = chunks[c] if c == 1 else self.q(chunks[c] + prev, "res2net")
+            prev = self.q(self.tdnn(inp, f"blk{i}.res2net.{c - 1}", d), "res2net")
             ys.append(prev)
         r = torch.cat(ys, dim=-1)
-        z = self.q(self.tdnn(r, f"blk{i}.tdnn2"))
+        z = self.q(self.tdnn(r, f"blk{i}.tdnn2"), "tdnn2")
         # squeeze-excitation (fp32, per utterance)
         mean = z.double().mean(dim=1).float()                               # [B, C]
         w1 = self.w[f"blk{i}.se.conv1.w"][:, :, 0]; b1 = self.w[f"blk{i}.se.conv1.b"]
         w2 = self.w[f"blk{i}.se.conv2.w"][:, :, 0]; b2 = self.w[f"blk{i}.se.conv2.b"]
         h = torch.relu((mean.double() @ w1.double().T).float() + b1)
         g = torch.sigmoid((h.double() @ w2.double().T).float() + b2)        # [B, C]
-        return self.q(g[:, None, :] * z + x)
+        return self.q(g[:, None, :] * z + x, "se_out")
 
     def forward_pooled(self, feats: torch.Tensor):
         """feats [B,T,80] fp32 -> (pooled [B,6144] fp32, intermediates dict)."""
         inter = {}
-        x0 = self.q(feats)
-        x = self.q(self.tdnn(x0, "blk0"))
+        x0 = self.q(feats, "feats")
+        x = self.q(self.tdnn(x0, "blk0"), "blk0")
         inter["blk0"] = x
         outs = []
         for i in range(1, len(self.dil) + 1):
@@ -108,7 +150,7 @@ class EcapaOracle:
             inter[f"blk{i}"] = x
             outs.append(x)
         cat = torch.cat(outs, dim=-1)                                       # [B,T,3072]
-        h = self.q(self.tdnn(cat, "mfa"))
+        h = self.q(self.tdnn(cat, "mfa"), "mfa")
         inter["mfa"] = h
         # attentive statistics pooling with global context
         hd = h.double()
@@ -116,14 +158,14 @@ class EcapaOracle:
         sd = torch.sqrt(((hd - mu[:, None, :]) ** 2).mean(dim=1).clamp_min(STD_EPS))
         Wt = self.w["asp.tdnn.conv.w"][:, :, 0]                              # [128, 9216]
         Cm = h.shape[-1]
-        Wh = self.q(Wt[:, :Cm]).to(self.acc)
+        Wh = self.q(Wt[:, :Cm], "w").to(self.acc)
         ctx = torch.cat([mu, sd], dim=-1).float()                           # [B, 6144] fp32
         ubias = (ctx.double() @ Wt[:, Cm:].double().T).float() + self.w["asp.tdnn.conv.b"]
         s, sh = self.bn("asp.tdnn.bn")
         pre = (h.to(self.acc) @ Wh.T).float() + ubias[:, None, :]
-        a = self.q(torch.tanh(torch.relu(pre) * s + sh))                    # [B,T,128]
+        a = self.q(torch.tanh(torch.relu(pre) * s + sh), "attn_hidden")    # [B,T,128]
         inter["attn_hidden"] = a
-        W2 = self.q(self.w["asp.conv.w"][:, :, 0]).to(self.acc)              # [3072,128]
+        W2 = self.q(self.w["asp.conv.w"][:, :, 0], "w").to(self.acc)         # [3072,128]
         logits = (a.to(self.acc) @ W2.T).float() + self.w["asp.conv.b"]     # [B,T,3072] fp32
         wgt = torch.softmax(logits.double(), dim=1)
         wmu = (wgt * hd).sum(dim=1)

@@ -82,17 +82,27 @@ def frames_of(pcm: np.ndarray) -> np.ndarray:
     return x[:, idx]
 
 
-def power_spectrum(pcm: np.ndarray) -> np.ndarray:
+def _round_significand(x: np.ndarray, bits: int) -> np.ndarray:
+    """float64 -> nearest value with `bits` significand bits (error-budget switch only)."""
+    m, e = np.frexp(x)
+    return np.ldexp(np.round(m * (1 << bits)) / (1 << bits), e)
+
+
+def power_spectrum(pcm: np.ndarray, dft_bits: int | None = None) -> np.ndarray:
+    """dft_bits (error budget): round the windowed DFT matrices to that many significand bits - 16 models
+    the GPU kernel's bf16 hi+lo split of the table (the int16 samples split exactly); None = the exact float64 table."""
     C, Sn = dft_matrices()
+    if dft_bits is not None:
+        C, Sn = _round_significand(C, dft_bits), _round_significand(Sn, dft_bits)
     fr = frames_of(pcm)
     re = fr @ C
     im = fr @ Sn
     return re * re + im * im
 
 
-def fbank(pcm: np.ndarray) -> np.ndarray:
+def fbank(pcm: np.ndarray, dft_bits: int | None = None) -> np.ndarray:
     """[B, S] int16 -> [B, T, 80] float32 mean-normalised log-mel features."""
-    P = power_spectrum(pcm)
+    P = power_spectrum(pcm, dft_bits)
     M = P @ mel_matrix()
     L = 10.0 * np.log10(np.maximum(M, AMIN))
     peak = L.reshape(L.shape[0], -1).max(axis=1)[:, None, None]

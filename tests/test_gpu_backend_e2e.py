@@ -128,3 +128,29 @@ def test_graph_replay_matches_eager(engine):
         E2, _, _ = engine.embed_pcm_graph(pcm2)          # replay with new input
         torch.cuda.synchronize()
         assert torch.equal(E2, engine.embed_pcm(pcm2)[0])
+
+
+def test_embed_windows_in_bounded_batches(monkeypatch):
+    """Backend.embed_windows cuts a long recording into SDK_MAX_BATCH-window batches; the embeddings
+    must not depend on the cut beyond the batch-invariance tolerance written in test_config2_full_batch_properties (|dE| <= 1e-3 on
+    unit vectors, cos >= 1 - 1e-5: per-segment fp32 statistics are summed in another grouping when a segment starts on another tile row)."""
+    import torch
+    B = sub("backend")
+    rng = np.random.default_rng(7)
+    t = np.arange(32000) / 16000.0
+    pcm = np.stack([np.clip(np.round(3000 * np.sin(2 * np.pi * (90 + 17 * i) * t) + 1200 * np.sin(2 * np.pi * (300 + 41 * i) * t)
+                                     + rng.normal(0, 700, t.shape)), -32768, 32767).astype(np.int16) for i in range(10)])
+    be = B.Backend()
+    monkeypatch.delenv("SDK_MAX_BATCH", raising=False)
+    E1, Eb1, r1 = be.embed_windows(pcm)
+    monkeypatch.setenv("SDK_MAX_BATCH", "3")                 # 3 + 3 + 3 + 1
+    E2, Eb2, r2 = be.embed_windows(pcm)
+    torch.cuda.synchronize()
+    assert E2.shape == (10, 192) and Eb2.shape == (10, 192) and r2.shape == (10,)
+    assert torch.equal(E1[:3], E2[:3])                       # the first batch starts on the same tile rows: bit-identical
+    dmax = float((E1 - E2).abs().max())
+    cmin = float((E1.double() * E2.double()).sum(1).min())
+    assert dmax < 1e-3 and cmin > 1 - 1e-5, (dmax, cmin)
+    monkeypatch.setenv("SDK_MAX_BATCH", "1")
+    E3 = be.embed_windows(pcm)[0]
+    assert float((E1 - E3).abs().max()) < 1e-3

@@ -78,9 +78,11 @@ def test_plugin_errors(tmp_path, monkeypatch):
     same = be.check_embedding_compatibility({"model_version": "mi355x-other-model"})
     other = be.check_embedding_compatibility({"model_version": "speechmatics-v2"})
     assert same["compatible"] is True and same["current"] == rec["model_version"] and other["compatible"] is False
-    # a profile pointing at a vanished .npy is reported and skipped
+    # a profile pointing at a vanished .npy is reported and skipped; when that leaves NOTHING to compare against, the call is loud
+    # (the CLI's "Error during identification: ..." + rc 1) instead of answering "no match"
     ghost = {"id": "g", "embeddings": {"mi355x": [{"id": "emb-g", "external_id": "npy:000000000000000000000000", "model_version": rec["model_version"]}]}}
-    assert be.identify_speaker(good, [ghost]) == []
+    with pytest.raises(ValueError, match="1 of 1 enrolled embeddings are unusable"):
+        be.identify_speaker(good, [ghost])
     ok = {"id": "a", "embeddings": {"mi355x": [{"id": "emb-a", "external_id": rec["external_id"], "model_version": rec["model_version"]}]}}
     rows = be.identify_speaker(good, [ghost, ok], threshold=0.354)
     assert [r["speaker_id"] for r in rows] == ["a"] and rows[0]["similarity"] > 0.99

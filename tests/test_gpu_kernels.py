@@ -297,6 +297,23 @@ def test_ecapa_forward_full_config(engine):
     assert (_cos(emb, ref32) > 0.999).all()
 
 
+@pytest.mark.parametrize("B,T", [(2, 301), (2, 501)])
+def test_ecapa_forward_full_config_long_windows(engine, B, T):
+    """SDK_WINDOW_S lets a user pick any window.  T > 208 drops the Res2Net chain to seven conv_gemm launches
+    (sdk_res2net_chain_max_frames) and T > 224 takes the unfused ASP path (fp32 logits in HBM + sdk_asp_pool): those pieces are
+    tested alone above; here the whole C = 1024 forward at 3-s / 5-s windows against the bf16-model oracle, same tolerance as T = 201."""
+    weights = W.synthetic_weights(0)
+    feats = _feats(B, T, 23 + T)
+    f = torch.zeros(B * T, WP.N_MELS_PADDED, dtype=torch.bfloat16)
+    f[:, :80] = feats.reshape(-1, 80).to(torch.bfloat16)
+    assert T > engine.lib.sdk_res2net_chain_max_frames() and T > engine.lib.sdk_asp_fused_max_frames()
+    emb = engine.ecapa_forward(f.cuda(), B, T).cpu()
+    want = oecapa.EcapaOracle(weights, "bf16", torch.float64).embed(feats)
+    c = _cos(emb, want)
+    assert (c > 1 - 2e-5).all(), c
+    assert torch.allclose(emb, want, rtol=0, atol=2e-3 * float(want.abs().max())), float((emb - want).abs().max())
+
+
 # ------------------------------------------------------------------------------------------------
 # k4 affinity + top-k
 def _unit(n, d, seed):
