@@ -44,7 +44,7 @@
 extern "C" {
 #endif
 
-#define SDK_ABI_VERSION 1
+#define SDK_ABI_VERSION 2   /* 2: sdk_ecapa_desc.precision (round 3) */
 
 typedef struct sdk_ctx sdk_ctx;
 
@@ -70,7 +70,10 @@ int sdk_get_device_info(sdk_ctx* ctx, sdk_device_info* out);
  * (likewise for the ASP logit weights, EL_ASP_W2PACK), "asp_per_segment"
  * (1 default / 0 = one workgroup per (segment, 128 channels)), "affinity_fast_path" / "affinity_variant" /
  * "affinity_whole_groups" (k = 1 affinity kernel selection), "gemm_variant" (see sdk_set_gemm_variant).  Results do not
- * depend on them. */
+ * depend on them.
+ * NOT a knob - a numerical contract: "precision" 0 (default: bf16 operands, bf16 layer-boundary storage; PCM -> score within ~4e-3 of
+ * the fp32 model) / 1 (fp16 hi+lo planes, three MFMAs per product: within 1e-5, ~3x the GEMM time).  It selects the output format of
+ * sdk_fbank (planes) and must match the weight blob's sdk_ecapa_desc.precision. */
 int sdk_set_option(sdk_ctx* ctx, const char* name, int value);
 /* Diagnostics: "stamps" = device buffer [workgroups][64] of uint64 that the affinity kernel (tools/aff_timeline.py) and the
  * Res2Net chain (tools/res2net_timeline.py) fill with in-kernel wall-clock stamps; "gemm_clock" = EXACTLY [4096][2] uint64 {shader cycles, 100 MHz ticks} of each
@@ -83,7 +86,7 @@ int sdk_debug_set_ptr(sdk_ctx* ctx, const char* name, void* device_ptr);
 enum {
   SDK_K_CONV_GEMM = 0, SDK_K_SE_GATE, SDK_K_ASP_STATS, SDK_K_ROWS_FC, SDK_K_ASP_POOL, SDK_K_FBANK_TILE,
   SDK_K_FBANK_NORM, SDK_K_L2NORM, SDK_K_AFF_COARSE, SDK_K_AFF_RESCORE, SDK_K_AFF_RESCAN, SDK_K_COPY,
-  SDK_K_AFF_MATVEC, SDK_K_CONV_GEMM256, SDK_K_ASP_FUSED, SDK_K_RES2NET, SDK_K_RESAMPLE, SDK_K_COUNT
+  SDK_K_AFF_MATVEC, SDK_K_CONV_GEMM256, SDK_K_ASP_FUSED, SDK_K_RES2NET, SDK_K_RESAMPLE, SDK_K_CONV_GEMM_HP, SDK_K_COUNT
 };
 typedef struct sdk_profile_report {
   int32_t launches[24];
@@ -100,6 +103,8 @@ int sdk_profile_end(sdk_ctx* ctx, sdk_profile_report* out);   /* synchronises th
  *       the device by the caller (16-byte aligned)
  * ws    caller scratch of sdk_fbank_workspace_bytes(B, S)
  * feats [B*T, ldf] bf16, channels 0..79 = mean-normalised log-mel, 80..ldf-1 = 0 (ldf >= 80)
+ *       precise mode ("precision" 1): fp16 planes, hi in columns [0, ldf/2), lo in [ldf/2, ldf), channels >= 80 of each zero
+ *       (ldf/2 >= 80, ldf % 16 == 0); the DFT then runs with a THREE-way bf16 split of the table (6 MFMAs per product)
  */
 size_t sdk_fbank_tables_bytes(void);
 int sdk_fbank_tables_fill(void* host_dst, size_t bytes);          /* HOST buffer */
@@ -190,6 +195,27 @@ int sdk_asp_fused_max_frames(void);
 int sdk_asp_fused(sdk_ctx* ctx, const uint16_t* ah, int64_t ldah, const uint16_t* w2, const float* b2,
                   const uint16_t* h, int64_t ldh, int B, int T, int C, int A, float* pooled, void* stream);
 
+/* ---- PRECISE MODE (sdk_set_option "precision" 1; north_star: cosine scores within 1e-5 of the fp32 model, which bf16 operands miss
+ *      by 4e-3 - profiles/r03_error_budget.md).  Tensors the default mode rounds to bf16 travel as fp16 hi + lo PLANES: a [rows, C]
+ *      activation is [rows, ld] fp16, hi values in columns [0, C), lo values `lo` columns to the right, x = float(hi) + float(lo);
+ *      the lo values are stored times 2^11 (x = float(hi) + float(lo) / 2048: always in the normal fp16 range of their hi);
+ *      GEMM weights are a 256-byte header (float 1 / 2^s) + [2][N][K] fp16 planes (hi, lo) of 2^s * W, s per layer
+ *      (weights_pack.hp_weight_planes); every product runs as three fp16 MFMAs (hi.hi + lo.hi + hi.lo), fp32 accumulate, fp32 epilogue
+ *      with libm tanh.  Same operator as sdk_conv_gemm otherwise (Cin % 32 == 0, N % 128 == 0). */
+typedef struct sdk_conv_gemm_hp_args {
+  const uint16_t* A;  int64_t lda, a_lo;
+  const uint16_t* W;                       /* the weight slot: header + [2][N][taps*Cin] fp16 planes */
+  uint16_t* C;        int64_t ldc, c_lo;   /* planes out (may be NULL) */
+  float* C32;         int64_t ldc32;       /* fp32 out (may be NULL) */
+  const float* bias;  const float* scale;  const float* shift;
+  const float* ubias; int64_t ldub;
+  const uint16_t* X2; int64_t ldx2, x2_lo; /* S = planes(v + X2) (Res2Net running sum; may be NULL) */
+  uint16_t* S;        int64_t lds, s_lo;
+  int M, N, Cin, taps, dil, T;
+  uint32_t flags;
+} sdk_conv_gemm_hp_args;
+int sdk_conv_gemm_hp(sdk_ctx* ctx, const sdk_conv_gemm_hp_args* a, void* stream);
+
 /* Whole forward: feats [B*T, ldf] bf16 -> raw embeddings emb [B, 192] fp32.
  * `wblob` is the packed device weight blob and `wdesc` (HOST) its offset table, both produced by
  * the host packer (weights_pack.py); `ws` is caller-owned scratch of sdk_ecapa_workspace_bytes(). */
@@ -197,6 +223,9 @@ typedef struct sdk_ecapa_desc {
   int32_t n_mels_padded, channels, sub_channels, scale, se_channels, attn_channels, mfa_channels, embed_dim;
   int32_t n_blocks, kernel0;
   int32_t dilation[4];
+  int32_t precision;       /* 0: bf16 operand blob (default mode); 1: fp16 hi+lo plane blob (precise mode: feats are planes [B*T, ldf] with
+                              the lo plane ldf/2 columns to the right, n_mels_padded = 96); must equal the context's "precision" option */
+  int32_t reserved0;
   /* byte offsets into wblob; -1 = absent.  Layout of the index space: see weights_pack.py */
   int64_t off[256];
 } sdk_ecapa_desc;

@@ -42,7 +42,17 @@ class EcapaDesc(C.Structure):
     _fields_ = [("n_mels_padded", C.c_int32), ("channels", C.c_int32), ("sub_channels", C.c_int32),
                 ("scale", C.c_int32), ("se_channels", C.c_int32), ("attn_channels", C.c_int32),
                 ("mfa_channels", C.c_int32), ("embed_dim", C.c_int32), ("n_blocks", C.c_int32),
-                ("kernel0", C.c_int32), ("dilation", C.c_int32 * 4), ("off", C.c_int64 * 256)]
+                ("kernel0", C.c_int32), ("dilation", C.c_int32 * 4), ("precision", C.c_int32), ("reserved0", C.c_int32),
+                ("off", C.c_int64 * 256)]
+
+
+class ConvGemmHpArgs(C.Structure):
+    """sdk_conv_gemm_hp_args (precise mode: fp16 hi+lo planes)."""
+    _fields_ = [("A", C.c_void_p), ("lda", C.c_int64), ("a_lo", C.c_int64), ("W", C.c_void_p),
+                ("C", C.c_void_p), ("ldc", C.c_int64), ("c_lo", C.c_int64), ("C32", C.c_void_p), ("ldc32", C.c_int64),
+                ("bias", C.c_void_p), ("scale", C.c_void_p), ("shift", C.c_void_p), ("ubias", C.c_void_p), ("ldub", C.c_int64),
+                ("X2", C.c_void_p), ("ldx2", C.c_int64), ("x2_lo", C.c_int64), ("S", C.c_void_p), ("lds", C.c_int64), ("s_lo", C.c_int64),
+                ("M", C.c_int), ("N", C.c_int), ("Cin", C.c_int), ("taps", C.c_int), ("dil", C.c_int), ("T", C.c_int), ("flags", C.c_uint32)]
 
 
 class ProfileReport(C.Structure):
@@ -50,8 +60,10 @@ class ProfileReport(C.Structure):
 
 
 KERNEL_FAMILIES = ["conv_gemm", "se_gate", "asp_stats", "rows_fc", "asp_pool", "fbank_tile", "fbank_norm", "l2norm",
-                   "affinity_coarse", "affinity_rescore", "affinity_rescan", "copy", "affinity_matvec", "conv_gemm256", "asp_fused", "res2net_chain", "resample"]
+                   "affinity_coarse", "affinity_rescore", "affinity_rescan", "copy", "affinity_matvec", "conv_gemm256", "asp_fused", "res2net_chain", "resample",
+                   "conv_gemm_hp"]
 
+ABI_VERSION = 2
 GEMM_RELU = 1
 GEMM_TANH = 2
 
@@ -73,6 +85,7 @@ SIGNATURES = {
     "sdk_fbank_workspace_bytes": (_sz, [_i, _i]),
     "sdk_fbank": (_i, [_vp, _vp, _i, _i, _vp, _vp, _i, _vp, _sz, _vp]),
     "sdk_conv_gemm": (_i, [_vp, C.POINTER(ConvGemmArgs), _vp]),
+    "sdk_conv_gemm_hp": (_i, [_vp, C.POINTER(ConvGemmHpArgs), _vp]),
     "sdk_set_gemm_variant": (_i, [_i]),
     "sdk_conv_gemm_stats_bytes": (_sz, [_i, _i, _i]),
     "sdk_conv_gemm_stats_fusable": (_i, [_i, _i, _i]),
@@ -124,8 +137,8 @@ def load_library() -> C.CDLL:
         fn = getattr(lib, name)  # AttributeError here = header/library mismatch
         fn.restype = res
         fn.argtypes = args
-    if lib.sdk_abi_version() != 1:
-        raise SdkError(f"libsdk_hip.so ABI {lib.sdk_abi_version()} != 1 expected by this host package")
+    if lib.sdk_abi_version() != ABI_VERSION:
+        raise SdkError(f"libsdk_hip.so ABI {lib.sdk_abi_version()} != {ABI_VERSION} expected by this host package")
     _lib = lib
     return lib
 

@@ -33,6 +33,7 @@ struct sdk_ctx {
   bool no_chain_packed = false;   // A/B + test knob: ignore the fragment-ordered copies of the Res2Net chain weights (EL_CHAINPACK)
   bool no_asp_packed = false;     // A/B + test knob: ignore the fragment-ordered copy of the ASP logit weights (EL_ASP_W2PACK)
   bool no_asp_seg = false;        // A/B + test knob: ASP by (segment, 128-channel) workgroups instead of one per segment
+  int precision = 0;              // 0: bf16 operands (default); 1: fp16 hi+lo planes, 3 MFMAs per product ("precision": hp.hip)
   int aff_fast = 1;               // k = 1 affinity: 1 = row/column-maxima kernel (affinity_rowcol.hip), 0 = general sorted-list kernel
   void* dbg_ptr = nullptr;         // diagnostics only: device buffer for the affinity kernel's time stamps (sdk_debug_set_ptr "stamps")
   void* gemm_clk_ptr = nullptr;    // diagnostics only: [4096][2] uint64 {shader cycles, 100 MHz ticks} of conv_gemm256_kernel ("gemm_clock")

@@ -20,7 +20,10 @@
 #include <math.h>
 #include <string.h>
 
+#include <type_traits>
+
 #include "common.hpp"
+#include "hp.hpp"
 
 namespace {
 
@@ -42,6 +45,9 @@ struct FbankTables {
   int32_t mlen[NMEL];
   int32_t moff[NMEL];
   float melw[MELW_MAX];
+  // precise mode ("precision" 1): the same matrix split into fp16 hi + lo (22 significand bits; the folded int16 samples split exactly
+  // there too), same fragment order - three fp16 MFMAs per product, ~2^-22 relative instead of ~2^-16
+  uint16_t dft16[NW][2][KSTEPS][2][64][8];
 };
 
 // The windowed real DFT of 32 frames as a [32 x 208] x [208 x 2*224] product on the bf16 matrix pipe at
@@ -54,6 +60,7 @@ struct FbankTables {
 // The folded, split sample images are built once per tile in LDS (rows of 432 B), so an A fragment is one
 // ds_read_b128; wave w owns bins 32w..32w+31 and keeps cos and sin accumulators in the same lane/register
 // positions, so |X|^2 forms in registers.
+template <bool F16>
 __global__ __launch_bounds__(NW * 64) __attribute__((amdgpu_waves_per_eu(4, 4))) void fbank_tile_kernel(const int16_t* __restrict__ pcm, int S, int T,
                                                             int tiles_per_seg, const FbankTables* __restrict__ tab,
                                                             float* __restrict__ L, unsigned long long* __restrict__ dbg) {
@@ -62,7 +69,10 @@ __global__ __launch_bounds__(NW * 64) __attribute__((amdgpu_waves_per_eu(4, 4)))
   int nstamp = 0;
   auto stamp = [&]() { if (dbg && threadIdx.x == 0 && blockIdx.x < 256) dbg[blockIdx.x * 16 + nstamp++] = __builtin_amdgcn_s_memrealtime(); };
   stamp();
-  bf16_t* img = reinterpret_cast<bf16_t*>(lds);                       // [cos hi | cos lo | sin hi | sin lo][32][AROW]
+  typedef typename std::conditional<F16, _Float16, bf16_t>::type el_t;       // operand element: bf16 (default) or fp16 (precise mode)
+  typedef el_t elx8 __attribute__((ext_vector_type(8)));
+  typedef el_t elx2 __attribute__((ext_vector_type(2)));
+  el_t* img = reinterpret_cast<el_t*>(lds);                           // [cos hi | cos lo | sin hi | sin lo][32][AROW]
   float* xs = reinterpret_cast<float*>(lds + 4 * FT * AROW * 2);      // raw samples of the tile
   float* pw = reinterpret_cast<float*>(lds);                          // power tile, overlays the images after the MFMAs
   static_assert(FT * PW_STRIDE * 4 <= 4 * FT * AROW * 2, "power tile must fit over the folded images");
@@ -105,12 +115,13 @@ __global__ __launch_bounds__(NW * 64) __attribute__((amdgpu_waves_per_eu(4, 4)))
         es[q] = xa - xb;
       }
     }
-    const bf16_t ch0 = f32_to_bf16(ec[0]), ch1 = f32_to_bf16(ec[1]), sh0 = f32_to_bf16(es[0]), sh1 = f32_to_bf16(es[1]);
+    const el_t ch0 = (el_t)ec[0], ch1 = (el_t)ec[1], sh0 = (el_t)es[0], sh1 = (el_t)es[1];     // RNE both ways
+    auto pk = [](float a, float b) { elx2 t; t[0] = (el_t)a; t[1] = (el_t)b; return __builtin_bit_cast(uint32_t, t); };
     uint32_t* dst = reinterpret_cast<uint32_t*>(img + i * AROW + n);
-    dst[(0 * FT * AROW) / 2] = pack2(bf16_to_f32(ch0), bf16_to_f32(ch1));
-    dst[(1 * FT * AROW) / 2] = pack2(ec[0] - bf16_to_f32(ch0), ec[1] - bf16_to_f32(ch1));
-    dst[(2 * FT * AROW) / 2] = pack2(bf16_to_f32(sh0), bf16_to_f32(sh1));
-    dst[(3 * FT * AROW) / 2] = pack2(es[0] - bf16_to_f32(sh0), es[1] - bf16_to_f32(sh1));
+    dst[(0 * FT * AROW) / 2] = pk((float)ch0, (float)ch1);
+    dst[(1 * FT * AROW) / 2] = pk(ec[0] - (float)ch0, ec[1] - (float)ch1);
+    dst[(2 * FT * AROW) / 2] = pk((float)sh0, (float)sh1);
+    dst[(3 * FT * AROW) / 2] = pk(es[0] - (float)sh0, es[1] - (float)sh1);
   }
   __syncthreads();
   stamp();
@@ -119,28 +130,32 @@ __global__ __launch_bounds__(NW * 64) __attribute__((amdgpu_waves_per_eu(4, 4)))
 #pragma unroll
   for (int r = 0; r < 16; ++r) { are[r] = 0.f; aim[r] = 0.f; }
   const int fi = lane & 31, kk = lane >> 5;
-  const bf16_t* arow = img + fi * AROW + kk * 8;
+  const el_t* arow = img + fi * AROW + kk * 8;
   // table fragments through buffer loads: ONE per-lane offset register (lane * 16), everything else - wave, part, k-step, hi/lo -
   // in the scalar offset (the 53-KiB span of a wave's slice is far beyond a global load's immediate range, and flat addressing
   // kept several 64-bit base pointers alive through the MFMA loop)
-  const __amdgpu_buffer_rsrc_t trs = __builtin_amdgcn_make_buffer_rsrc(const_cast<uint16_t*>(&tab->dft[0][0][0][0][0][0]), 0, (int)sizeof(tab->dft), 0x00020000);
+  const __amdgpu_buffer_rsrc_t trs = __builtin_amdgcn_make_buffer_rsrc(const_cast<uint16_t*>(F16 ? &tab->dft16[0][0][0][0][0][0] : &tab->dft[0][0][0][0][0][0]), 0, (int)sizeof(tab->dft), 0x00020000);
   const int wu = __builtin_amdgcn_readfirstlane(w);
   // DFT-matrix fragments (cos hi, cos lo, sin hi, sin lo) travel TWO k-steps ahead of their MFMAs through a ring of three
   // register sets: one step (6 MFMAs = 192 cycles) is far less than the L2 round trip they come from - with a single step of
   // look-ahead every k-step ended in a wait for the table.  The sample fragments (LDS) stay one step ahead.  The loop is
   // unrolled so that the ring indices are static; the scheduling fences keep hipcc from hoisting all 52 table loads at once.
-  bf16x8 bt[3][4];
-  bf16x8 ac[2][4];
-  auto load_b = [&](int ks, bf16x8* dst) {
+  elx8 bt[3][4];
+  elx8 ac[2][4];
+  auto load_b = [&](int ks, elx8* dst) {
 #pragma unroll
     for (int v = 0; v < 2; ++v) {
-      dst[v] = __builtin_bit_cast(bf16x8, __builtin_amdgcn_raw_buffer_load_b128(trs, lane * 16, ((((wu * 2 + 0) * KSTEPS + ks) * 2 + v) * 64) * 16, 0));
-      dst[2 + v] = __builtin_bit_cast(bf16x8, __builtin_amdgcn_raw_buffer_load_b128(trs, lane * 16, ((((wu * 2 + 1) * KSTEPS + ks) * 2 + v) * 64) * 16, 0));
+      dst[v] = __builtin_bit_cast(elx8, __builtin_amdgcn_raw_buffer_load_b128(trs, lane * 16, ((((wu * 2 + 0) * KSTEPS + ks) * 2 + v) * 64) * 16, 0));
+      dst[2 + v] = __builtin_bit_cast(elx8, __builtin_amdgcn_raw_buffer_load_b128(trs, lane * 16, ((((wu * 2 + 1) * KSTEPS + ks) * 2 + v) * 64) * 16, 0));
     }
   };
-  auto load_a = [&](int ks, bf16x8* dst) {
+  auto load_a = [&](int ks, elx8* dst) {
 #pragma unroll
-    for (int q = 0; q < 4; ++q) dst[q] = *reinterpret_cast<const bf16x8*>(arow + (q * FT) * AROW + ks * 16);
+    for (int q = 0; q < 4; ++q) dst[q] = *reinterpret_cast<const elx8*>(arow + (q * FT) * AROW + ks * 16);
+  };
+  auto mma = [](const elx8& a, const elx8& b, const f32x16& c) {
+    if constexpr (F16) return __builtin_amdgcn_mfma_f32_32x32x16_f16(a, b, c, 0, 0, 0);
+    else return __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b, c, 0, 0, 0);
   };
   load_b(0, bt[0]);
   load_b(1, bt[1]);
@@ -151,14 +166,14 @@ __global__ __launch_bounds__(NW * 64) __attribute__((amdgpu_waves_per_eu(4, 4)))
     if (ks + 2 < KSTEPS) load_b(ks + 2, bt[(ks + 2) % 3]);
     if (ks + 1 < KSTEPS) load_a(ks + 1, ac[(ks + 1) & 1]);
     __builtin_amdgcn_sched_barrier(0);
-    const bf16x8* bc = bt[ks % 3];
-    const bf16x8* aa = ac[ks & 1];
-    are = __builtin_amdgcn_mfma_f32_32x32x16_bf16(aa[1], bc[0], are, 0, 0, 0);     // small terms first
-    aim = __builtin_amdgcn_mfma_f32_32x32x16_bf16(aa[3], bc[2], aim, 0, 0, 0);
-    are = __builtin_amdgcn_mfma_f32_32x32x16_bf16(aa[0], bc[1], are, 0, 0, 0);
-    aim = __builtin_amdgcn_mfma_f32_32x32x16_bf16(aa[2], bc[3], aim, 0, 0, 0);
-    are = __builtin_amdgcn_mfma_f32_32x32x16_bf16(aa[0], bc[0], are, 0, 0, 0);
-    aim = __builtin_amdgcn_mfma_f32_32x32x16_bf16(aa[2], bc[2], aim, 0, 0, 0);
+    const elx8* bc = bt[ks % 3];
+    const elx8* aa = ac[ks & 1];
+    are = mma(aa[1], bc[0], are);     // small terms first
+    aim = mma(aa[3], bc[2], aim);
+    are = mma(aa[0], bc[1], are);
+    aim = mma(aa[2], bc[3], aim);
+    are = mma(aa[0], bc[0], are);
+    aim = mma(aa[2], bc[2], aim);
   }
   __syncthreads();                                       // every wave is done with the images: pw may overlay them
   // power tile -> LDS [frame][bin]
@@ -194,12 +209,14 @@ __global__ __launch_bounds__(NW * 64) __attribute__((amdgpu_waves_per_eu(4, 4)))
       for (int i = 0; i < ln; ++i) acc += pw[frame * PW_STRIDE + st + i] * melw[of + i];
       // 10 log10(x) on the hardware log2 unit (v_log_f32, ~1 ulp of log2 - far below the bf16 rounding of the feature): libm's
       // log10f was ~half of this phase (2560 calls per tile)
-      L[((int64_t)b * T + t) * NMEL + m] = 3.0102999566398120f * __log2f(fmaxf(acc, 1e-10f));
+      if constexpr (F16) L[((int64_t)b * T + t) * NMEL + m] = 10.0f * log10f(fmaxf(acc, 1e-10f));      // precise mode: libm (the hardware log2 is ~1 ulp of log2 = 6e-6 dB)
+      else L[((int64_t)b * T + t) * NMEL + m] = 3.0102999566398120f * __log2f(fmaxf(acc, 1e-10f));
     }
   }
   stamp();
 }
 
+template <bool HP>
 __global__ __launch_bounds__(256) void fbank_norm_kernel(const float* __restrict__ L, int T, bf16_t* __restrict__ feats,
                                                         int ldf) {
   __shared__ float red[256];
@@ -225,7 +242,7 @@ __global__ __launch_bounds__(256) void fbank_norm_kernel(const float* __restrict
   __syncthreads();
   if (tid < NMEL) mean[tid] = (red[tid] + red[tid + NMEL] + red[tid + 2 * NMEL]) / (float)T;
   __syncthreads();
-  const int c8n = ldf >> 3;
+  const int c8n = (HP ? ldf >> 1 : ldf) >> 3;
   bf16_t* out = feats + (int64_t)blockIdx.x * T * ldf;
   for (int i = tid; i < T * c8n; i += 256) {
     const int t = i / c8n, c8 = i - t * c8n;
@@ -235,7 +252,8 @@ __global__ __launch_bounds__(256) void fbank_norm_kernel(const float* __restrict
       const int c = c8 * 8 + e;
       f[e] = c < NMEL ? fmaxf(Ls[t * NMEL + c], flo) - mean[c] : 0.f;
     }
-    *reinterpret_cast<u32x4*>(out + (int64_t)t * ldf + c8 * 8) = pack8(f);
+    if constexpr (HP) sdk_hp::store8(reinterpret_cast<uint16_t*>(out) + (int64_t)t * ldf + c8 * 8, ldf >> 1, f);   // planes: hi | lo, ldf / 2 columns each
+    else *reinterpret_cast<u32x4*>(out + (int64_t)t * ldf + c8 * 8) = pack8(f);
   }
 }
 
@@ -245,6 +263,7 @@ __global__ __launch_bounds__(256) void fbank_norm_kernel(const float* __restrict
 // Arithmetic (and its order per mel bin: frames g, g + 3, ... per thread, three partial sums) is the streaming form's, so the
 // features are bit-identical.
 constexpr int NORM_LDS_MAX_T = 480;                      // 480 x 80 x 4 B = 150 KiB
+template <bool HP>
 __global__ __launch_bounds__(256) void fbank_norm_lds_kernel(const float* __restrict__ L, int T, bf16_t* __restrict__ feats,
                                                             int ldf) {
   extern __shared__ __attribute__((aligned(16))) float tile[];
@@ -284,7 +303,7 @@ __global__ __launch_bounds__(256) void fbank_norm_lds_kernel(const float* __rest
   __syncthreads();
   if (tid < NMEL) mean[tid] = (red[tid] + red[tid + NMEL] + red[tid + 2 * NMEL]) / (float)T;
   __syncthreads();
-  const int c8n = ldf >> 3;
+  const int c8n = (HP ? ldf >> 1 : ldf) >> 3;
   bf16_t* out = feats + (int64_t)blockIdx.x * T * ldf;
   for (int i = tid; i < T * c8n; i += 256) {
     const int t = i / c8n, c8 = i - t * c8n;
@@ -294,7 +313,8 @@ __global__ __launch_bounds__(256) void fbank_norm_lds_kernel(const float* __rest
       const int c = c8 * 8 + e;
       f[e] = c < NMEL ? fmaxf(tile[t * NMEL + c], flo) - mean[c] : 0.f;
     }
-    *reinterpret_cast<u32x4*>(out + (int64_t)t * ldf + c8 * 8) = pack8(f);
+    if constexpr (HP) sdk_hp::store8(reinterpret_cast<uint16_t*>(out) + (int64_t)t * ldf + c8 * 8, ldf >> 1, f);   // planes: hi | lo, ldf / 2 columns each
+    else *reinterpret_cast<u32x4*>(out + (int64_t)t * ldf + c8 * 8) = pack8(f);
   }
 }
 
@@ -312,6 +332,28 @@ extern "C" int sdk_fbank_tables_fill(void* host_dst, size_t bytes) {
     uint32_t u;
     memcpy(&u, &v, 4);
     return (uint16_t)((u + 0x7FFFu + ((u >> 16) & 1u)) >> 16);
+  };
+  auto f16_bits = [](double v) -> uint16_t {                 // fp16 bits of v, round-to-nearest-even, subnormals kept (|v| <= 2 here)
+    const double a = fabs(v);
+    uint16_t out;
+    if (a == 0.0) out = 0;
+    else {
+      int e;
+      (void)frexp(a, &e);                                    // a = m * 2^e, 0.5 <= m < 1
+      int ex = e - 1;                                        // a = 1.xxx * 2^ex
+      if (ex < -14) ex = -14;                                // subnormal range: fixed quantum 2^-24
+      const double q = ldexp(1.0, ex - 10);                  // spacing of fp16 at this exponent
+      double n = nearbyint(a / q);                           // default rounding mode: to nearest even
+      if (n >= 2048.0) { n /= 2.0; ex += 1; }
+      const int mant = (int)n;
+      out = mant < 1024 ? (uint16_t)mant : (uint16_t)(((ex + 15) << 10) | (mant - 1024));
+    }
+    return (uint16_t)(out | (v < 0 ? 0x8000u : 0u));
+  };
+  auto f16_val = [](uint16_t h) -> double {
+    const int e = (h >> 10) & 31, m = h & 1023;
+    const double a = e ? ldexp(1.0 + m / 1024.0, e - 15) : ldexp((double)m, -24);
+    return (h & 0x8000u) ? -a : a;
   };
   auto bf16_val = [](uint16_t b) -> float {
     const uint32_t u = (uint32_t)b << 16;
@@ -338,6 +380,11 @@ extern "C" int sdk_fbank_tables_fill(void* host_dst, size_t bytes) {
           t->dft[w][0][ks][1][l][j] = bf16_bits((float)(vc - (double)bf16_val(ch)));
           t->dft[w][1][ks][0][l][j] = sh;
           t->dft[w][1][ks][1][l][j] = bf16_bits((float)(vs - (double)bf16_val(sh)));
+          const uint16_t ch16 = f16_bits(vc), sh16 = f16_bits(vs);
+          t->dft16[w][0][ks][0][l][j] = ch16;
+          t->dft16[w][0][ks][1][l][j] = f16_bits(vc - f16_val(ch16));
+          t->dft16[w][1][ks][0][l][j] = sh16;
+          t->dft16[w][1][ks][1][l][j] = f16_bits(vs - f16_val(sh16));
         }
   // HTK-mel triangular filters, 0..8000 Hz, unit peak (oracle/fbank.py: mel_matrix)
   auto hz2mel = [](double f) { return 2595.0 * log10(1.0 + f / 700.0); };
@@ -379,6 +426,8 @@ extern "C" int sdk_fbank(sdk_ctx* ctx, const int16_t* pcm, int B, int S, const v
                          void* ws, size_t ws_bytes, void* stream) {
   SDK_REQUIRE(ctx && pcm && tabs && feats && ws, "sdk_fbank: null argument");
   SDK_REQUIRE(B > 0 && S > 0, "sdk_fbank: empty batch (B=%d S=%d)", B, S);
+  const bool hp = ctx->precision == 1;
+  if (hp) SDK_REQUIRE((ldf >> 1) >= NMEL && ldf % 16 == 0, "sdk_fbank: precise mode writes planes: ldf=%d must be >= 160 and a multiple of 16", ldf);
   SDK_REQUIRE(ldf >= NMEL && ldf % 8 == 0, "sdk_fbank: ldf=%d must be >= 80 and a multiple of 8", ldf);
   SDK_REQUIRE(ws_bytes >= sdk_fbank_workspace_bytes(B, S), "sdk_fbank: workspace too small");
   SDK_REQUIRE(((uintptr_t)feats % 16) == 0 && ((uintptr_t)tabs % 16) == 0, "sdk_fbank: feats/tabs must be 16-byte aligned");
@@ -387,17 +436,17 @@ extern "C" int sdk_fbank(sdk_ctx* ctx, const int16_t* pcm, int B, int S, const v
   SDK_REQUIRE((int64_t)B * tps < (1ll << 31), "sdk_fbank: batch too large for one launch");
   {
   ProfScope ps(ctx, stream, SDK_K_FBANK_TILE, 3 * 2.0 * B * T * (double)NSYM * 2 * (NW * 32) + 2.0 * B * T * NBIN * NMEL, 2.0 * B * S + 4.0 * B * T * NMEL);
-  hipLaunchKernelGGL(fbank_tile_kernel, dim3(B * tps), dim3(NW * 64), 0, (hipStream_t)stream, pcm, S, T, tps,
+  hipLaunchKernelGGL(hp ? fbank_tile_kernel<true> : fbank_tile_kernel<false>, dim3(B * tps), dim3(NW * 64), 0, (hipStream_t)stream, pcm, S, T, tps,
                      (const FbankTables*)tabs, (float*)ws, (unsigned long long*)ctx->dbg_ptr);
   }
   SDK_LAUNCH_CHECK();
   ProfScope ps2(ctx, stream, SDK_K_FBANK_NORM, 3.0 * B * T * NMEL, 4.0 * B * T * NMEL + 2.0 * B * T * ldf);
   if (T <= NORM_LDS_MAX_T) {
     const int lds = T * NMEL * 4;
-    if (sdk_lds_optin(ctx, (const void*)fbank_norm_lds_kernel, NORM_LDS_MAX_T * NMEL * 4)) return 1;   // (opt-in is per function: the maximum)
-    hipLaunchKernelGGL(fbank_norm_lds_kernel, dim3(B), dim3(256), lds, (hipStream_t)stream, (const float*)ws, T, (bf16_t*)feats, ldf);
+    if (sdk_lds_optin(ctx, hp ? (const void*)fbank_norm_lds_kernel<true> : (const void*)fbank_norm_lds_kernel<false>, NORM_LDS_MAX_T * NMEL * 4)) return 1;   // (opt-in is per function: the maximum)
+    hipLaunchKernelGGL(hp ? fbank_norm_lds_kernel<true> : fbank_norm_lds_kernel<false>, dim3(B), dim3(256), lds, (hipStream_t)stream, (const float*)ws, T, (bf16_t*)feats, ldf);
   } else {
-    hipLaunchKernelGGL(fbank_norm_kernel, dim3(B), dim3(256), 0, (hipStream_t)stream, (const float*)ws, T, (bf16_t*)feats, ldf);
+    hipLaunchKernelGGL(hp ? fbank_norm_kernel<true> : fbank_norm_kernel<false>, dim3(B), dim3(256), 0, (hipStream_t)stream, (const float*)ws, T, (bf16_t*)feats, ldf);
   }
   SDK_LAUNCH_CHECK();
   return 0;

@@ -6,6 +6,7 @@
 
 #include "common.hpp"
 #include "ecapa_layout.h"
+#include "hp.hpp"
 
 static thread_local char g_err[512] = "";
 
@@ -83,6 +84,11 @@ extern "C" int sdk_set_option(sdk_ctx* ctx, const char* name, int value) {
   if (strcmp(name, "res2net_two_per_cu") == 0) { ctx->no_chain_two_per_cu = value == 0; return 0; }
   if (strcmp(name, "asp_packed_weights") == 0) { ctx->no_asp_packed = value == 0; return 0; }
   if (strcmp(name, "asp_per_segment") == 0) { ctx->no_asp_seg = value == 0; return 0; }
+  if (strcmp(name, "precision") == 0) {
+    SDK_REQUIRE(value == 0 || value == 1, "sdk_set_option: precision must be 0 (bf16 operands) or 1 (fp16 hi+lo planes), got %d", value);
+    ctx->precision = value;
+    return 0;
+  }
   if (strcmp(name, "gemm_variant") == 0) return sdk_set_gemm_variant(value);
   if (strcmp(name, "affinity_fast_path") == 0) { ctx->aff_fast = value; return 0; }
   if (strcmp(name, "affinity_variant") == 0) { ctx->aff_variant = value; return 0; }
@@ -170,20 +176,134 @@ size_t fwd_layout(const sdk_ecapa_desc* d, int B, int T, char* base, FwdWs* w) {
   return off;
 }
 
+// ---- precise mode: every activation a pair of fp16 planes [M, 2 C] (hi | lo), logits fp32
+struct FwdWsHp {
+  uint16_t *X0, *U, *R, *Z, *Sa, *Sb, *CAT, *H, *AH;
+  float *ctx, *ubias, *logits, *pooled, *mean, *hid, *gate;
+};
+
+size_t fwd_layout_hp(const sdk_ecapa_desc* d, int B, int T, char* base, FwdWsHp* w) {
+  const size_t M = (size_t)B * T, C = d->channels, Cm = d->mfa_channels, S = d->sub_channels, A = d->attn_channels;
+  size_t off = 0;
+  auto take = [&](size_t bytes) { char* p = base ? base + off : nullptr; off += a256(bytes); return p; };
+  char* x0 = take(M * C * 4);
+  char* u = take(M * C * 4);
+  char* r = take(M * C * 4);
+  char* z = take(M * C * 4);
+  char* sa = take(M * S * 4);
+  char* sb = take(M * S * 4);
+  char* cat = take(M * Cm * 4);
+  char* h = take(M * Cm * 4);
+  char* ah = take(M * A * 4);
+  char* cx = take((size_t)B * 2 * Cm * 4);
+  char* ub = take((size_t)B * A * 4);
+  char* lg = take(M * Cm * 4);
+  char* po = take((size_t)B * 2 * Cm * 4);
+  char* mn = take((size_t)B * C * 4);
+  char* hd = take((size_t)B * d->se_channels * 4);
+  char* gt = take((size_t)B * C * 4);
+  if (w) {
+    w->X0 = (uint16_t*)x0; w->U = (uint16_t*)u; w->R = (uint16_t*)r; w->Z = (uint16_t*)z; w->Sa = (uint16_t*)sa; w->Sb = (uint16_t*)sb;
+    w->CAT = (uint16_t*)cat; w->H = (uint16_t*)h; w->AH = (uint16_t*)ah; w->ctx = (float*)cx; w->ubias = (float*)ub; w->logits = (float*)lg;
+    w->pooled = (float*)po; w->mean = (float*)mn; w->hid = (float*)hd; w->gate = (float*)gt;
+  }
+  return off;
+}
+
 int check_desc(const sdk_ecapa_desc* d) {
   SDK_REQUIRE(d, "ecapa desc is null");
   SDK_REQUIRE(d->n_blocks >= 1 && d->n_blocks <= 4, "ecapa desc: n_blocks=%d", d->n_blocks);
   SDK_REQUIRE(d->channels % 128 == 0 && d->mfa_channels == d->n_blocks * d->channels, "ecapa desc: channels=%d mfa=%d", d->channels, d->mfa_channels);
   SDK_REQUIRE(d->scale >= 2 && d->sub_channels * d->scale == d->channels && d->sub_channels % 128 == 0, "ecapa desc: res2net scale=%d sub=%d", d->scale, d->sub_channels);
-  SDK_REQUIRE(d->attn_channels % 128 == 0 && d->n_mels_padded % 64 == 0, "ecapa desc: attn=%d mels=%d", d->attn_channels, d->n_mels_padded);
+  SDK_REQUIRE(d->attn_channels % 128 == 0 && d->n_mels_padded % (d->precision == 1 ? 32 : 64) == 0, "ecapa desc: attn=%d mels=%d", d->attn_channels, d->n_mels_padded);
   SDK_REQUIRE((d->kernel0 & 1) == 1, "ecapa desc: kernel0=%d must be odd", d->kernel0);
+  SDK_REQUIRE(d->precision == 0 || d->precision == 1, "ecapa desc: precision=%d", d->precision);
   return 0;
+}
+
+// The forward in precise mode (hp.hip): the same layer sequence on fp16 hi+lo planes, every GEMM as three fp16 MFMAs per product,
+// no fusion (the Res2Net chain as seven launches with the running sum in the epilogue, SE as mean sweep + two FCs + apply sweep,
+// attention logits in fp32 through HBM): this mode buys accuracy, the default mode is the fast one.
+int ecapa_forward_hp(sdk_ctx* ctx, const void* wblob, const sdk_ecapa_desc* d, const uint16_t* feats, int ldf, int B, int T, void* ws,
+                     float* emb, void* stream) {
+  FwdWsHp w;
+  fwd_layout_hp(d, B, T, (char*)ws, &w);
+  const char* wb = (const char*)wblob;
+  auto P16 = [&](int slot) -> const uint16_t* { return d->off[slot] < 0 ? nullptr : (const uint16_t*)(wb + d->off[slot]); };
+  auto P32 = [&](int slot) -> const float* { return d->off[slot] < 0 ? nullptr : (const float*)(wb + d->off[slot]); };
+  const int M = B * T, C = d->channels, Cm = d->mfa_channels, S = d->sub_channels, A = d->attn_channels;
+  const int flo = ldf >> 1;
+  SDK_REQUIRE(ldf % 16 == 0 && flo >= d->n_mels_padded, "sdk_ecapa_forward: precise mode takes feature planes, ldf=%d must be >= 2 x %d", ldf, d->n_mels_padded);
+
+  auto tdnn = [&](const uint16_t* Ain, int64_t lda, int64_t a_lo, int Cin, int taps, int dil, int slot, int N, uint16_t* Cout, int64_t ldc, int64_t c_lo,
+                  const uint16_t* X2, int64_t ldx2, int64_t x2_lo, uint16_t* Sout, int64_t lds, int64_t s_lo) -> int {
+    sdk_conv_gemm_hp_args g;
+    memset(&g, 0, sizeof(g));
+    g.A = Ain; g.lda = lda; g.a_lo = a_lo; g.W = P16(slot + EL_W); g.C = Cout; g.ldc = ldc; g.c_lo = c_lo;
+    g.bias = P32(slot + EL_B); g.scale = P32(slot + EL_SCALE); g.shift = P32(slot + EL_SHIFT);
+    g.X2 = X2; g.ldx2 = ldx2; g.x2_lo = x2_lo; g.S = Sout; g.lds = lds; g.s_lo = s_lo;
+    g.M = M; g.N = N; g.Cin = Cin; g.taps = taps; g.dil = dil; g.T = T; g.flags = SDK_GEMM_RELU;
+    SDK_REQUIRE(g.W && g.bias && g.scale && g.shift, "sdk_ecapa_forward: weight slot %d missing", slot);
+    return sdk_conv_gemm_hp(ctx, &g, stream);
+  };
+  hipStream_t st = (hipStream_t)stream;
+
+  if (int rc = tdnn(feats, ldf, flo, d->n_mels_padded, d->kernel0, 1, EL_BLK0, C, w.X0, 2 * C, C, nullptr, 0, 0, nullptr, 0, 0)) return rc;
+  const uint16_t* xin = w.X0;
+  int64_t ldx = 2 * C, xlo = C;
+  for (int i = 1; i <= d->n_blocks; ++i) {
+    const int base = EL_BLOCK_BASE(i), dil = d->dilation[i - 1];
+    if (int rc = tdnn(xin, ldx, xlo, C, 1, 1, base + EL_TDNN1, C, w.U, 2 * C, C, nullptr, 0, 0, nullptr, 0, 0)) return rc;
+    {   // Res2Net chunk 0 passes through: both planes
+      ProfScope ps(ctx, stream, SDK_K_COPY, 0.0, 2.0 * M * S * 4);
+      SDK_HIP_OK(hipMemcpy2DAsync(w.R, (size_t)C * 4, w.U, (size_t)C * 4, (size_t)S * 2, (size_t)M, hipMemcpyDeviceToDevice, st));
+      SDK_HIP_OK(hipMemcpy2DAsync(w.R + C, (size_t)C * 4, w.U + C, (size_t)C * 4, (size_t)S * 2, (size_t)M, hipMemcpyDeviceToDevice, st));
+    }
+    for (int j = 0; j < d->scale - 1; ++j) {
+      const uint16_t* Ain = j == 0 ? w.U + S : ((j & 1) ? w.Sa : w.Sb);
+      const int64_t lda = j == 0 ? 2 * C : 2 * S, alo = j == 0 ? C : S;
+      const bool more = j + 1 < d->scale - 1;
+      uint16_t* Sout = more ? ((j & 1) ? w.Sb : w.Sa) : nullptr;
+      const uint16_t* X2 = more ? w.U + (int64_t)S * (j + 2) : nullptr;
+      if (int rc = tdnn(Ain, lda, alo, S, 3, dil, base + EL_RES2NET(j), S, w.R + (int64_t)S * (j + 1), 2 * C, C, X2, 2 * C, C, Sout, 2 * S, S)) return rc;
+    }
+    if (int rc = tdnn(w.R, 2 * C, C, C, 1, 1, base + EL_TDNN2, C, w.Z, 2 * C, C, nullptr, 0, 0, nullptr, 0, 0)) return rc;
+    // squeeze-excitation: mean sweep, two per-utterance FCs (fp32 matrix pipe), apply sweep
+    if (int rc = hp_seg_mean(ctx, w.Z, 2 * C, C, B, T, C, w.mean, stream)) return rc;
+    if (int rc = sdk_rows_fc(ctx, w.mean, C, nullptr, nullptr, P32(base + EL_SE_W1T), P32(base + EL_SE_B1), w.hid, d->se_channels, B, C, d->se_channels, 1, stream)) return rc;
+    if (int rc = sdk_rows_fc(ctx, w.hid, d->se_channels, nullptr, nullptr, P32(base + EL_SE_W2T), P32(base + EL_SE_B2), w.gate, C, B, d->se_channels, C, 2, stream)) return rc;
+    uint16_t* slab = w.CAT + (int64_t)C * (i - 1);
+    if (int rc = hp_se_apply(ctx, w.Z, 2 * C, C, xin, ldx, xlo, w.gate, slab, 2 * Cm, Cm, B, T, C, stream)) return rc;
+    xin = slab;
+    ldx = 2 * Cm;
+    xlo = Cm;
+  }
+  const int tb = EL_TAIL_BASE(d->n_blocks);
+  if (int rc = tdnn(w.CAT, 2 * Cm, Cm, Cm, 1, 1, tb + EL_MFA, Cm, w.H, 2 * Cm, Cm, nullptr, 0, 0, nullptr, 0, 0)) return rc;
+  if (int rc = hp_asp_stats(ctx, w.H, 2 * Cm, Cm, B, T, Cm, w.ctx, stream)) return rc;
+  if (int rc = sdk_rows_fc(ctx, w.ctx, 2 * Cm, nullptr, nullptr, P32(tb + EL_ASP_WMS_T), P32(tb + EL_ASP_B), w.ubias, A, B, 2 * Cm, A, 0, stream)) return rc;
+  {
+    sdk_conv_gemm_hp_args g;
+    memset(&g, 0, sizeof(g));
+    g.A = w.H; g.lda = 2 * Cm; g.a_lo = Cm; g.W = P16(tb + EL_ASP_WH); g.C = w.AH; g.ldc = 2 * A; g.c_lo = A;
+    g.ubias = w.ubias; g.ldub = A; g.scale = P32(tb + EL_ASP_SCALE); g.shift = P32(tb + EL_ASP_SHIFT);
+    g.M = M; g.N = A; g.Cin = Cm; g.taps = 1; g.dil = 1; g.T = T; g.flags = SDK_GEMM_RELU | SDK_GEMM_TANH;
+    if (int rc = sdk_conv_gemm_hp(ctx, &g, stream)) return rc;
+    memset(&g, 0, sizeof(g));
+    g.A = w.AH; g.lda = 2 * A; g.a_lo = A; g.W = P16(tb + EL_ASP_W2); g.C32 = w.logits; g.ldc32 = Cm; g.bias = P32(tb + EL_ASP_B2);
+    g.M = M; g.N = Cm; g.Cin = A; g.taps = 1; g.dil = 1; g.T = T; g.flags = 0;
+    if (int rc = sdk_conv_gemm_hp(ctx, &g, stream)) return rc;
+  }
+  if (int rc = hp_asp_pool(ctx, w.logits, Cm, w.H, 2 * Cm, Cm, B, T, Cm, w.pooled, stream)) return rc;
+  return sdk_rows_fc(ctx, w.pooled, 2 * Cm, P32(tb + EL_ASPBN_SCALE), P32(tb + EL_ASPBN_SHIFT), P32(tb + EL_FC_WT), P32(tb + EL_FC_B), emb,
+                     d->embed_dim, B, 2 * Cm, d->embed_dim, 0, stream);
 }
 
 }  // namespace
 
 extern "C" size_t sdk_ecapa_workspace_bytes(const sdk_ecapa_desc* d, int B, int T) {
   if (!d || B <= 0 || T <= 0) return 0;
+  if (d->precision == 1) return fwd_layout_hp(d, B, T, nullptr, nullptr);
   return fwd_layout(d, B, T, nullptr, nullptr);
 }
 
@@ -194,6 +314,8 @@ extern "C" int sdk_ecapa_forward(sdk_ctx* ctx, const void* wblob, const sdk_ecap
   SDK_REQUIRE(B > 0 && T > 0, "sdk_ecapa_forward: empty batch (B=%d T=%d)", B, T);
   SDK_REQUIRE((int64_t)B * T < (1ll << 31), "sdk_ecapa_forward: B*T overflows int32; split the batch");
   SDK_REQUIRE(ldf >= d->n_mels_padded && ldf % 8 == 0, "sdk_ecapa_forward: ldf=%d < padded mel width %d", ldf, d->n_mels_padded);
+  SDK_REQUIRE(d->precision == ctx->precision, "sdk_ecapa_forward: the weight blob was packed for precision %d but the context runs precision %d "
+              "(sdk_set_option \"precision\"; features and weights must be in the same format)", d->precision, ctx->precision);
   int maxhalo = d->kernel0 / 2;
   for (int i = 0; i < d->n_blocks; ++i) maxhalo = d->dilation[i] > maxhalo ? d->dilation[i] : maxhalo;
   SDK_REQUIRE(T > maxhalo, "sdk_ecapa_forward: segments of %d frames are shorter than the receptive halo %d", T, maxhalo);
@@ -208,6 +330,7 @@ extern "C" int sdk_ecapa_forward(sdk_ctx* ctx, const void* wblob, const sdk_ecap
         SDK_REQUIRE(d->off[EL_BLOCK_BASE(i) + s] >= 0, "sdk_ecapa_forward: SE weight slot %d of block %d missing", s, i);
     for (int s = EL_ASP_WH; s <= EL_FC_B; ++s) SDK_REQUIRE(d->off[tbs + s] >= 0, "sdk_ecapa_forward: tail weight slot %d missing", s);
   }
+  if (d->precision == 1) return ecapa_forward_hp(ctx, wblob, d, feats, ldf, B, T, ws, emb, stream);
   FwdWs w;
   fwd_layout(d, B, T, (char*)ws, &w);
   const char* wb = (const char*)wblob;

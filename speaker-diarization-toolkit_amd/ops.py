@@ -17,7 +17,7 @@ import torch
 from . import _lib, resample
 from ._lib import ConvGemmArgs, EcapaDesc, SdkError, check
 from .weights import DEFAULT_CONFIG, EcapaConfig, synthetic_weights
-from .weights_pack import N_MELS_PADDED, pack_weights
+from .weights_pack import N_MELS_PADDED, N_MELS_PADDED_HP, pack_weights
 
 HOP = 160
 EMBED_DIM = 192
@@ -54,6 +54,8 @@ class Engine:
         self._seed = seed
         self._wblob = None
         self._desc = None
+        self._packed = {}                 # precision -> (device blob, desc): each numerical contract has its own weight format
+        self.precision = 0
         self._fbank_tabs = None
         self._scratch: Dict[str, torch.Tensor] = {}
         self._graphs: Dict[tuple, tuple] = {}
@@ -79,19 +81,33 @@ class Engine:
     def load_weights(self, weights: Optional[Dict[str, np.ndarray]] = None) -> None:
         if weights is not None:
             self._weights_host = weights
+            self._packed.clear()
         if self._weights_host is None:
             self._weights_host = synthetic_weights(self._seed, self.cfg)
-        blob, f = pack_weights(self._weights_host, self.cfg)
-        self._wblob = torch.from_numpy(blob).to(self.device)
-        d = EcapaDesc()
-        for k, v in f.items():
-            if k == "dilation":
-                d.dilation = (C.c_int32 * 4)(*v)
-            elif k == "off":
-                d.off = (C.c_int64 * 256)(*v)
-            else:
-                setattr(d, k, v)
-        self._desc = d
+        if self.precision not in self._packed:
+            blob, f = pack_weights(self._weights_host, self.cfg, precision=self.precision)
+            d = EcapaDesc()
+            for k, v in f.items():
+                if k == "dilation":
+                    d.dilation = (C.c_int32 * 4)(*v)
+                elif k == "off":
+                    d.off = (C.c_int64 * 256)(*v)
+                else:
+                    setattr(d, k, v)
+            self._packed[self.precision] = (torch.from_numpy(blob).to(self.device), d)
+        self._wblob, self._desc = self._packed[self.precision]
+
+    def set_precision(self, precision: int) -> None:
+        """0 (default): bf16 GEMM operands, bf16 layer-boundary storage - PCM -> cosine score within ~4e-3 of the fp32 model.
+        1: the precise mode (csrc/hp.hip): fp16 hi+lo planes and three MFMAs per product everywhere, within 1e-5 (north_star's
+        tolerance), ~3x the GEMM time.  Selects the fbank output format and the weight blob together; embeddings of the two modes
+        are comparable with each other at the 4e-3 level only."""
+        if precision not in (0, 1):
+            raise SdkError(f"precision must be 0 or 1, got {precision}")
+        self.set_option("precision", precision)
+        self.precision = precision
+        self._wblob = self._desc = None
+        self._graphs.clear()
 
     @property
     def desc(self) -> EcapaDesc:
@@ -136,13 +152,16 @@ class Engine:
         return y
 
     # ------------------------------------------------------------------ k1
-    def fbank(self, pcm: torch.Tensor, ldf: int = N_MELS_PADDED) -> torch.Tensor:
-        """pcm [B, S] int16 (device) -> feats [B*T, ldf] bf16 (channels >= 80 are zero)."""
+    def fbank(self, pcm: torch.Tensor, ldf: Optional[int] = None) -> torch.Tensor:
+        """pcm [B, S] int16 (device) -> feats [B*T, ldf] bf16 (channels >= 80 are zero); in precise mode fp16 planes
+        [B*T, 2 x 96]: hi values in columns [0, 96), lo values (times 2^11) in [96, 192)."""
         _need(pcm, torch.int16, "pcm")
         pcm = pcm.contiguous()
         B, S = pcm.shape
         T = num_frames(S)
-        feats = torch.empty((B * T, ldf), dtype=torch.bfloat16, device=self.device)
+        if ldf is None:
+            ldf = 2 * N_MELS_PADDED_HP if self.precision == 1 else N_MELS_PADDED
+        feats = torch.empty((B * T, ldf), dtype=torch.float16 if self.precision == 1 else torch.bfloat16, device=self.device)
         wsb = self.lib.sdk_fbank_workspace_bytes(B, S)
         ws = self._scratch_bytes("fbank", wsb)
         check(self.lib.sdk_fbank(self.ctx, pcm.data_ptr(), B, S, self.fbank_tables().data_ptr(), feats.data_ptr(), ldf,
@@ -151,8 +170,8 @@ class Engine:
 
     # ------------------------------------------------------------------ k2
     def ecapa_forward(self, feats: torch.Tensor, B: int, T: int) -> torch.Tensor:
-        """feats [B*T, ldf] bf16 -> raw embeddings [B, 192] fp32."""
-        _need(feats, torch.bfloat16, "feats")
+        """feats [B*T, ldf] bf16 (precise mode: fp16 planes) -> raw embeddings [B, 192] fp32."""
+        _need(feats, torch.float16 if self.precision == 1 else torch.bfloat16, "feats")
         if feats.shape[0] != B * T or feats.stride(1) != 1:
             raise SdkError(f"feats must be [B*T={B * T}, ldf] row-major, got {tuple(feats.shape)}")
         d = self.desc
@@ -275,6 +294,45 @@ class Engine:
             st = torch.empty((M // T, N * stats_mode), dtype=torch.float32, device=self.device)
             check(self.lib.sdk_colstats_finish(self.ctx, part.data_ptr(), M, N, T, stats_mode, st.data_ptr(), _stream()), "sdk_colstats_finish")
             return Cout, C32, S, st
+        return Cout, C32, S
+
+    # ---- precise mode building blocks (csrc/hp.hip) ------------------------------------------------
+    @staticmethod
+    def to_planes(x: torch.Tensor) -> torch.Tensor:
+        """fp32 [M, C] -> fp16 planes [M, 2C]: hi | lo * 2^11 (the format csrc/hp.hpp stores; same arithmetic, for tests and tools)."""
+        x = x.float().clamp(-65504.0, 65504.0)
+        hi = x.to(torch.float16)
+        lo = ((x - hi.float()) * 2048.0).to(torch.float16)
+        return torch.cat([hi, lo], dim=1).contiguous()
+
+    @staticmethod
+    def from_planes(p: torch.Tensor) -> torch.Tensor:
+        c = p.shape[1] // 2
+        return p[:, :c].float() + p[:, c:].float() * (1.0 / 2048.0)
+
+    def conv_gemm_hp(self, A, Wslot, N, Cin, taps=1, dil=1, T=None, bias=None, scale=None, shift=None, ubias=None,
+                     relu=False, tanh=False, out_planes=True, out_f32=False, X2=None):
+        """A: fp16 planes [M, 2*Cin']; Wslot: uint16/fp16 device tensor holding weights_pack.hp_weight_planes(W [N, taps*Cin]).
+        Returns (C planes [M, 2N] or None, C32 fp32 or None, S planes or None)."""
+        from ._lib import ConvGemmHpArgs
+        _need(A, torch.float16, "A")
+        M = A.shape[0]
+        T = T or M
+        g = ConvGemmHpArgs()
+        g.A, g.lda, g.a_lo, g.W = A.data_ptr(), A.stride(0), A.shape[1] // 2, Wslot.data_ptr()
+        Cout = torch.empty((M, 2 * N), dtype=torch.float16, device=self.device) if out_planes else None
+        C32 = torch.empty((M, N), dtype=torch.float32, device=self.device) if out_f32 else None
+        S = torch.empty((M, 2 * N), dtype=torch.float16, device=self.device) if X2 is not None else None
+        g.C, g.ldc, g.c_lo, g.C32, g.ldc32 = _ptr(Cout), 2 * N, N, _ptr(C32), N
+        g.bias, g.scale, g.shift = _ptr(bias), _ptr(scale), _ptr(shift)
+        g.ubias, g.ldub = _ptr(ubias), (ubias.stride(0) if ubias is not None else 0)
+        if X2 is not None:
+            _need(X2, torch.float16, "X2")
+            g.X2, g.ldx2, g.x2_lo = X2.data_ptr(), X2.stride(0), X2.shape[1] // 2
+            g.S, g.lds, g.s_lo = S.data_ptr(), 2 * N, N
+        g.M, g.N, g.Cin, g.taps, g.dil, g.T = M, N, Cin, taps, dil, T
+        g.flags = (_lib.GEMM_RELU if relu else 0) | (_lib.GEMM_TANH if tanh else 0)
+        check(self.lib.sdk_conv_gemm_hp(self.ctx, C.byref(g), _stream()), "sdk_conv_gemm_hp")
         return Cout, C32, S
 
     def se_gate_residual(self, z, x, w1t, b1, w2t, b2, B, T, split: bool = True):

@@ -95,9 +95,54 @@ def conv_weight_kmajor(w: np.ndarray, cin_pad: int | None = None) -> np.ndarray:
     return f32_to_bf16_bits(out.reshape(co, k * cp))
 
 
-def pack_weights(weights: Dict[str, np.ndarray], cfg: EcapaConfig = DEFAULT_CONFIG):
-    """Return (blob: np.uint8 [bytes], desc_fields: dict) - host side only, no device access."""
+N_MELS_PADDED_HP = 96          # precise mode: the mel channels padded to the next multiple of its 32-wide K-step
+HP_WHDR = 128                  # fp16 elements (256 bytes) in front of a precise weight slot's planes (csrc/hp.hpp)
+
+
+def hp_weight_planes(wk: np.ndarray) -> np.ndarray:
+    """fp32 [N, K] (K contiguous) -> the precise mode's weight slot (csrc/hp.hip): a 256-byte header whose first float is 2^-s, then
+    the fp16 planes hi = fp16(2^s W), lo = fp16(2^s W - hi), both [N, K].  s is the largest power of two that keeps max |2^s W| <= 2^13:
+    the lo plane of every weight above 2^-13 of the largest stays in fp16's normal range (22 significand bits for the pair)."""
+    wk = np.ascontiguousarray(wk, dtype=np.float32)
+    amax = float(np.abs(wk).max())
+    s = 0 if amax == 0.0 else int(np.clip(np.floor(np.log2(8192.0 / amax)), -14, 60))
+    scaled = wk.astype(np.float64) * (2.0 ** s)
+    hi = scaled.astype(np.float16)
+    lo = (scaled - hi.astype(np.float64)).astype(np.float16)
+    assert np.isfinite(hi.astype(np.float32)).all()
+    out = np.zeros(HP_WHDR + 2 * wk.size, dtype=np.uint16)
+    out[:2] = np.array([2.0 ** -s], dtype=np.float32).view(np.uint16)
+    out[HP_WHDR:HP_WHDR + wk.size] = hi.view(np.uint16).reshape(-1)
+    out[HP_WHDR + wk.size:] = lo.view(np.uint16).reshape(-1)
+    return out
+
+
+def hp_planes_to_f64(slot: np.ndarray, n: int, k: int) -> np.ndarray:
+    """Inverse of hp_weight_planes (tests): the value the precise GEMM multiplies by."""
+    inv = float(slot[:2].view(np.float32)[0])
+    hi = slot[HP_WHDR:HP_WHDR + n * k].view(np.float16).astype(np.float64)
+    lo = slot[HP_WHDR + n * k:HP_WHDR + 2 * n * k].view(np.float16).astype(np.float64)
+    return ((hi + lo) * inv).reshape(n, k)
+
+
+def conv_weight_kmajor_f32(w: np.ndarray, cin_pad: int | None = None) -> np.ndarray:
+    """[C_out, C_in, k] -> fp32 [C_out, k * C_in_pad] (tap-major, zero-padded channels)."""
+    co, ci, k = w.shape
+    cp = cin_pad or ci
+    out = np.zeros((co, k, cp), dtype=np.float32)
+    out[:, :, :ci] = np.transpose(w, (0, 2, 1))
+    return out.reshape(co, k * cp)
+
+
+def pack_weights(weights: Dict[str, np.ndarray], cfg: EcapaConfig = DEFAULT_CONFIG, precision: int = 0):
+    """Return (blob: np.uint8 [bytes], desc_fields: dict) - host side only, no device access.
+    precision 0: bf16 GEMM operands (default mode).  precision 1 (precise mode, csrc/hp.hip): every GEMM weight slot holds fp16
+    hi+lo planes behind a scale header (hp_weight_planes), the mel channels are padded to 96, no fragment-ordered copies;
+    everything fp32 is identical in both blobs."""
     check_weights(weights, cfg)
+    assert precision in (0, 1)
+    hp = precision == 1
+    mel_pad = N_MELS_PADDED_HP if hp else N_MELS_PADDED
     chunks: List[Tuple[int, np.ndarray]] = []
     off = [-1] * 256
     cur = 0
@@ -111,21 +156,25 @@ def pack_weights(weights: Dict[str, np.ndarray], cfg: EcapaConfig = DEFAULT_CONF
         chunks.append((cur, a.view(np.uint8).reshape(-1)))
         cur += (a.nbytes + ALIGN - 1) // ALIGN * ALIGN
 
+    def gemm_w(w3: np.ndarray, cin_pad=None) -> np.ndarray:
+        """[C_out, C_in, k] conv weight -> the slot content of the blob's precision"""
+        return hp_weight_planes(conv_weight_kmajor_f32(w3, cin_pad)) if hp else conv_weight_kmajor(w3, cin_pad)
+
     def tdnn(slot: int, name: str, cin_pad=None):
-        put(slot + EL_W, conv_weight_kmajor(weights[f"{name}.conv.w"], cin_pad))
+        put(slot + EL_W, gemm_w(weights[f"{name}.conv.w"], cin_pad))
         put(slot + EL_B, weights[f"{name}.conv.b"].astype(np.float32))
         s, sh = bn_affine(weights, f"{name}.bn")
         put(slot + EL_SCALE, s)
         put(slot + EL_SHIFT, sh)
 
     nb = len(cfg.dilations)
-    tdnn(EL_BLK0, "blk0", N_MELS_PADDED)
+    tdnn(EL_BLK0, "blk0", mel_pad)
     for i in range(1, nb + 1):
         b = block_base(i)
         tdnn(b + EL_TDNN1, f"blk{i}.tdnn1")
         for j in range(cfg.res2net_scale - 1):
             tdnn(b + res2net_slot(j), f"blk{i}.res2net.{j}")
-            if cfg.sub_channels == 128 and i <= 4 and j < 7:
+            if cfg.sub_channels == 128 and i <= 4 and j < 7 and not hp:
                 put(chainpack_slot(i, j), chain_fragment_order(conv_weight_kmajor(weights[f"blk{i}.res2net.{j}.conv.w"])))
         tdnn(b + EL_TDNN2, f"blk{i}.tdnn2")
         put(b + EL_SE_W1T, weights[f"blk{i}.se.conv1.w"][:, :, 0].T.astype(np.float32))
@@ -136,14 +185,14 @@ def pack_weights(weights: Dict[str, np.ndarray], cfg: EcapaConfig = DEFAULT_CONF
     tdnn(t + EL_MFA, "mfa")
     m = cfg.mfa_channels
     wt = weights["asp.tdnn.conv.w"][:, :, 0]
-    put(t + EL_ASP_WH, f32_to_bf16_bits(wt[:, :m]))
+    put(t + EL_ASP_WH, hp_weight_planes(wt[:, :m]) if hp else f32_to_bf16_bits(wt[:, :m]))
     put(t + EL_ASP_WMS_T, wt[:, m:].T.astype(np.float32))
     put(t + EL_ASP_B, weights["asp.tdnn.conv.b"])
     s, sh = bn_affine(weights, "asp.tdnn.bn")
     put(t + EL_ASP_SCALE, s)
     put(t + EL_ASP_SHIFT, sh)
-    put(t + EL_ASP_W2, f32_to_bf16_bits(weights["asp.conv.w"][:, :, 0]))
-    if cfg.attn_channels == 128 and m % 32 == 0:
+    put(t + EL_ASP_W2, hp_weight_planes(weights["asp.conv.w"][:, :, 0]) if hp else f32_to_bf16_bits(weights["asp.conv.w"][:, :, 0]))
+    if cfg.attn_channels == 128 and m % 32 == 0 and not hp:
         put(t + EL_ASP_W2PACK, asp_w2_fragment_order(f32_to_bf16_bits(weights["asp.conv.w"][:, :, 0])))
     put(t + EL_ASP_B2, weights["asp.conv.b"])
     s, sh = bn_affine(weights, "asp_bn")
@@ -155,7 +204,7 @@ def pack_weights(weights: Dict[str, np.ndarray], cfg: EcapaConfig = DEFAULT_CONF
     blob = np.zeros(cur, dtype=np.uint8)
     for o, a in chunks:
         blob[o:o + a.size] = a
-    fields = dict(n_mels_padded=N_MELS_PADDED, channels=cfg.channels, sub_channels=cfg.sub_channels,
+    fields = dict(n_mels_padded=mel_pad, precision=precision, channels=cfg.channels, sub_channels=cfg.sub_channels,
                   scale=cfg.res2net_scale, se_channels=cfg.se_channels, attn_channels=cfg.attn_channels,
                   mfa_channels=cfg.mfa_channels, embed_dim=cfg.embed_dim, n_blocks=nb, kernel0=cfg.kernel0,
                   dilation=list(cfg.dilations) + [0] * (4 - nb), off=off)

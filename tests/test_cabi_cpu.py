@@ -26,11 +26,13 @@ def test_library_exports_every_declared_symbol():
     for n in names:
         assert hasattr(lib, n), f"{n} declared in include/sdk_hip.h but not exported by libsdk_hip.so"
     assert sorted(LIB.SIGNATURES) == names, "host binding (_lib.SIGNATURES) out of sync with the header"
-    assert lib.sdk_abi_version() == 1
+    assert lib.sdk_abi_version() == 2
 
 
 def test_struct_layouts_match_header():
-    assert C.sizeof(LIB.EcapaDesc) == 14 * 4 + 256 * 8
+    assert C.sizeof(LIB.EcapaDesc) == 16 * 4 + 256 * 8            # ABI 2: + precision, reserved0
+    assert LIB.EcapaDesc.off.offset == 64 and LIB.EcapaDesc.precision.offset == 56
+    assert C.sizeof(LIB.ConvGemmHpArgs) == 20 * 8 + 7 * 4 + 4     # 20 pointer/int64 slots, 6 ints + flags, tail padding
     assert C.sizeof(LIB.ProfileReport) == 24 * 4 + 3 * 24 * 8
     assert C.sizeof(LIB.ConvGemmArgs) == 16 * 8 + 8 * 4 + 8 + 16  # 16 pointer/int64 slots, 6 ints + flags + stats_mode, stats_part, A2 + lda2
 
@@ -62,6 +64,11 @@ def test_host_only_entry_points_work_without_gpu():
         st, ln, of = ints[0, m], ints[1, m], ints[2, m]
         assert np.array_equal(np.nonzero(Wm[:, m])[0], np.arange(st, st + ln))
         assert np.allclose(melw[of:of + ln], Wm[st:st + ln, m], rtol=0, atol=1e-7)
+    # precise mode: the same matrix split into fp16 hi + lo (22 bits), same fragment order, behind the mel table
+    t16 = buf[tab.nbytes + 3 * 80 * 4 + 512 * 4:][:tab.nbytes].view(np.float16).reshape(7, 2, 13, 2, 64, 8).astype(np.float64)
+    val16 = t16[:, :, :, 0] + t16[:, :, :, 1]
+    assert abs(val16[2, 0, 3, 32 + 7, 5] - want_c) < 3e-7 and abs(val16[2, 1, 3, 32 + 7, 5] - want_s) < 3e-7
+    assert np.abs(val16 - val.astype(np.float64)).max() < 2e-5 and not val16[:, :, 12, 32:, 1:].any()
     assert lib.sdk_fbank_tables_fill(buf.ctypes.data, 10) != 0 and b"too small" in lib.sdk_last_error()
     assert lib.sdk_fbank_workspace_bytes(1000, 32000) == 1000 * 201 * 80 * 4
     assert lib.sdk_affinity_workspace_bytes(100000, 1000) > 100000 * 56
@@ -172,6 +179,45 @@ def test_four_block_layout_has_no_slot_collisions():
     # the header's macro agrees with the packer
     hdr = (ROOT / "speaker-diarization-toolkit_amd" / "csrc" / "ecapa_layout.h").read_text()
     assert "#define EL_CHAINPACK(i, j) (200 + ((i) - 1) * 8 + (j))" in hdr
+
+
+def test_precise_mode_weight_planes():
+    """weights_pack.hp_weight_planes (csrc/hp.hip's weight slot): 256-byte header with 2^-s, fp16 hi / lo planes of 2^s W; the pair
+    reproduces W to 22 bits whatever the layer's scale, and the precise blob keeps every fp32 slot of the default blob bit for bit."""
+    W, WP = sub("weights"), sub("weights_pack")
+    rng = np.random.default_rng(4)
+    for scale in (1e-5, 3e-2, 1.0, 40.0):
+        w = (rng.standard_normal((64, 96)) * scale).astype(np.float32)
+        slot = WP.hp_weight_planes(w)
+        assert slot.dtype == np.uint16 and slot.size == WP.HP_WHDR + 2 * w.size
+        inv = float(slot[:2].view(np.float32)[0])
+        assert inv > 0 and np.log2(inv) == np.round(np.log2(inv))                      # an exact power of two
+        hi = slot[WP.HP_WHDR:WP.HP_WHDR + w.size].view(np.float16).astype(np.float64)
+        assert 4096 <= np.abs(hi).max() <= 8192 + 4                                    # max |2^s W| in [2^12, 2^13]
+        back = WP.hp_planes_to_f64(slot, 64, 96)
+        assert np.abs(back - w).max() <= 2.0 ** -21 * np.abs(w).max()
+    cfg = W.EcapaConfig(channels=256, mfa_channels=768)
+    wts = W.synthetic_weights(5, cfg)
+    b0, f0 = WP.pack_weights(wts, cfg, precision=0)
+    b1, f1 = WP.pack_weights(wts, cfg, precision=1)
+    assert f0["precision"] == 0 and f1["precision"] == 1 and f1["n_mels_padded"] == 96 and f0["n_mels_padded"] == 128
+    gemm_w = {0} | {WP.block_base(i) + s for i in (1, 2, 3) for s in [WP.EL_TDNN1, WP.EL_TDNN2] + [WP.res2net_slot(j) for j in range(7)]}
+    t = WP.tail_base(3)
+    gemm_w |= {t + WP.EL_MFA, t + WP.EL_ASP_WH, t + WP.EL_ASP_W2}
+    for slot in range(256):
+        o0, o1 = f0["off"][slot], f1["off"][slot]
+        if slot in gemm_w:
+            assert o0 >= 0 and o1 >= 0
+        elif slot >= 200 or slot == t + WP.EL_ASP_W2PACK:
+            assert o1 == -1                                                           # no fragment-ordered copies in the precise blob
+        elif o0 >= 0:
+            nxt0 = min([x for x in f0["off"] if x > o0] + [b0.size])
+            nxt1 = min([x for x in f1["off"] if x > o1] + [b1.size])
+            assert nxt0 - o0 == nxt1 - o1 and np.array_equal(b0[o0:nxt0], b1[o1:nxt1]), slot
+    # blk0: taps x 96 padded mel channels, channels 80.. are zero in both planes
+    w0 = WP.hp_planes_to_f64(b1[f1["off"][0]:].view(np.uint16)[:WP.HP_WHDR + 2 * 256 * 5 * 96], 256, 5 * 96).reshape(256, 5, 96)
+    assert not w0[:, :, 80:].any()
+    assert np.abs(w0[:, :, :80] - np.transpose(wts["blk0.conv.w"], (0, 2, 1))).max() < 2.0 ** -21 * np.abs(wts["blk0.conv.w"]).max()
 
 
 def test_bf16_bits_roundtrip():
