@@ -69,7 +69,8 @@ def parity_object(E_gpu: np.ndarray, idx_gpu: np.ndarray, score_gpu: np.ndarray,
     own = np.take_along_axis(S_gpu, idx_gpu[:, None].astype(np.int64), 1)[:, 0]
     return {"segments": int(E_gpu.shape[0]), "profiles": int(P.shape[0]),
             "max_abs_dscore_all_pairs": bound, "max_abs_dscore_top1": float(np.abs(score_gpu - osc[:, 0]).max()),
-            "min_cos_embedding": float((E_gpu.astype(np.float64) * E_ref).sum(1).min()),
+            "min_cos_embedding": float(((E_gpu.astype(np.float64) * E_ref).sum(1) / (np.linalg.norm(E_gpu.astype(np.float64), axis=1)
+                                                                                    * np.linalg.norm(E_ref.astype(np.float64), axis=1))).min()),
             "id_mismatches": int(len(mism)),
             "mismatches": [{"segment": int(n), "gpu_id": int(idx_gpu[n]), "ref_id": int(oidx[n, 0]), "fp32_margin": float(margin[n])} for n in mism],
             "rows_with_margin_above_2x_bound": int((margin > 2 * bound).sum()),

@@ -106,13 +106,19 @@ def test_fbank_precise_mode(precise):
     torch.cuda.synchronize()
     T = 201
     assert feats.dtype == torch.float16 and feats.shape == (6 * T, 192)
-    got = OPS.Engine.from_planes(feats.cpu())                          # [M, 96]
-    assert not got[:, 80:].any()
-    want = torch.from_numpy(ofbank.fbank(pcm)).reshape(6 * T, 80)
-    # features are dB values of magnitude ~10: 2e-5 absolute = 2^-19 relative (fp32 power sums + libm log10 on both sides); the default
-    # mode's bf16 features are 4e-2 away
-    err = float((got[:, :80] - want).abs().max())
-    assert err < 2e-5, err
+    got = OPS.Engine.from_planes(feats.cpu()).double().reshape(6, T, 96)
+    assert not got[:, :, 80:].any()
+    want = torch.from_numpy(ofbank.fbank(pcm)).double()
+    # What fp32 accumulation can promise: a DFT bin is a sum of ~200 terms of the size of the LOUDEST component of the frame, so a quiet
+    # bin next to a loud one (mel 0 at -41 dB beside a 0.2-amplitude sinusoid) carries an absolute error of ~2^-24 of that size:
+    # |d dB| ~ 4.35 * 2 * 2^-24 * sqrt(loudest mel power of the frame / this mel power)  (measured: tools/fbank_hp_debug.py - max 6.6e-4 dB
+    # at exactly such a bin, median 6e-7 dB; the default mode's bf16 x 3 table: 3.7e-3 / 1.3e-5).  Tolerance = twice the measured worst ratio.
+    Mp = torch.from_numpy(ofbank.power_spectrum(pcm) @ ofbank.mel_matrix())
+    tol = 4e-6 + 3.4e-6 * torch.sqrt(Mp.max(dim=2, keepdim=True).values / Mp.clamp_min(1e-10))      # (measured worst: 0.5 of this)
+    err = (got[:, :, :80] - want).abs()
+    # (the per-bin mean over frames is subtracted on both sides: its own error is an average of the above, far inside the tolerance)
+    assert (err <= tol + 2e-6).all(), (float(err.max()), float((err / tol).max()))
+    assert float(err.median()) < 3e-6 and float(err.flatten().kthvalue(int(0.999 * err.numel())).values) < 1e-4
 
 
 def test_ecapa_forward_precise_vs_unrounded_oracle(precise):
@@ -154,4 +160,4 @@ def test_pcm_to_score_within_1e5_in_precise_mode(precise):
     print("\nprecise-mode parity vs the un-rounded oracle:", json.dumps(rep))
     assert rep["max_abs_dscore_all_pairs"] <= PRECISE_SCORE_BOUND and rep["max_abs_dscore_top1"] <= PRECISE_SCORE_BOUND
     assert rep["id_mismatches"] == 0
-    assert rep["min_cos_embedding"] > 1 - 1e-9
+    assert rep["min_cos_embedding"] > 1 - 1e-11
