@@ -30,7 +30,7 @@
  *     sdk_rows_apply  sdk_chol_inverse  sdk_rows_unit  sdk_kmeans_mindist  sdk_kmeans_assign            k6 (driven by cluster.py)
  * BUILDING BLOCKS AND KNOBS - exported for the parity tests and the A/B tools, free to change between rounds, not for binding:
  *     sdk_conv_gemm*  sdk_colstats_finish  sdk_res2net_chain*  sdk_se_*  sdk_asp_*  sdk_rows_fc  (pieces of sdk_ecapa_forward)
- *     sdk_set_option  sdk_set_gemm_variant  sdk_profile_begin / _end  sdk_debug_set_ptr  sdk_affinity_plan
+ *     sdk_set_option  sdk_set_gemm_variant  sdk_profile_begin / _end  sdk_debug_set_ptr  sdk_affinity_plan  sdk_affinity_matvec_plan  sdk_conv_gemm_hp
  * k5 (the embedding all-gather) is NOT here by design: the library holds no communicator; the exchange is one
  * torch.distributed all_gather_into_tensor (backend "nccl" = RCCL over xGMI) in the host layer (dist.py).
  */
@@ -69,8 +69,8 @@ int sdk_get_device_info(sdk_ctx* ctx, sdk_device_info* out);
  * 0 = 8-wave workgroups, one segment per CU), "asp_packed_weights"
  * (likewise for the ASP logit weights, EL_ASP_W2PACK), "asp_per_segment"
  * (1 default / 0 = one workgroup per (segment, 128 channels)), "affinity_fast_path" / "affinity_variant" /
- * "affinity_whole_groups" (k = 1 affinity kernel selection), "gemm_variant" (see sdk_set_gemm_variant).  Results do not
- * depend on them.
+ * "affinity_whole_groups" (k = 1 affinity kernel selection), "matvec_variant" (0 default: persistent row-group kernel / 1 = round 1's
+ * kernel; sums differ in the last bits only), "gemm_variant" (see sdk_set_gemm_variant).  Results do not depend on them.
  * NOT a knob - a numerical contract: "precision" 0 (default: bf16 operands, bf16 layer-boundary storage; PCM -> score within ~4e-3 of
  * the fp32 model) / 1 (fp16 hi+lo planes, three MFMAs per product: within 1e-5, ~3x the GEMM time).  It selects the output format of
  * sdk_fbank (planes) and must match the weight blob's sdk_ecapa_desc.precision. */
@@ -287,6 +287,10 @@ int sdk_affinity_topk(sdk_ctx* ctx, const float* E, const uint16_t* Eb, const fl
  *                         partial sums [nblk, kc, k] and counts [nblk, kc]
  */
 size_t sdk_affinity_matvec_workspace_bytes(int N);
+/* Host-only (no device): the mat-vec kernel's work decomposition, for tests.  out4 = {row groups of 512, j stages per group, workgroups,
+ * partial-tile slots per group}; *units = groups * stages; workgroup i sweeps the units [i * units / workgroups, (i + 1) * units / workgroups)
+ * in (group, stage) order and writes one partial Y tile per group it touches; a group's tiles are summed in slot order. */
+int sdk_affinity_matvec_plan(int rows, int N, int num_cu, int32_t* out4, int64_t* units);
 int sdk_affinity_matvec(sdk_ctx* ctx, const uint16_t* Eb, int N, int d, int row0, int rows, const float* X,
                         const float* xscale, int kv, float* Y, void* ws, size_t ws_bytes, void* stream);
 size_t sdk_rows_gram_workspace_bytes(int n, int k);

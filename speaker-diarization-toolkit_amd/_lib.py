@@ -107,6 +107,7 @@ SIGNATURES = {
     "sdk_affinity_workspace_bytes": (_sz, [_i, _i]),
     "sdk_affinity_plan": (_i, [_i, _i, _i, _vp, _vp]),
     "sdk_affinity_matvec_workspace_bytes": (_sz, [_i]),
+    "sdk_affinity_matvec_plan": (_i, [_i, _i, _i, _vp, _vp]),
     "sdk_affinity_matvec": (_i, [_vp, _vp, _i, _i, _i, _i, _vp, _vp, _i, _vp, _vp, _sz, _vp]),
     "sdk_rows_gram_workspace_bytes": (_sz, [_i, _i]),
     "sdk_rows_gram": (_i, [_vp, _vp, _vp, _i, _i, _vp, _vp, _sz, _vp]),

@@ -132,6 +132,203 @@ __global__ __launch_bounds__(256, 2) void affinity_matvec_kernel(const bf16_t* _
   }
 }
 
+// ---- round 3: the same contraction in the structure of aff_rowcol_kernel (affinity_rowcol.hip) ---------------------------------------
+// PMC of the kernel above at 100k x 100k (profiles/r03_pmc_matvec.json): matrix pipe busy 22 % of a wave's lifetime, 39 % of wave cycles
+// parked on s_waitcnt / the per-tile __syncthreads, 37 % issue-stalled behind a dependent MFMA: a wave owns ONE block of 32 rows of A, so
+// every LDS fragment read feeds one MFMA, a workgroup barrier closes every 16 MFMAs, and 196 row groups of 512 leave 60 of 256 CUs idle
+// in the second round.  Here:
+//   * a wave owns 64 rows i (two blocks): every E_j fragment read from LDS feeds two MFMAs, two independent accumulation chains;
+//   * ONE persistent workgroup per CU (8 waves x 64 = 512 rows i per group) walks a contiguous range of (row group, j stage) units, so
+//     every CU gets the same matrix work whatever N is; a group's sweep over j may be split over <= 3 workgroups, each writing its partial
+//     Y tile to the workspace, summed in slot order by matvec_reduce_kernel (reproducible: no atomics);
+//   * j stages of 2 tiles (64 rows of E as swizzled 384-byte rows + their packed X fragments, 32 KiB) stream through a 4-deep LDS-DMA
+//     ring with counted vmcnt and one raw barrier per stage (32 + 32 MFMAs per wave per barrier); nothing is loaded from global memory
+//     inside the stage loop.
+constexpr int MV_WAVES = 8, MV_TPS = 2, MV_NSTAGE = 4, MV_SEGS = MV_WAVES * 64, MV_MAX_WG = 1024;
+constexpr int MV_PROWB = 384, MV_ETILE = PT * MV_PROWB, MV_XTILE = 4 * 64 * 16;          // 12 KiB + 4 KiB per tile
+constexpr int MV_STAGE = MV_TPS * (MV_ETILE + MV_XTILE);                                  // 32 KiB
+constexpr int MV_LDS = MV_NSTAGE * MV_STAGE;                                              // 128 KiB
+constexpr int MV_DPW = MV_STAGE / 1024 / MV_WAVES;                                        // 4 DMA pieces per wave and stage
+static_assert(MV_DPW * MV_WAVES * 1024 == MV_STAGE && MV_TPS * MV_ETILE / 1024 == 6 * MV_DPW, "waves 0-5 stage E, waves 6-7 stage X");
+
+struct MvGeom { int ngroups, nst, G, maxp; long long U; };
+
+// One workgroup per CU whatever the shape: with few row groups (a rank's 12 500-row block of config #5 at 8 GPUs = 25 groups) a group's
+// sweep is cut into as many parts as it takes - maxp = the most workgroups any one group's sweep can meet.
+MvGeom mv_geometry(int rows, int N, int num_cu) {
+  MvGeom g;
+  g.ngroups = ceil_div(rows, MV_SEGS);
+  g.nst = ceil_div(ceil_div(N, PT), MV_TPS);
+  g.U = (long long)g.ngroups * g.nst;
+  long long G = num_cu > 0 ? num_cu : 256;
+  if (G > MV_MAX_WG) G = MV_MAX_WG;
+  if (G > g.U) G = g.U;
+  g.G = (int)G;
+  // range i starts at floor(i U / G): at most nst G / U + 1 = G / ngroups + 1 ranges start inside a group's nst units, plus the one reaching in
+  g.maxp = (int)(G / g.ngroups) + 2;
+  return g;
+}
+
+__global__ __launch_bounds__(MV_WAVES * 64, 2) void affinity_matvec2_kernel(const bf16_t* __restrict__ Eb, int N, int row0, int rows,
+                                                                           const bf16_t* __restrict__ Xp, MvGeom gm, float* __restrict__ ypart,
+                                                                           int32_t* __restrict__ part_cnt) {
+  extern __shared__ __attribute__((aligned(16))) char sM[];
+  const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
+  const int col = lane & 31, h = lane >> 5;
+  const long long u0 = ((long long)blockIdx.x * gm.U) / gm.G, u1 = ((long long)(blockIdx.x + 1) * gm.U) / gm.G;
+  if (u0 >= u1) return;
+  const int nst = gm.nst;
+  const int ntiles = (N + PT - 1) / PT;
+  const int wu = __builtin_amdgcn_readfirstlane(wid);
+
+  // DMA assignment: a stage is 32 wave-instructions of 1 KiB; wave w issues pieces 4 w .. 4 w + 3: pieces 0..23 = the stage's 64 E rows
+  // (24 sixteen-byte chunks per row, source-side XOR swizzle as in aff_rowcol_kernel), pieces 24..31 = the two tiles' packed X fragments
+  int drow[MV_DPW], dsrc[MV_DPW];
+#pragma unroll
+  for (int i = 0; i < MV_DPW; ++i) {
+    const int id = (wu * MV_DPW + i) * 64 + lane;
+    const int row = id / 24, pos = id - row * 24;
+    drow[i] = row;
+    dsrc[i] = ((pos & ~7) | ((pos & 7) ^ ((row >> 1) & 7))) * 8;
+  }
+  int s_issue = (int)(u0 % nst), k_issue = 0;
+  auto issue = [&]() {
+    char* st = sM + (k_issue % MV_NSTAGE) * MV_STAGE;
+    if (wu < 6) {
+#pragma unroll
+      for (int i = 0; i < MV_DPW; ++i) {
+        int pr = s_issue * (MV_TPS * PT) + drow[i];
+        pr = pr < N ? pr : N - 1;                    // rows past the end: some valid row, their X rows are zero
+        __builtin_amdgcn_global_load_lds((const void __attribute__((address_space(1)))*)(Eb + (int64_t)pr * D + dsrc[i]),
+                                         (void __attribute__((address_space(3)))*)(st + (wu * MV_DPW + i) * 1024), 16, 0, 0);
+      }
+    } else {
+#pragma unroll
+      for (int i = 0; i < MV_DPW; ++i) {
+        const int q = (wu - 6) * MV_DPW + i;         // 0..7: tile q >> 2 of the stage, fragment q & 3
+        int tile = s_issue * MV_TPS + (q >> 2);
+        tile = tile < ntiles ? tile : ntiles - 1;
+        __builtin_amdgcn_global_load_lds((const void __attribute__((address_space(1)))*)(Xp + ((int64_t)tile * 4 + (q & 3)) * 512 + lane * 8),
+                                         (void __attribute__((address_space(3)))*)(st + MV_TPS * MV_ETILE + q * 1024), 16, 0, 0);
+      }
+    }
+    ++k_issue;
+    if (++s_issue == nst) s_issue = 0;
+  };
+
+  int b = (int)(u0 / nst), s = (int)(u0 % nst);
+  int slot;
+  {
+    const long long x = (long long)b * nst;
+    const long long ifirst = ((x + 1) * gm.G + gm.U - 1) / gm.U - 1;      // first workgroup whose range reaches into group b
+    slot = (int)(blockIdx.x - ifirst);
+  }
+  bf16x8 bfrag[2][KS];
+  f32x16 yacc[2];
+  auto begin_portion = [&]() {
+#pragma unroll
+    for (int sb = 0; sb < 2; ++sb) {
+      const int iloc = b * MV_SEGS + (wid * 2 + sb) * 32 + col;
+      const int irow = row0 + (iloc < rows ? iloc : rows - 1);
+#pragma unroll
+      for (int ks = 0; ks < KS; ++ks) bfrag[sb][ks] = *reinterpret_cast<const bf16x8*>(Eb + (int64_t)irow * D + ks * 16 + h * 8);
+#pragma unroll
+      for (int r = 0; r < 16; ++r) yacc[sb][r] = 0.f;
+    }
+  };
+  auto end_portion = [&](bool group_done) {
+    if (slot < gm.maxp) {                            // (always: mv_geometry sizes maxp for the shortest range)
+#pragma unroll
+      for (int sb = 0; sb < 2; ++sb) {
+        float* dst = ypart + (((int64_t)b * gm.maxp + slot) * MV_SEGS + (wid * 2 + sb) * 32 + col) * KV + 4 * h;
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {               // accumulator register r = 4 q + e holds column c = 8 q + 4 h + e of Y
+          f32x4 v;
+#pragma unroll
+          for (int e = 0; e < 4; ++e) v[e] = yacc[sb][4 * q + e];
+          *reinterpret_cast<f32x4*>(dst + 8 * q) = v;
+        }
+      }
+    }
+    if (group_done && tid == 0) part_cnt[b] = slot + 1 < gm.maxp ? slot + 1 : gm.maxp;
+  };
+
+  constexpr int AHEAD = MV_NSTAGE - 1;
+#pragma unroll
+  for (int a = 0; a < AHEAD; ++a)
+    if (u0 + a < u1) issue();
+  const int rsw = (col >> 1) & 7;
+  int aoff[4];
+#pragma unroll
+  for (int q = 0; q < 4; ++q) aoff[q] = col * MV_PROWB + (((2 * q + h) ^ rsw) << 4);
+  int k = 0;
+  long long u = u0;
+  while (u < u1) {
+    const long long gend = (long long)(b + 1) * nst;
+    const long long uend = gend < u1 ? gend : u1;
+    begin_portion();                                 // plain loads OUTSIDE the stage loop: drained once here, the loop keeps its counted waits
+    for (; u < uend; ++u, ++k) {
+      const long long after = u1 - 1 - u < AHEAD - 1 ? u1 - 1 - u : AHEAD - 1;
+      if (after >= 2) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+      else if (after == 1) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+      else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      __builtin_amdgcn_s_barrier();                  // stage k landed for everyone; the buffer of stage k - 1 is free
+      if (u + AHEAD < u1) issue();
+      const char* stg = sM + (k % MV_NSTAGE) * MV_STAGE;
+#pragma unroll
+      for (int tt = 0; tt < MV_TPS; ++tt) {
+        if (s * MV_TPS + tt < ntiles) {              // wave-uniform
+          f32x16 sacc[2];
+#pragma unroll
+          for (int sb = 0; sb < 2; ++sb)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) sacc[sb][r] = 0.f;
+#pragma unroll
+          for (int ks = 0; ks < KS; ++ks) {
+            const bf16x8 a = *reinterpret_cast<const bf16x8*>(stg + tt * MV_ETILE + aoff[ks & 3] + (ks >> 2) * 128);
+            sacc[0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, bfrag[0][ks], sacc[0], 0, 0, 0);
+            sacc[1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, bfrag[1][ks], sacc[1], 0, 0, 0);
+          }
+          bf16x8 xf[4];
+#pragma unroll
+          for (int q = 0; q < 4; ++q) xf[q] = *reinterpret_cast<const bf16x8*>(stg + MV_TPS * MV_ETILE + (tt * 4 + q) * 1024 + lane * 16);
+#pragma unroll
+          for (int sb = 0; sb < 2; ++sb) {
+            bf16x8 sf[2];
+#pragma unroll
+            for (int hs = 0; hs < 2; ++hs)
+#pragma unroll
+              for (int jj = 0; jj < 8; ++jj) sf[hs][jj] = f32_to_bf16(fmaxf(sacc[sb][8 * hs + jj], 0.f));
+#pragma unroll
+            for (int hs = 0; hs < 2; ++hs) {
+              yacc[sb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(xf[2 * hs], sf[hs], yacc[sb], 0, 0, 0);
+              yacc[sb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(xf[2 * hs + 1], sf[hs], yacc[sb], 0, 0, 0);
+            }
+          }
+        }
+      }
+      ++s;
+    }
+    end_portion(s == nst);
+    if (s == nst) { ++b; s = 0; slot = 0; }
+  }
+}
+
+// Y[row0 + i, c] = sum over the parts of row group i / 512, in slot order
+__global__ __launch_bounds__(256) void matvec_reduce_kernel(const float* __restrict__ ypart, const int32_t* __restrict__ part_cnt, int maxp, int row0,
+                                                           int rows, int kv, float* __restrict__ Y) {
+  const int64_t gid = (int64_t)blockIdx.x * 256 + threadIdx.x;       // one thread per (row, 4 columns)
+  const int i = (int)(gid >> 3), c4 = (int)(gid & 7) * 4;
+  if (i >= rows || c4 >= kv) return;
+  const int g = i / MV_SEGS, il = i - g * MV_SEGS;
+  const int np = part_cnt[g];
+  f32x4 a = {0.f, 0.f, 0.f, 0.f};
+  for (int p = 0; p < np; ++p) a += *reinterpret_cast<const f32x4*>(ypart + (((int64_t)g * maxp + p) * MV_SEGS + il) * KV + c4);
+#pragma unroll
+  for (int e = 0; e < 4; ++e)
+    if (c4 + e < kv) Y[(int64_t)(row0 + i) * kv + c4 + e] = a[e];
+}
+
 // ---- thin [n, k] helpers -------------------------------------------------------------------------
 // G_part[block] = X_blk^T Y_blk (k x k), fixed-order in-block reduction; gram_reduce sums the blocks in order.
 constexpr int GR_ROWS = 256;
@@ -288,9 +485,22 @@ __global__ __launch_bounds__(64) void chol_inverse_kernel(const float* __restric
 
 }  // namespace
 
+static size_t mv_xp_bytes(int N) { return (((size_t)((N + PT - 1) / PT) * 4 * 64 * 8 * sizeof(uint16_t)) + 255) & ~(size_t)255; }
+// partial Y tiles: groups x maxp tiles of 64 KiB; maxp <= G / ngroups + 3, so groups x maxp <= G + 3 groups for any row block of <= N rows
+static size_t mv_ypart_bytes(int N) { return ((size_t)MV_MAX_WG + 3 * (size_t)ceil_div(N, MV_SEGS)) * MV_SEGS * KV * sizeof(float); }
+
 extern "C" size_t sdk_affinity_matvec_workspace_bytes(int N) {
   if (N <= 0) return 0;
-  return (size_t)((N + PT - 1) / PT) * 4 * 64 * 8 * sizeof(uint16_t);
+  // packed X fragments | partial Y tiles of the parts of every row group | part counts
+  return mv_xp_bytes(N) + mv_ypart_bytes(N) + (size_t)ceil_div(N, MV_SEGS) * sizeof(int32_t) + 256;
+}
+
+extern "C" int sdk_affinity_matvec_plan(int rows, int N, int num_cu, int32_t* out4, int64_t* units) {
+  SDK_REQUIRE(out4 && units && rows > 0 && N >= rows, "sdk_affinity_matvec_plan: bad arguments");
+  const MvGeom g = mv_geometry(rows, N, num_cu);
+  out4[0] = g.ngroups; out4[1] = g.nst; out4[2] = g.G; out4[3] = g.maxp;
+  *units = g.U;
+  return 0;
 }
 
 extern "C" int sdk_affinity_matvec(sdk_ctx* ctx, const uint16_t* Eb, int N, int d, int row0, int rows, const float* X,
@@ -305,11 +515,26 @@ extern "C" int sdk_affinity_matvec(sdk_ctx* ctx, const uint16_t* Eb, int N, int 
   const int ntiles = ceil_div(N, PT);
   hipLaunchKernelGGL(pack_x_kernel, dim3(ceil_div(ntiles * 2 * 64, 256)), dim3(256), 0, s, X, N, kv, (bf16_t*)ws, xscale);
   SDK_LAUNCH_CHECK();
-  {
+  if (ctx->matvec_variant == 1) {                    // A/B + test knob ("matvec_variant" 1): round 1's kernel, one 32-row block per wave
     ProfScope ps(ctx, stream, SDK_K_AFF_MATVEC, 2.0 * rows * (double)N * (D + KV), 2.0 * (double)N * D + 4.0 * N * kv);
     hipLaunchKernelGGL(affinity_matvec_kernel, dim3(ceil_div(rows, 128)), dim3(256), 0, s, (const bf16_t*)Eb, N, row0, rows,
                        (const bf16_t*)ws, kv, Y);
+    SDK_LAUNCH_CHECK();
+    return 0;
   }
+  float* ypart = reinterpret_cast<float*>((char*)ws + mv_xp_bytes(N));
+  int32_t* pcnt = reinterpret_cast<int32_t*>((char*)ws + mv_xp_bytes(N) + mv_ypart_bytes(N));
+  const MvGeom gm = mv_geometry(rows, N, ctx->num_cu);
+  SDK_REQUIRE((size_t)gm.ngroups * gm.maxp * MV_SEGS * KV * sizeof(float) <= mv_ypart_bytes(N), "sdk_affinity_matvec: internal: %d groups x %d parts exceed the workspace", gm.ngroups, gm.maxp);
+  if (sdk_lds_optin(ctx, (const void*)affinity_matvec2_kernel, MV_LDS)) return 1;
+  {
+    ProfScope ps(ctx, stream, SDK_K_AFF_MATVEC, 2.0 * rows * (double)N * (D + KV), 2.0 * (double)N * D + 4.0 * N * kv);
+    hipLaunchKernelGGL(affinity_matvec2_kernel, dim3(gm.G), dim3(MV_WAVES * 64), MV_LDS, s, (const bf16_t*)Eb, N, row0, rows, (const bf16_t*)ws, gm,
+                       ypart, pcnt);
+  }
+  SDK_LAUNCH_CHECK();
+  hipLaunchKernelGGL(matvec_reduce_kernel, dim3((unsigned)(((int64_t)rows * 8 + 255) / 256)), dim3(256), 0, s, (const float*)ypart, (const int32_t*)pcnt,
+                     gm.maxp, row0, rows, kv, Y);
   SDK_LAUNCH_CHECK();
   return 0;
 }

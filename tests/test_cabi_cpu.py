@@ -220,6 +220,40 @@ def test_precise_mode_weight_planes():
     assert np.abs(w0[:, :, :80] - np.transpose(wts["blk0.conv.w"], (0, 2, 1))).max() < 2.0 ** -21 * np.abs(wts["blk0.conv.w"]).max()
 
 
+def test_matvec_plan_every_group_fits_its_partial_tile_slots():
+    """Host side of the config #5 tile kernel's decomposition (csrc/spectral.hip affinity_matvec2_kernel): workgroup i owns the units
+    [i*U/G, (i+1)*U/G) of the (row group, j stage) grid and writes one partial Y tile per group it touches, into slot = number of
+    earlier workgroups that touch the same group.  Replays that arithmetic: every group's sweep is tiled exactly once, by consecutive
+    slots 0..n-1 with n <= the slot count the workspace is sized for - also for a rank's thin row block (12 500 rows of 100 000)."""
+    lib = LIB.load_library()
+    rng = np.random.default_rng(12)
+    shapes = [(100_000, 100_000, 256), (12_500, 100_000, 256), (33, 33, 256), (5000, 5000, 304), (2600, 5000, 64), (1, 1, 256), (512, 100_000, 256)]
+    shapes += [(int(r), int(r + rng.integers(0, 50_000)), int(rng.choice([256, 304, 8, 64]))) for r in rng.integers(1, 120_000, 40)]
+    for rows, N, cus in shapes:
+        out = (C.c_int32 * 4)()
+        units = C.c_int64()
+        assert lib.sdk_affinity_matvec_plan(rows, N, cus, out, C.byref(units)) == 0
+        ng, nst, G, maxp = list(out)
+        U = units.value
+        assert ng == -(-rows // 512) and nst == -(-(-(-N // 32)) // 2) and U == ng * nst and 1 <= G <= min(cus, U)
+        covered = np.zeros(U, np.int32)
+        slots = [[] for _ in range(ng)]
+        for i in range(G):
+            u0, u1 = i * U // G, (i + 1) * U // G
+            covered[u0:u1] += 1
+            if u0 < u1:
+                for b in range(u0 // nst, (u1 - 1) // nst + 1):
+                    slots[b].append(i)
+        assert (covered == 1).all()
+        assert max(len(x) for x in slots) <= maxp, (rows, N, cus)
+        assert ng * maxp * 512 * 32 * 4 + (-(-N // 32)) * 4096 <= lib.sdk_affinity_matvec_workspace_bytes(N)
+        # the kernel's closed form for "first workgroup whose range reaches into group b"
+        for b in range(0, ng, max(1, ng // 7)):
+            x = b * nst
+            ifirst = ((x + 1) * G + U - 1) // U - 1
+            assert slots[b][0] == ifirst, (rows, N, cus, b)
+
+
 def test_bf16_bits_roundtrip():
     WP = sub("weights_pack")
     import torch

@@ -423,8 +423,32 @@ from oracle import spectral as ospec  # noqa: E402
 CL = sub("cluster")
 
 
-@pytest.mark.parametrize("N,kv,row0,rows", [(1000, 16, 0, 1000), (777, 5, 100, 300), (4096, 32, 0, 4096), (130, 1, 0, 130)])
-def test_affinity_matvec(engine, N, kv, row0, rows):
+@pytest.mark.parametrize("variant", [0, 1])
+@pytest.mark.parametrize("N,kv,row0,rows", [(1000, 16, 0, 1000), (777, 5, 100, 300), (4096, 32, 0, 4096), (130, 1, 0, 130), (5000, 16, 1200, 2600), (33, 3, 0, 33)])
+def test_affinity_matvec(engine, N, kv, row0, rows, variant):
+    """variant 0 = the persistent row-group kernel (round 3: 64 rows per wave, LDS-DMA ring, parts summed in slot order),
+    variant 1 = round 1's kernel; both against the float64 product of the bf16 rows."""
+    engine.set_option("matvec_variant", variant)
+    try:
+        _check_matvec(engine, N, kv, row0, rows)
+    finally:
+        engine.set_option("matvec_variant", 0)
+
+
+def test_affinity_matvec_is_reproducible_and_splits_groups(engine):
+    """A row group's sweep over j is split over up to three workgroups whose partial tiles are summed in slot order: two runs give the
+    same bits, and a shape whose groups are all split (rows = 4 groups on 256 CUs -> 8 workgroups) still matches the reference."""
+    N, kv = 6000, 16
+    _, Eb, _ = engine.l2norm(dev(_unit(N, 192, 77)))
+    X = dev(np.random.default_rng(3).standard_normal((N, kv)).astype(np.float32))
+    Y1 = engine.affinity_matvec(Eb, X, 0, 2048).clone()
+    Y2 = engine.affinity_matvec(Eb, X, 0, 2048).clone()
+    torch.cuda.synchronize()
+    assert torch.equal(Y1, Y2)
+    _check_matvec(engine, N, kv, 0, 2048)
+
+
+def _check_matvec(engine, N, kv, row0, rows):
     E = _unit(N, 192, N)
     _, Eb, _ = engine.l2norm(dev(E))
     Ef = Eb.float().cpu().numpy().astype(np.float64)            # the kernel sees the bf16 rows
