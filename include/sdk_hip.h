@@ -145,6 +145,10 @@ typedef struct sdk_conv_gemm_args {
   /* optional addend of the A operand, same rows/row map/channels: the GEMM consumes bf16(A + A2)
    * (Res2Net: y_{c-1} + u_c formed on the way into LDS instead of round-tripping through HBM) */
   const uint16_t* A2; int64_t lda2;
+  /* > 0: the taps are PACKED along K: W is [N, round_up(taps * tap_pack, 64)] (tap-major, tap_pack channels per tap, zero K padding),
+   * Cin == tap_pack (a multiple of 8, not of 64): the first layer's 5 x 80 mel channels take 7 K-steps of 64 instead of 5 x 128 -> 10 */
+  int32_t tap_pack;
+  int32_t reserved;
 } sdk_conv_gemm_args;
 int sdk_conv_gemm(sdk_ctx* ctx, const sdk_conv_gemm_args* a, void* stream);
 size_t sdk_conv_gemm_stats_bytes(int M, int N, int mode);
@@ -225,7 +229,8 @@ typedef struct sdk_ecapa_desc {
   int32_t dilation[4];
   int32_t precision;       /* 0: bf16 operand blob (default mode); 1: fp16 hi+lo plane blob (precise mode: feats are planes [B*T, ldf] with
                               the lo plane ldf/2 columns to the right, n_mels_padded = 96); must equal the context's "precision" option */
-  int32_t reserved0;
+  int32_t blk0_tap_pack;   /* default mode: > 0 = the first layer's weight slot is packed along K (sdk_conv_gemm_args.tap_pack), value = mel channels per
+                              tap (80); 0 = [C][kernel0 * n_mels_padded] */
   /* byte offsets into wblob; -1 = absent.  Layout of the index space: see weights_pack.py */
   int64_t off[256];
 } sdk_ecapa_desc;

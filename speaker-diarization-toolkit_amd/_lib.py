@@ -35,14 +35,14 @@ class ConvGemmArgs(C.Structure):
                 ("X2", C.c_void_p), ("ldx2", C.c_int64), ("S", C.c_void_p), ("lds", C.c_int64),
                 ("M", C.c_int), ("N", C.c_int), ("Cin", C.c_int), ("taps", C.c_int), ("dil", C.c_int),
                 ("T", C.c_int), ("flags", C.c_uint32), ("stats_mode", C.c_int32), ("stats_part", C.c_void_p),
-                ("A2", C.c_void_p), ("lda2", C.c_int64)]
+                ("A2", C.c_void_p), ("lda2", C.c_int64), ("tap_pack", C.c_int32), ("reserved", C.c_int32)]
 
 
 class EcapaDesc(C.Structure):
     _fields_ = [("n_mels_padded", C.c_int32), ("channels", C.c_int32), ("sub_channels", C.c_int32),
                 ("scale", C.c_int32), ("se_channels", C.c_int32), ("attn_channels", C.c_int32),
                 ("mfa_channels", C.c_int32), ("embed_dim", C.c_int32), ("n_blocks", C.c_int32),
-                ("kernel0", C.c_int32), ("dilation", C.c_int32 * 4), ("precision", C.c_int32), ("reserved0", C.c_int32),
+                ("kernel0", C.c_int32), ("dilation", C.c_int32 * 4), ("precision", C.c_int32), ("blk0_tap_pack", C.c_int32),
                 ("off", C.c_int64 * 256)]
 
 

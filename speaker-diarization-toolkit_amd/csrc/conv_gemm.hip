@@ -43,6 +43,8 @@ struct Params {
   int tune;
   float* stats_part; int stats_mode;   // fused per-segment column statistics (256^2 kernel only)
   const bf16_t* A2; int64_t lda2;      // optional addend of the A operand (128^2 kernel only): A := bf16(A + A2)
+  int tap_pack;                        // > 0: the taps are packed along K (W is [N][round64(taps * tap_pack)], a 16-byte chunk of 8 channels
+                                       // belongs to tap chunk / (tap_pack / 8)): blk0's 5 x 80 mel channels in 7 K-steps instead of 5 x 128 in 10
   unsigned long long* clk;             // diagnostics (256^2 kernel): per workgroup {shader cycles, 100 MHz ticks} of its lifetime, or null
   unsigned long long* stamps;          // diagnostics (256^2 kernel): [4096] wall-clock stamps of workgroup 0's phases (own buffer: "gemm_stamps"), or null
 };
@@ -80,7 +82,9 @@ __global__ __launch_bounds__(NT, 2) void conv_gemm_kernel(Params p) {
       tloc[i] = 0;
     }
   }
-  const int Ktot = p.taps * p.Cin;
+  const int cpt = p.tap_pack >> 3;                                       // packed taps: 16-byte chunks per tap
+  const int cin_w = p.tap_pack ? BK : p.Cin;                             // (packed: one "tap" of the weight walk per K-step)
+  const int Ktot = p.tap_pack ? ((p.taps * p.tap_pack + BK - 1) / BK) * BK : p.taps * p.Cin;
   const bf16_t* wrow[4];
 #pragma unroll
   for (int i = 0; i < 4; ++i) wrow[i] = p.W + (int64_t)(n0 + r0 + 32 * i) * Ktot + ch * 8;
@@ -92,21 +96,28 @@ __global__ __launch_bounds__(NT, 2) void conv_gemm_kernel(Params p) {
     lds_w[i] = row * 128 + ((ch ^ (row & 7)) << 4);
   }
 
-  const int ksteps_per_tap = p.Cin / BK;
-  const int nk = p.taps * ksteps_per_tap;
+  const int ksteps_per_tap = cin_w / BK;
+  const int nk = p.tap_pack ? Ktot / BK : p.taps * ksteps_per_tap;
   const int half = p.taps >> 1;
 
   u32x4 ra[4], rb[4], ra2[4];
   auto gload = [&](int s) {
     const int j = s / ksteps_per_tap;
     const int kc = (s - j * ksteps_per_tap) * BK;
-    const int off = (j - half) * p.dil;
+    int off = (j - half) * p.dil, acol = kc + ch * 8;
+    if (p.tap_pack) {                                                    // this thread's chunk of the packed K: its own tap
+      const int g = s * 8 + ch;
+      int tap = g / cpt;
+      acol = (g - tap * cpt) * 8;
+      if (tap >= p.taps) { tap = half; acol = 0; }                       // K padding: any valid (finite) activation, its weights are zero
+      off = (tap - half) * p.dil;
+    }
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
       const int src = p.taps > 1 ? segbase[i] + reflect_idx(tloc[i] + off, p.T) : segbase[i];
-      ra[i] = *reinterpret_cast<const u32x4*>(p.A + (int64_t)src * p.lda + kc + ch * 8);
-      rb[i] = *reinterpret_cast<const u32x4*>(wrow[i] + j * p.Cin + kc);
-      if (p.A2) ra2[i] = *reinterpret_cast<const u32x4*>(p.A2 + (int64_t)src * p.lda2 + kc + ch * 8);
+      ra[i] = *reinterpret_cast<const u32x4*>(p.A + (int64_t)src * p.lda + acol);
+      rb[i] = *reinterpret_cast<const u32x4*>(wrow[i] + j * cin_w + kc);
+      if (p.A2) ra2[i] = *reinterpret_cast<const u32x4*>(p.A2 + (int64_t)src * p.lda2 + acol);
     }
   };
 
@@ -254,9 +265,11 @@ __global__ __launch_bounds__(NT2, 2) void conv_gemm256_kernel(Params p) {
   const int nbn = p.N / BN2;
   const int nbm = (p.M + BM2 - 1) / BM2;
   const int ntiles = nbn * nbm;
-  const int Ktot = p.taps * p.Cin;
-  const int ksteps_per_tap = p.Cin / BK;
-  const int nk = p.taps * ksteps_per_tap;
+  const int cpt = p.tap_pack >> 3;                                       // packed taps (blk0): 16-byte chunks per tap
+  const int cin_w = p.tap_pack ? BK : p.Cin;
+  const int Ktot = p.tap_pack ? ((p.taps * p.tap_pack + BK - 1) / BK) * BK : p.taps * p.Cin;
+  const int ksteps_per_tap = cin_w / BK;
+  const int nk = p.tap_pack ? Ktot / BK : p.taps * ksteps_per_tap;
   const int half = p.taps >> 1;
 
   // Tile schedule.  A workgroup's XCD is blockIdx & 7 (the grid is a multiple of 8), its slot on the XCD l = blockIdx >> 3.
@@ -360,13 +373,23 @@ __global__ __launch_bounds__(NT2, 2) void conv_gemm256_kernel(Params p) {
     char* sB = sA + BM2 * BK * 2;
     const char* abase = reinterpret_cast<const char*>(p.A + kc);
     if constexpr (TAPS) {
-      const int off = (j - half) * p.dil;
+      int off = (j - half) * p.dil;
+      uint32_t acol = (uint32_t)gch;
+      if (p.tap_pack) {
+        // taps packed along K: this lane's 16-byte chunk of the K-step is chunk g of the packed row [tap 0 | tap 1 | ...], i.e. its OWN
+        // tap's row shift - the gather is per lane anyway (abase carries no K offset here: kc = 0)
+        const int g = t * 8 + (gch >> 3);
+        int tap = g / cpt;
+        acol = (uint32_t)(g - tap * cpt) * 8u;
+        if (tap >= p.taps) { tap = half; acol = 0; }    // K padding: any valid (finite) activation, its weights are zero
+        off = (tap - half) * p.dil;
+      }
 #pragma unroll
       for (int i = 0; i < 4; ++i) {
         int tl = atl0 + 8 * i, sb = aseg0;
         if (tl >= p.T) { tl -= p.T; sb += p.T; }      // T >= 64 > 24: at most one segment boundary inside the 4 rows
         const uint32_t src = (uint32_t)min(sb + reflect_idx(tl + off, p.T), p.M - 1);
-        __builtin_amdgcn_global_load_lds((gptr_t)(abase + (size_t)((src * (uint32_t)p.lda + (uint32_t)gch) * 2u)), (lptr_t)(sA + i * 1024), 16, 0, 0);
+        __builtin_amdgcn_global_load_lds((gptr_t)(abase + (size_t)((src * (uint32_t)p.lda + acol) * 2u)), (lptr_t)(sA + i * 1024), 16, 0, 0);
       }
     } else if (a_nt) {
       // A is read exactly ONCE per XCD when the layer has a single n-chunk (N = 1024): fetched non-temporal, its 4 MB per round no
@@ -381,7 +404,7 @@ __global__ __launch_bounds__(NT2, 2) void conv_gemm256_kernel(Params p) {
       for (int i = 0; i < 4; ++i)
         __builtin_amdgcn_global_load_lds((gptr_t)(abase + (size_t)aoff[i]), (lptr_t)(sA + i * 1024), 16, 0, 0);
     }
-    const char* wbase = reinterpret_cast<const char*>(p.W + (j * p.Cin + kc));
+    const char* wbase = reinterpret_cast<const char*>(p.W + (j * cin_w + kc));
 #pragma unroll
     for (int i = 0; i < 4; ++i)
       __builtin_amdgcn_global_load_lds((gptr_t)(wbase + (size_t)i * 16 * Ktot + (size_t)woff), (lptr_t)(sB + i * 1024), 16, 0, 0);
@@ -973,6 +996,10 @@ extern "C" int sdk_conv_gemm(sdk_ctx* ctx, const sdk_conv_gemm_args* a, void* st
   SDK_REQUIRE(ctx && a, "sdk_conv_gemm: null ctx/args");
   SDK_REQUIRE(a->A && a->W, "sdk_conv_gemm: A and W are required");
   SDK_REQUIRE(a->M > 0 && a->N > 0 && a->N % BN == 0, "sdk_conv_gemm: N=%d must be a positive multiple of %d", a->N, BN);
+  const int pack = a->tap_pack;
+  if (pack) {
+    SDK_REQUIRE(pack > 0 && pack % 8 == 0 && a->taps > 1 && !a->A2 && a->Cin == pack, "sdk_conv_gemm: tap_pack=%d needs taps > 1, a multiple of 8 channels per tap, Cin == tap_pack and no A2", pack);
+  } else
   SDK_REQUIRE(a->Cin > 0 && a->Cin % BK == 0, "sdk_conv_gemm: Cin=%d must be a multiple of %d", a->Cin, BK);
   SDK_REQUIRE(a->taps >= 1 && (a->taps & 1), "sdk_conv_gemm: taps=%d must be odd", a->taps);
   SDK_REQUIRE(a->T > 0 && a->M % a->T == 0, "sdk_conv_gemm: M=%d must be a multiple of T=%d", a->M, a->T);
@@ -1005,11 +1032,12 @@ extern "C" int sdk_conv_gemm(sdk_ctx* ctx, const sdk_conv_gemm_args* a, void* st
   p.tune = g_gemm_variant / 16;
   p.stats_part = nullptr; p.stats_mode = 0;
   p.A2 = (const bf16_t*)a->A2; p.lda2 = a->lda2;
+  p.tap_pack = pack;
   p.clk = (unsigned long long*)ctx->gemm_clk_ptr;
   p.stamps = (unsigned long long*)ctx->gemm_stamps_ptr;
   if (a->A2) SDK_REQUIRE(a->lda2 % 8 == 0 && a->lda2 >= a->Cin && ((uintptr_t)a->A2 % 16) == 0, "sdk_conv_gemm: bad A2/lda2");
 
-  const double kk = (double)a->taps * a->Cin;
+  const double kk = pack ? (double)(((a->taps * pack + BK - 1) / BK) * BK) : (double)a->taps * a->Cin;      // K as launched
   // the 256^2 kernel covers the plain layer shape (bias / ReLU / BN affine -> bf16, optional column statistics);
   // fp32 output, residual sum, per-segment bias, tanh and the A2 addend stay with the 128^2 kernel
   const bool use256 = (g_gemm_variant & 15) != 1 && a->N % BN2 == 0 && a->M >= BM2 && !a->A2 && a->C && !a->C32 && !a->S &&
@@ -1031,7 +1059,7 @@ extern "C" int sdk_conv_gemm(sdk_ctx* ctx, const sdk_conv_gemm_args* a, void* st
     // tune bit 4 (gemm_variant 258) selects v3, the overlapped tile boundary: bit-identical output, 6-7 % fewer cycles per
     // K = 1024 tile in the in-kernel timeline, and the same wall time in interleaved A/B (0.97-1.01x) - the chip returns the
     // saved cycles as a lower clock (DVFS give-back), so the simpler v2 stays the default
-    if ((p.tune & 16) && par_ok)
+    if ((p.tune & 16) && par_ok && !pack)
     {
       const bool st = p.stats_part != nullptr, tp = p.taps > 1;
       auto kern = st ? (tp ? conv_gemm256_v3_kernel<true, true> : conv_gemm256_v3_kernel<true, false>)

@@ -265,7 +265,7 @@ class Engine:
 
     # ------------------------------------------------------------------ building blocks (tests / tuning)
     def conv_gemm(self, A, W, N, Cin, taps=1, dil=1, T=None, bias=None, scale=None, shift=None, ubias=None,
-                  relu=False, tanh=False, out_bf16=True, out_f32=False, X2=None, stats_mode=0, A2=None):
+                  relu=False, tanh=False, out_bf16=True, out_f32=False, X2=None, stats_mode=0, A2=None, tap_pack=0):
         """stats_mode 1/2 additionally returns the fused per-segment column statistics as a 4th value
         ([B, N] means, or [B, 2N] mean | std)."""
         _need(A, torch.bfloat16, "A"); _need(W, torch.bfloat16, "W")
@@ -285,6 +285,7 @@ class Engine:
         g.S, g.lds = _ptr(S), N
         g.M, g.N, g.Cin, g.taps, g.dil, g.T = M, N, Cin, taps, dil, T
         g.flags = (_lib.GEMM_RELU if relu else 0) | (_lib.GEMM_TANH if tanh else 0)
+        g.tap_pack = tap_pack
         part = None
         if stats_mode:
             part = torch.empty(self.lib.sdk_conv_gemm_stats_bytes(M, N, stats_mode), dtype=torch.uint8, device=self.device)

@@ -168,7 +168,22 @@ def pack_weights(weights: Dict[str, np.ndarray], cfg: EcapaConfig = DEFAULT_CONF
         put(slot + EL_SHIFT, sh)
 
     nb = len(cfg.dilations)
-    tdnn(EL_BLK0, "blk0", mel_pad)
+    blk0_pack = 0
+    if not hp and cfg.n_mels % 8 == 0 and cfg.kernel0 > 1:
+        # default mode: the first layer's taps packed along K - [C][round_up(kernel0 * n_mels, 64)] (5 x 80 = 400 -> 448: 7 K-steps of 64
+        # where the per-tap padding 80 -> 128 took 10); the activations stay [M, 128] with zero columns 80.., read 80 wide per tap
+        blk0_pack = cfg.n_mels
+        wk = conv_weight_kmajor(weights["blk0.conv.w"])                       # [C, kernel0 * n_mels] bf16 bits
+        kp = (wk.shape[1] + 63) // 64 * 64
+        wp = np.zeros((wk.shape[0], kp), dtype=np.uint16)
+        wp[:, :wk.shape[1]] = wk
+        put(EL_BLK0 + EL_W, wp)
+        put(EL_BLK0 + EL_B, weights["blk0.conv.b"].astype(np.float32))
+        s0, sh0 = bn_affine(weights, "blk0.bn")
+        put(EL_BLK0 + EL_SCALE, s0)
+        put(EL_BLK0 + EL_SHIFT, sh0)
+    else:
+        tdnn(EL_BLK0, "blk0", mel_pad)
     for i in range(1, nb + 1):
         b = block_base(i)
         tdnn(b + EL_TDNN1, f"blk{i}.tdnn1")
@@ -204,7 +219,7 @@ def pack_weights(weights: Dict[str, np.ndarray], cfg: EcapaConfig = DEFAULT_CONF
     blob = np.zeros(cur, dtype=np.uint8)
     for o, a in chunks:
         blob[o:o + a.size] = a
-    fields = dict(n_mels_padded=mel_pad, precision=precision, channels=cfg.channels, sub_channels=cfg.sub_channels,
+    fields = dict(n_mels_padded=mel_pad, precision=precision, blk0_tap_pack=blk0_pack, channels=cfg.channels, sub_channels=cfg.sub_channels,
                   scale=cfg.res2net_scale, se_channels=cfg.se_channels, attn_channels=cfg.attn_channels,
                   mfa_channels=cfg.mfa_channels, embed_dim=cfg.embed_dim, n_blocks=nb, kernel0=cfg.kernel0,
                   dilation=list(cfg.dilations) + [0] * (4 - nb), off=off)

@@ -31,10 +31,10 @@ def test_library_exports_every_declared_symbol():
 
 def test_struct_layouts_match_header():
     assert C.sizeof(LIB.EcapaDesc) == 16 * 4 + 256 * 8            # ABI 2: + precision, reserved0
-    assert LIB.EcapaDesc.off.offset == 64 and LIB.EcapaDesc.precision.offset == 56
+    assert LIB.EcapaDesc.off.offset == 64 and LIB.EcapaDesc.precision.offset == 56 and LIB.EcapaDesc.blk0_tap_pack.offset == 60
     assert C.sizeof(LIB.ConvGemmHpArgs) == 20 * 8 + 7 * 4 + 4     # 20 pointer/int64 slots, 6 ints + flags, tail padding
     assert C.sizeof(LIB.ProfileReport) == 24 * 4 + 3 * 24 * 8
-    assert C.sizeof(LIB.ConvGemmArgs) == 16 * 8 + 8 * 4 + 8 + 16  # 16 pointer/int64 slots, 6 ints + flags + stats_mode, stats_part, A2 + lda2
+    assert C.sizeof(LIB.ConvGemmArgs) == 16 * 8 + 8 * 4 + 8 + 16 + 8  # 16 pointer/int64 slots, 6 ints + flags + stats_mode, stats_part, A2 + lda2, tap_pack + reserved
 
 
 def test_host_only_entry_points_work_without_gpu():
@@ -102,11 +102,12 @@ def test_weight_packing_layout():
     off = f["off"]
     used = [o for o in off if o >= 0]
     assert all(o % 256 == 0 for o in used) and len(used) == len(set(used))
-    # blk0 weight: [256][5][128] tap-major, channels 80..127 zero, values = bf16(w)
-    k0 = blob[off[0]:off[0] + 256 * 640 * 2].view(np.uint16).reshape(256, 5, 128)
-    assert not k0[:, :, 80:].any()
+    # blk0 weight, taps packed along K (round 3): [256][448] = tap-major 5 x 80 channels + 48 zero columns, values = bf16(w)
+    assert f["blk0_tap_pack"] == 80
+    k0 = blob[off[0]:off[0] + 256 * 448 * 2].view(np.uint16).reshape(256, 448)
+    assert not k0[:, 400:].any()
     want = WP.f32_to_bf16_bits(np.transpose(w["blk0.conv.w"], (0, 2, 1)))
-    assert np.array_equal(k0[:, :, :80], want)
+    assert np.array_equal(k0[:, :400].reshape(256, 5, 80), want)
     # folded BN of blk0
     s, sh = W.bn_affine(w, "blk0.bn")
     assert np.array_equal(blob[off[2]:off[2] + 1024].view(np.float32), s)

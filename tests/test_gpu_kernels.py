@@ -102,6 +102,30 @@ def test_conv_gemm_integer_exact(engine, M, T, N, Cin, taps, dil):
     assert torch.equal(C32.cpu(), want), f"max diff {float((C32.cpu() - want).abs().max())}"
 
 
+@pytest.mark.parametrize("M,T,N,C,taps,dil", [(1005, 201, 256, 80, 5, 1), (2010, 201, 1024, 80, 5, 1), (250, 50, 256, 80, 5, 1), (402, 201, 128, 24, 3, 2),
+                                              (603, 201, 256, 40, 7, 1)])
+def test_conv_gemm_packed_taps_integer_exact(engine, M, T, N, C, taps, dil):
+    """tap_pack (round 3): the taps share K - W is [N, round_up(taps * C, 64)], a 16-byte chunk of 8 channels belongs to tap chunk / (C / 8),
+    the K padding multiplies finite activations by zero weights.  Small integers: bit-exact against the oracle, in the 256^2 kernel
+    (M >= 256, N % 256 == 0) and in the 128^2 kernel (the other shapes).  blk0 of the model is the first case's shape with N = 1024."""
+    g = torch.Generator().manual_seed(M + N + C)
+    lda = 128                                             # the activations stay 128 wide (feats), C channels are read per tap
+    A = torch.randint(-3, 4, (M, lda), generator=g).float()
+    Wt = torch.randint(-2, 3, (N, taps * C), generator=g).float()
+    kp = (taps * C + 63) // 64 * 64
+    Wp = torch.zeros(N, kp)
+    Wp[:, :taps * C] = Wt
+    A[:, C:] = 7.0                                        # columns beyond C must never be read as data (only as zero-weighted padding)
+    want = _conv_ref(A, Wt, C, taps, dil, T)
+    assert float(want.abs().max()) < 256                  # exactly representable in bf16: the 256^2 kernel (bf16 output only) is exact too
+    Ad, Wd = dev(A, torch.bfloat16), dev(Wp, torch.bfloat16)
+    Cb, _, _ = engine.conv_gemm(Ad, Wd, N, C, taps=taps, dil=dil, T=T, tap_pack=C)                                  # 256^2 kernel where the shape allows
+    _, C32, _ = engine.conv_gemm(Ad, Wd, N, C, taps=taps, dil=dil, T=T, out_bf16=False, out_f32=True, tap_pack=C)   # always the 128^2 kernel
+    torch.cuda.synchronize()
+    assert torch.equal(Cb.float().cpu(), want), f"max diff {float((Cb.float().cpu() - want).abs().max())}"
+    assert torch.equal(C32.cpu(), want), f"max diff {float((C32.cpu() - want).abs().max())}"
+
+
 def test_conv_gemm_epilogue(engine):
     M, T, N, Cin = 402, 201, 256, 128
     g = torch.Generator().manual_seed(5)
