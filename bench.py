@@ -111,15 +111,19 @@ def cpu_baseline(pcm: np.ndarray, P: np.ndarray, budget_s: float = 18.0):
         times.append(dt)
     med = sorted(times)[reps // 2]
     torch.set_num_threads(1)
-    n1 = max(1, min(n, 2))
+    n1 = max(1, min(n, 8))
     run(1)
-    t1 = sorted(run(n1)[0] for _ in range(reps))[reps // 2]
+    t1s = [run(n1)[0] for _ in range(reps)]
+    t1 = sorted(t1s)[reps // 2]
     torch.set_num_threads(cores)
     return {"value": n / med, "unit": "segment-embeddings/sec", "cores": cores, "kind": "port",
             "sample": f"{n} of the {len(pcm)} segments, oracle fbank+ECAPA(fp32)+L2+cosine argmax on torch-CPU; 1 warm-up + {reps} timed reps "
                       f"({', '.join(f'{t:.2f}' for t in times)} s), median",
             "reps_s": [round(t, 3) for t in times],
-            "one_thread": {"value": n1 / t1, "cores": 1, "sample": f"{n1} segment(s), median of {reps} reps ({t1:.2f} s)"}}, emb
+            "one_thread": {"value": n1 / t1, "cores": 1, "sample": f"{n1} segments, median of {reps} reps ({', '.join(f'{t:.2f}' for t in t1s)} s)"},
+            "scaling_note": "the port restates every conv as 'gather shifted frames, then matmul' in fp32 torch: per tap and layer it materialises a [B, T, C] copy, "
+                            "and ReLU / BN / softmax / exp are elementwise sweeps - beyond a few threads it is bound by host memory bandwidth and by the box's "
+                            "cgroup share of the socket (16 hardware threads of a much larger part), not by the sgemm calls; a reported baseline, not a tuned CPU implementation"}, emb
 
 
 def measure_gemm_clock(eng, step):
@@ -138,6 +142,71 @@ def measure_gemm_clock(eng, step):
         return None
 
 
+def precision_modes(eng, pcm, pcm_host, P_host, Pn, Pb, rpm, default_value, default_ms, default_parity, n_par=32):
+    """Both numerical contracts on the same workload (VERDICT r2 next #1c): the default mode's figures are the headline's; the precise mode
+    (fp16 hi+lo planes, three MFMAs per product, csrc/hp.hip) is timed here on the same 1000 resident segments (outside the timed region)
+    and its PCM -> score deviation from the UN-ROUNDED oracle (float64 accumulation) is measured on the first `n_par` segments."""
+    from oracle import ecapa as oecapa, fbank as ofbank
+    weights = importlib.import_module(f"{PKG}.weights").synthetic_weights(0)
+    B = pcm.shape[0]
+    eng.set_precision(1)
+    try:
+        def step():
+            E, Eb, re = eng.embed_pcm(pcm)
+            return E, eng.affinity_topk(E, Eb, re, Pn, Pb, rpm, k=1)
+        step()
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        reps = 4
+        for _ in range(reps):
+            E, (gi, gs) = step()
+        torch.cuda.synchronize()
+        ms = (time.perf_counter() - t0) / reps * 1e3
+        eng.profile_begin()
+        step()
+        prof = eng.profile_end()
+        m = min(n_par, B)
+        model = oecapa.EcapaOracle(weights, "fp32", torch.float64)
+        Eo = oecapa.l2_normalise(model.embed(torch.from_numpy(ofbank.fbank(pcm_host[:m]))).numpy())
+        par = parity_object(E[:m].cpu().numpy(), gi[:m, 0].cpu().numpy(), gs[:m, 0].cpu().numpy(), Eo, P_host)
+        hp = prof.get("conv_gemm_hp", {"ms": 0.0, "flops": 0.0})
+    finally:
+        eng.set_precision(0)
+    return {"default": {"precision": 0, "operands": "bf16 (bf16 layer-boundary storage)", "value": round(default_value, 1), "ms_per_step": round(default_ms, 3),
+                        "max_abs_dscore_all_pairs": default_parity["max_abs_dscore_all_pairs"] if default_parity else None,
+                        "id_mismatches": default_parity["id_mismatches"] if default_parity else None,
+                        "parity_sample": f"{default_parity['segments']} segments x {default_parity['profiles']} profiles vs the fp32 oracle" if default_parity else None},
+            "precise": {"precision": 1, "operands": "fp16 hi+lo planes, 3 MFMAs per product, fp32 accumulate (sdk_set_option precision 1)",
+                        "value": round(B / ms * 1e3, 1), "unit": "segment-embeddings/sec", "ms_per_step": round(ms, 3), "steps_timed": reps,
+                        "max_abs_dscore_all_pairs": par["max_abs_dscore_all_pairs"], "max_abs_dscore_top1": par["max_abs_dscore_top1"],
+                        "id_mismatches": par["id_mismatches"], "min_cos_embedding": par["min_cos_embedding"],
+                        "parity_sample": f"{m} segments x {P_host.shape[0]} profiles vs the un-rounded oracle (float64 accumulation)",
+                        "meets_north_star_1e-5": bool(par["max_abs_dscore_all_pairs"] <= 1e-5 and par["id_mismatches"] == 0),
+                        "conv_gemm_hp_ms": round(hp["ms"], 3), "conv_gemm_hp_executed_tflops": round(hp["flops"] / (hp["ms"] * 1e-3) / 1e12, 1) if hp["ms"] else None},
+            "error_budget": "profiles/r03_error_budget.md (CPU, per rounding site): the bf16 WEIGHTS make 4.15e-3 of the default mode's 4.25e-3; 16 significand bits everywhere "
+                            "give 2.3e-5, 22 bits (fp16 pairs) 1.5e-7"}
+
+
+def cold_start_object(timeout_s=120):
+    """Time to the first identify row in a fresh process (tools/cold_start.py), once with an empty packed-blob cache and once with the
+    entry the first run wrote.  Child processes: they initialise the GPU themselves; this process never re-execs."""
+    import subprocess, tempfile
+    out = {}
+    with tempfile.TemporaryDirectory(prefix="sdk_cache_") as cache:
+        env = dict(os.environ, SDK_CACHE_DIR=cache, HSA_ENABLE_IPC_MODE_LEGACY="0")
+        env.pop("SDK_ECAPA_WEIGHTS", None)
+        for label in ("first_process_empty_cache", "second_process_cache_hit"):
+            try:
+                r = subprocess.run([sys.executable, str(ROOT / "tools" / "cold_start.py")], env=env, capture_output=True, text=True, timeout=timeout_s)
+                line = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
+                out[label] = json.loads(line[-1]) if line else {"error": (r.stderr or "no output")[-300:]}
+            except Exception as exc:  # noqa: BLE001
+                out[label] = {"error": repr(exc)[:300]}
+    out["note"] = ("fresh Python process through plugin_api.get_backend('mi355x'): import, weights (generate / cache), digest, pack, upload, first enroll + identify of a "
+                   "12-s WAV (code-object load), second identify; the reference builds its backend once per CLI process (base.py:272-293)")
+    return out
+
+
 def main() -> int:
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -147,6 +216,7 @@ def main() -> int:
     ap.add_argument("--profiles", type=int, default=100)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-affinity-config3", action="store_true")
+    ap.add_argument("--no-extras", action="store_true", help="skip the precise-mode, sustained and cold-start legs (they run outside the timed region)")
     args = ap.parse_args()
 
     rank = int(os.environ.get("RANK", "0"))
@@ -369,10 +439,22 @@ def main() -> int:
                 eng.affinity_matvec(E5b, X5)
             p5 = eng.profile_end()["affinity_matvec"]
             ms5 = p5["ms"] / 3
+            mv_traffic, mv_src = None, None
+            mv_files = sorted((ROOT / "profiles").glob("*pmc_matvec.json"))
+            if mv_files:      # committed rocprofv3 --pmc pass of this kernel at this shape (tools/pmc_any.sh tools/one_matvec.py): bytes leaving L2 per launch
+                try:
+                    pm = json.loads(mv_files[-1].read_text())["affinity_matvec2_kernel"]
+                    mv_traffic = round((2.0 * pm["FETCH_SIZE"] + pm["WRITE_SIZE"]) * 1024.0, 1)
+                    mv_src = f"profiles/{mv_files[-1].name}"
+                except Exception:  # noqa: BLE001
+                    pass
             clus = {"workload": "config #5 tile kernel: 100k x 100k segment-segment affinity recomputed + A.X (k=16), one GPU",
                     "pairs_per_sec": round(N5 * N5 / (ms5 * 1e-3), 1), "ms": round(ms5, 3),
-                    "roofline": {"kernel": "affinity_matvec_kernel", "bound": "mfma", "achieved": round(2.0 * N5 * N5 * (192 + k5) / (ms5 * 1e-3) / 1e12, 2),
-                                 "peak": PEAK_BF16_MFMA / 1e12, "unit": "TFLOP/s", "frac": round(2.0 * N5 * N5 * (192 + k5) / (ms5 * 1e-3) / PEAK_BF16_MFMA, 4), "traffic": None}}
+                    "roofline": {"kernel": "affinity_matvec2_kernel", "bound": "mfma", "achieved": round(2.0 * N5 * N5 * (192 + k5) / (ms5 * 1e-3) / 1e12, 2),
+                                 "peak": PEAK_BF16_MFMA / 1e12, "unit": "TFLOP/s", "frac": round(2.0 * N5 * N5 * (192 + k5) / (ms5 * 1e-3) / PEAK_BF16_MFMA, 4),
+                                 "traffic": mv_traffic, "traffic_source": mv_src,
+                                 "algorithmic_bytes_per_launch": 2.0 * N5 * 192 + 4.0 * N5 * k5 * 2,
+                                 "note": "executed flops are 1.23x the algorithmic 2 N^2 (192 + k): X is split hi+lo and padded to 32 columns"}}
 
         out = {
             "metric": "segment-embeddings/sec", "value": round(value, 2), "unit": "segment-embeddings/sec",
@@ -392,6 +474,24 @@ def main() -> int:
                            "note": "peak = 2.4 GHz datasheet figure; in_kernel_clock_mhz = shader clock the chip held inside the dominant kernel (s_memtime / s_memrealtime), "
                                    "clock-adjusted fraction = frac * 2400 / in_kernel_clock_mhz"},
         }
+        try:
+            out["rccl_version"] = ".".join(str(x) for x in torch.cuda.nccl.version())
+        except Exception:  # noqa: BLE001
+            out["rccl_version"] = None
+        if world == 1 and not args.no_extras:
+            # sustained: >= 200 steps (~2 s) of the same step, with the in-kernel clock of the dominant kernel before and after, so a reader (and
+            # the driver's utilisation sampler) can see whether the 20-step headline holds
+            c0 = measure_gemm_clock(eng, step)
+            torch.cuda.synchronize()
+            ts = time.perf_counter()
+            n_sus = 200
+            for _ in range(n_sus):
+                step()
+            torch.cuda.synchronize()
+            sus = time.perf_counter() - ts
+            c1 = measure_gemm_clock(eng, step)
+            out["sustained"] = {"steps": n_sus, "seconds": round(sus, 3), "value": round(B * n_sus / sus, 1), "ms_per_step": round(sus / n_sus * 1e3, 3),
+                                "ratio_to_headline": round((B * n_sus / sus) / value, 4), "in_kernel_clock_mhz_before": c0, "in_kernel_clock_mhz_after": c1}
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"], e_ref = cpu_baseline(pcm_host, P_host)
             # PCM -> score deviation of the GPU path from the fp32 oracle on the baseline's sample (>= 64 segments when the host is
@@ -402,6 +502,12 @@ def main() -> int:
             out["parity"] = dict(parity_object(Eg[:m].cpu().numpy(), gi[:m, 0].cpu().numpy(), gs[:m, 0].cpu().numpy(), e_ref[:m], P_host),
                                  reference="oracle/ecapa.py mode fp32 (no rounding anywhere) + oracle/scoring.py, same PCM, same profiles",
                                  note="k4 alone (given the embeddings) is exact: max_abs_top1_score_vs_own_embedding; the embedding deviation is the bf16 operand model")
+        if world == 1 and not args.no_extras:
+            try:
+                out["precision_modes"] = precision_modes(eng, pcm, pcm_host, P_host, Pn, Pb, rpm, value, ms_step, out.get("parity"))
+            except Exception as exc:  # noqa: BLE001
+                out["precision_modes"] = {"error": repr(exc)[:300]}
+            out["cold_start"] = cold_start_object()
         print(json.dumps(out), flush=True)
 
     if use_dist:

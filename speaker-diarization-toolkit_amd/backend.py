@@ -31,6 +31,10 @@ from .weights import DEFAULT_CONFIG, load_weights, synthetic_weights, weights_di
 
 class Backend(EmbeddingBackend):
     def __init__(self) -> None:
+        if not os.environ.get("SDK_ECAPA_WEIGHTS"):
+            print("mi355x backend: SDK_ECAPA_WEIGHTS not set - using seeded synthetic ECAPA-TDNN weights "
+                  "(scores are self-consistent but not trained)", file=sys.stderr)
+        self._cache_hit = False
         self._engine = None
         self._weights = None
         self._digest: Optional[str] = None
@@ -65,21 +69,33 @@ class Backend(EmbeddingBackend):
             if path:
                 self._weights = load_weights(path)
             else:
-                print("mi355x backend: SDK_ECAPA_WEIGHTS not set - using seeded synthetic ECAPA-TDNN weights "
-                      "(scores are self-consistent but not trained)", file=sys.stderr)
                 self._weights = synthetic_weights(0)
         return self._weights
 
+    def _cache_key(self) -> str:
+        """Identity of the weights for the packed-blob cache, without reading them (weights_cache.py)."""
+        from . import weights_cache
+        path = os.environ.get("SDK_ECAPA_WEIGHTS")
+        return weights_cache.key_for_file(path) if path else weights_cache.key_for_seed(0, DEFAULT_CONFIG)
+
     def _weights_digest(self) -> str:
+        """Content hash of the weights (part of model_version).  A process that finds the packed blob in the cache takes the digest
+        from the cache entry too: no 20.8 M-parameter generate / parse, no SHA-256 over 83 MB, no re-pack (cold start: tools/cold_start.py)."""
         if self._digest is None:
-            self._digest = weights_digest(self._host_weights())
+            from . import weights_cache
+            meta = weights_cache.load_meta(self._cache_key())
+            if meta and meta.get("digest") and self._weights is None:
+                self._digest = meta["digest"]
+                self._cache_hit = True
+            else:
+                self._digest = weights_digest(self._host_weights())
         return self._digest
 
     def engine(self):
         if self._engine is None:
             from .ops import Engine   # imports torch + dlopens libsdk_hip.so; raises SdkError if absent
             dev = int(os.environ.get("SDK_DEVICE", os.environ.get("LOCAL_RANK", "0")))
-            self._engine = Engine(dev, weights=self._host_weights())
+            self._engine = Engine(dev, cache_key=self._cache_key(), weights_fn=self._host_weights, digest_fn=self._weights_digest)
         return self._engine
 
     # ---- the GPU path ----------------------------------------------------------------------

@@ -45,12 +45,18 @@ def num_frames(n_samples: int) -> int:
 
 class Engine:
     def __init__(self, device: int = 0, weights: Optional[Dict[str, np.ndarray]] = None,
-                 cfg: EcapaConfig = DEFAULT_CONFIG, seed: int = 0):
+                 cfg: EcapaConfig = DEFAULT_CONFIG, seed: int = 0, cache_key: Optional[str] = None, weights_fn=None, digest_fn=None):
+        """weights: host dict (weights.py naming) or None; weights_fn: called only when the dict is really needed (cache miss);
+        cache_key / digest_fn: identity of the weights for the packed-blob cache (weights_cache.py) - None = no caching."""
         self.lib = _lib.load_library()
         self.ctx = _lib.get_ctx(device)        # raises SdkError without a gfx950 device
         self.device = torch.device("cuda", device)
         self.cfg = cfg
         self._weights_host = weights
+        self._weights_fn = weights_fn
+        self._cache_key = cache_key
+        self._digest_fn = digest_fn
+        self.cache_hit = False
         self._seed = seed
         self._wblob = None
         self._desc = None
@@ -82,10 +88,19 @@ class Engine:
         if weights is not None:
             self._weights_host = weights
             self._packed.clear()
-        if self._weights_host is None:
-            self._weights_host = synthetic_weights(self._seed, self.cfg)
+            self._cache_key = None                      # explicit weights: their identity is unknown to the cache
         if self.precision not in self._packed:
-            blob, f = pack_weights(self._weights_host, self.cfg, precision=self.precision)
+            from . import weights_cache
+            hit = weights_cache.load_blob(self._cache_key, self.precision) if self._cache_key else None
+            if hit is not None:
+                blob, f = hit                            # memory-mapped: the upload below is the only pass over the bytes
+                self.cache_hit = True
+            else:
+                if self._weights_host is None:
+                    self._weights_host = self._weights_fn() if self._weights_fn else synthetic_weights(self._seed, self.cfg)
+                blob, f = pack_weights(self._weights_host, self.cfg, precision=self.precision)
+                if self._cache_key and self._digest_fn:
+                    weights_cache.store(self._cache_key, self._digest_fn(), self.precision, blob, f)
             d = EcapaDesc()
             for k, v in f.items():
                 if k == "dilation":
@@ -94,7 +109,7 @@ class Engine:
                     d.off = (C.c_int64 * 256)(*v)
                 else:
                     setattr(d, k, v)
-            self._packed[self.precision] = (torch.from_numpy(blob).to(self.device), d)
+            self._packed[self.precision] = (torch.from_numpy(np.asarray(blob)).to(self.device), d)
         self._wblob, self._desc = self._packed[self.precision]
 
     def set_precision(self, precision: int) -> None:

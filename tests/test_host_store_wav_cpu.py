@@ -268,3 +268,45 @@ def test_identify_rows_early_exits_mirror_cmd_identify(tmp_path, monkeypatch, ca
     assert "No speakers with mi355x embeddings." in capsys.readouterr().err
     assert ident.make_rows_fn(audio, tags=["other"])("S1", []) == []
     assert "No speakers to match against." in capsys.readouterr().err
+
+
+def test_packed_blob_cache_roundtrip_and_backend_digest(tmp_path, monkeypatch):
+    """weights_cache.py (cold start): the packed blob + digest of a weight set are found by a key that needs no pass
+    over the weights; a second process takes model_version from the entry without generating / hashing 20.8 M parameters; a damaged,
+    foreign-format or disabled cache is ignored, never trusted."""
+    import json
+    wc, W, WP = sub("weights_cache"), sub("weights"), sub("weights_pack")
+    monkeypatch.setenv("SDK_CACHE_DIR", str(tmp_path / "cache"))
+    monkeypatch.delenv("SDK_ECAPA_WEIGHTS", raising=False)
+    cfg = W.EcapaConfig(channels=256, mfa_channels=768)
+    w = W.synthetic_weights(9, cfg)
+    key = wc.key_for_seed(9, cfg)
+    assert key != wc.key_for_seed(8, cfg) and wc.load_blob(key, 0) is None and wc.load_meta(key) is None
+    for prec in (0, 1):
+        blob, f = WP.pack_weights(w, cfg, precision=prec)
+        wc.store(key, "abc123abc123", prec, blob, f)
+        got, gf = wc.load_blob(key, prec)
+        assert np.array_equal(np.asarray(got), blob) and gf == f and isinstance(got, np.memmap)
+    assert wc.load_meta(key)["digest"] == "abc123abc123" and set(wc.load_meta(key)["fields"]) == {"0", "1"}
+    # a truncated blob or another format version is a miss
+    meta = json.loads((tmp_path / "cache" / f"{key}.json").read_text())
+    meta["fields"]["0"]["_bytes"] += 1
+    (tmp_path / "cache" / f"{key}.json").write_text(json.dumps(meta))
+    assert wc.load_blob(key, 0) is None and wc.load_blob(key, 1) is not None
+    meta["format"] = -1
+    (tmp_path / "cache" / f"{key}.json").write_text(json.dumps(meta))
+    assert wc.load_meta(key) is None and wc.load_blob(key, 1) is None
+    # file-keyed entries change with the file
+    path = tmp_path / "w.npz"
+    W.save_weights(path, w)
+    k1 = wc.key_for_file(str(path))
+    os.utime(path, ns=(1, 1))
+    assert wc.key_for_file(str(path)) != k1
+    # the backend's model_version comes from the cache entry when there is one (no weights are generated) ...
+    be_key = wc.key_for_seed(0, W.DEFAULT_CONFIG)
+    (tmp_path / "cache" / f"{be_key}.json").write_text(json.dumps({"format": wc.FORMAT, "digest": "feedfeedfeed", "fields": {}}))
+    be = backend.Backend()
+    assert be.model_version == "mi355x-ecapa1024-feedfeedfeed" and be._weights is None and be._cache_hit
+    # ... and from the weights themselves when the cache is switched off
+    monkeypatch.setenv("SDK_WEIGHTS_CACHE", "0")
+    assert wc.load_meta(be_key) is None

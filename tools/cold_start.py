@@ -1,0 +1,65 @@
+#!/usr/bin/env python3
+"""Time-to-first-row of the backend in a FRESH process: the reference constructs its backend once per CLI process
+(speaker_detection_backends/base.py:272-293: get_backend -> module.Backend()) and runs up to 4 of them at once
+(speaker-process:627-629), so for a 10-segment job what matters is import + weights + pack + upload + code-object load, not the
+steady-state step.  Prints one JSON object with the phases in seconds.  Run it twice: the second process finds the packed blob in
+the on-disk cache (weights_cache.py) and skips generate / digest / pack.
+
+    python tools/cold_start.py [--seconds 12] [--no-cache]
+"""
+import argparse, json, os, sys, tempfile, time
+t_proc = time.perf_counter()
+from pathlib import Path
+ROOT = Path(__file__).resolve().parent.parent
+sys.path.insert(0, str(ROOT))
+ap = argparse.ArgumentParser()
+ap.add_argument("--seconds", type=float, default=12.0)
+ap.add_argument("--no-cache", action="store_true")
+a = ap.parse_args()
+if a.no_cache:
+    os.environ["SDK_WEIGHTS_CACHE"] = "0"
+ph = {}
+def mark(name, t0):
+    ph[name] = round(time.perf_counter() - t0, 4)
+    return time.perf_counter()
+
+t = time.perf_counter()
+import numpy as np
+import torch                                                    # noqa: F401
+t = mark("import_numpy_torch", t)
+import importlib
+api = importlib.import_module("speaker-diarization-toolkit_amd.plugin_api")
+wav = importlib.import_module("speaker-diarization-toolkit_amd.wav")
+t = mark("import_package", t)
+be = api.get_backend("mi355x")
+t = mark("get_backend", t)
+tmp = Path(tempfile.mkdtemp(prefix="cold_"))
+os.environ["SPEAKERS_EMBEDDINGS_DIR"] = str(tmp)
+rng = np.random.default_rng(0)
+n = int(16000 * a.seconds)
+tt = np.arange(n) / 16000.0
+x = 0.3 * np.sin(2 * np.pi * 140 * tt) + 0.1 * np.sin(2 * np.pi * 420 * tt) + rng.normal(0, 0.02, n)
+wav.write_wav_s16(tmp / "a.wav", np.clip(np.round(x * 32767 * 0.5), -32768, 32767).astype(np.int16))
+t = time.perf_counter()
+mv = be.model_version                                           # host weights (generate or load, or the cache) + digest
+t = mark("weights_and_digest", t)
+eng = be.engine()
+t = mark("engine_ctx (dlopen, hipInit)", t)
+eng.desc                                                        # pack (or cache hit) + upload
+torch.cuda.synchronize()
+t = mark("pack_and_upload", t)
+rec = be.enroll_speaker(tmp / "a.wav")                          # first GPU pass: code-object load, fbank tables, scratch allocation
+torch.cuda.synchronize()
+t = mark("first_enroll (code objects, tables, scratch)", t)
+cand = [{"id": "a", "embeddings": {"mi355x": [{"id": "emb-a", "external_id": rec["external_id"], "model_version": rec["model_version"]}]}}]
+rows = be.identify_speaker(tmp / "a.wav", cand)
+torch.cuda.synchronize()
+t = mark("first_identify", t)
+rows = be.identify_speaker(tmp / "a.wav", cand)
+torch.cuda.synchronize()
+t = mark("second_identify", t)
+wc = importlib.import_module("speaker-diarization-toolkit_amd.weights_cache")
+out = {"phases_s": ph, "time_to_first_row_s": round(sum(v for k, v in ph.items() if k != "second_identify"), 3),
+       "process_wall_s": round(time.perf_counter() - t_proc, 3), "audio_seconds": a.seconds, "windows": rows[0]["n_segments"] if rows else 0,
+       "cache": {"enabled": wc.enabled(), "dir": str(wc.cache_dir()), "hit": bool(getattr(be, "_cache_hit", False))}, "model_version": mv}
+print(json.dumps(out))

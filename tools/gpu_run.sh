@@ -27,7 +27,7 @@ if [ "$WHAT" = all ] || [ "$WHAT" = bench ]; then
 fi
 if [ "$WHAT" = all ] || [ "$WHAT" = prof ]; then
   rm -rf gpurun_out/prof
-  stage rocprof 600 rocprofv3 --kernel-trace --stats --output-format csv -d gpurun_out/prof -o bench -- python3 bench.py --steps 3 --warmup 1 --no-cpu-baseline
+  stage rocprof 600 rocprofv3 --kernel-trace --stats --output-format csv -d gpurun_out/prof -o bench -- python3 bench.py --steps 3 --warmup 1 --no-cpu-baseline --no-extras
   find gpurun_out/prof -name '*kernel_stats*' | head -n 3 | tee -a gpurun_out/run.log
 fi
 echo DONE | tee -a gpurun_out/run.log
