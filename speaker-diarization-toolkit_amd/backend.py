@@ -11,6 +11,8 @@ Environment:
   SDK_DEVICE          GPU index (default: $LOCAL_RANK, else 0)
   SDK_ECAPA_WEIGHTS   .npz checkpoint in the weights.py naming (default: seeded synthetic weights -
                       there is no network here to fetch a pretrained model; a warning is printed)
+  SDK_ECAPA_LAYOUT    "public": SDK_ECAPA_WEIGHTS is a checkpoint in the public ECAPA-TDNN state-dict naming (.ckpt / .pt via
+                      torch.load(weights_only=True), .safetensors, .npz); SDK_ECAPA_PREFIX strips a key prefix
   SDK_WINDOW_S / SDK_HOP_S   analysis window / hop in seconds (default 2.0 / 1.0)
 """
 from __future__ import annotations
@@ -67,7 +69,13 @@ class Backend(EmbeddingBackend):
         if self._weights is None:
             path = os.environ.get("SDK_ECAPA_WEIGHTS")
             if path:
-                self._weights = load_weights(path)
+                # SDK_ECAPA_LAYOUT=public: a checkpoint in the public ECAPA-TDNN state-dict naming (weights.from_public_state_dict);
+                # default: the .npz naming of weights.py.  Both through non-executing loaders only.
+                if os.environ.get("SDK_ECAPA_LAYOUT", "native") == "public":
+                    from .weights import load_public_checkpoint
+                    self._weights = load_public_checkpoint(path, prefix=os.environ.get("SDK_ECAPA_PREFIX", ""))
+                else:
+                    self._weights = load_weights(path)
             else:
                 self._weights = synthetic_weights(0)
         return self._weights

@@ -94,3 +94,37 @@ def load_from_dict(model: EcapaNN, w) -> EcapaNN:
     bn(model.asp_bn, "asp_bn")
     model.fc.weight.data = t("fc.w"); model.fc.bias.data = t("fc.b")
     return model.eval()
+
+
+def public_state_dict(model: EcapaNN):
+    """The module tree's own state_dict() re-keyed into the PUBLIC ECAPA-TDNN checkpoint naming (every Conv1d wrapped as `.conv`, every
+    BatchNorm1d as `.norm`; blocks.0 = first TDNN, blocks.1-3 = SE-Res2Net blocks, ...), float32, including the `num_batches_tracked`
+    buffers a real checkpoint carries.  Written from the public module structure, independently of weights._public_key_map."""
+    sd = model.state_dict()
+    out = {}
+
+    def tdnn(src, dst):
+        out[f"{dst}.conv.conv.weight"] = sd[f"{src}.conv.weight"]; out[f"{dst}.conv.conv.bias"] = sd[f"{src}.conv.bias"]
+        norm(f"{src}.bn", f"{dst}.norm")
+
+    def norm(src, dst):
+        for a, b in (("weight", "weight"), ("bias", "bias"), ("running_mean", "running_mean"), ("running_var", "running_var"),
+                     ("num_batches_tracked", "num_batches_tracked")):
+            out[f"{dst}.norm.{b}"] = sd[f"{src}.{a}"]
+
+    tdnn("blk0", "blocks.0")
+    for i in range(len(model.blocks)):
+        b = f"blocks.{i}"
+        tdnn(f"{b}.tdnn1", f"blocks.{i + 1}.tdnn1")
+        for j in range(len(model.blocks[i].res2net)):
+            tdnn(f"{b}.res2net.{j}", f"blocks.{i + 1}.res2net_block.blocks.{j}")
+        tdnn(f"{b}.tdnn2", f"blocks.{i + 1}.tdnn2")
+        for k, name in ((1, "se1"), (2, "se2")):
+            out[f"blocks.{i + 1}.se_block.conv{k}.conv.weight"] = sd[f"{b}.{name}.weight"]
+            out[f"blocks.{i + 1}.se_block.conv{k}.conv.bias"] = sd[f"{b}.{name}.bias"]
+    tdnn("mfa", "mfa")
+    tdnn("asp_tdnn", "asp.tdnn")
+    out["asp.conv.conv.weight"] = sd["asp_conv.weight"]; out["asp.conv.conv.bias"] = sd["asp_conv.bias"]
+    norm("asp_bn", "asp_bn")
+    out["fc.conv.weight"] = sd["fc.weight"]; out["fc.conv.bias"] = sd["fc.bias"]
+    return {k: (v.float() if v.is_floating_point() else v) for k, v in out.items()}

@@ -1,6 +1,7 @@
 """The oracle is the checker for the GPU path, so it is itself cross-checked against independent
 library implementations (parity with the reference is unpinned: it has no such arithmetic)."""
 import numpy as np
+import pytest
 import torch
 import torch.nn.functional as F
 
@@ -150,3 +151,48 @@ def test_spectral_against_scipy_and_sklearn():
     km = KMeans(5, n_init=5, random_state=0).fit(R)
     assert ospec.adjusted_rand_index(km.labels_, lab) == 1.0
     assert list(ospec.canonical_labels(np.array([7, 7, 2, 7, 5, 2]))) == [0, 0, 1, 0, 2, 1]
+
+
+def test_public_state_dict_import_gives_the_same_embeddings(tmp_path):
+    """VERDICT r2 missing #3: weights in the PUBLIC ECAPA-TDNN checkpoint naming (what the reference's "SpeechBrain ECAPA-TDNN" would ship:
+    backends.yaml:22-31) are mapped to the native naming.  A torch.nn model with random parameters emits its own state_dict() re-keyed into the
+    foreign layout (tests/nn_ecapa_ref.public_state_dict, num_batches_tracked buffers included); read back through
+    weights.from_public_state_dict - directly, through a torch file with weights_only=True, an .npz and a key prefix - it must give the
+    embeddings the model itself computes.  PARITY UNPINNED against any trained model: none exists here and none may be fetched."""
+    from nn_ecapa_ref import EcapaNN, load_from_dict, public_state_dict
+    cfg = W.EcapaConfig(channels=256, mfa_channels=768, se_channels=32, attn_channels=64, embed_dim=48)
+    torch.manual_seed(11)
+    model = EcapaNN(c=256, se=32, attn=64, mfa=768, emb=48).double().eval()
+    with torch.no_grad():                                   # non-trivial BatchNorm statistics, as a trained checkpoint has
+        for m in model.modules():
+            if isinstance(m, torch.nn.BatchNorm1d):
+                m.running_mean.normal_(0, 0.2); m.running_var.uniform_(0.5, 1.5); m.weight.uniform_(0.8, 1.2); m.bias.normal_(0, 0.1)
+    pub = public_state_dict(model)
+    assert "blocks.1.res2net_block.blocks.6.conv.conv.weight" in pub and "asp_bn.norm.running_var" in pub and "fc.conv.weight" in pub
+    assert pub["blocks.0.norm.norm.num_batches_tracked"].dtype == torch.int64
+    w = W.from_public_state_dict(pub, cfg)
+    feats = torch.randn(2, 30, 80, generator=torch.Generator().manual_seed(2), dtype=torch.float64) * 3
+    with torch.no_grad():
+        ref = model(feats)
+    got = oecapa.EcapaOracle(w, "fp32", torch.float64).embed(feats.float())
+    assert float((got.double() - ref).abs().max()) < 1e-4 * float(ref.abs().max())
+    # round trip of the map, and the file loaders (none of them unpickles)
+    back = W.to_public_state_dict(w, cfg)
+    assert all(np.array_equal(back[k], pub[k].numpy()) for k in back)
+    torch.save({k: v for k, v in pub.items()}, tmp_path / "embedding_model.ckpt")
+    w2 = W.load_public_checkpoint(tmp_path / "embedding_model.ckpt", cfg)
+    np.savez(tmp_path / "pub.npz", **{"module." + k: v.numpy() for k, v in pub.items()})
+    w3 = W.load_public_checkpoint(tmp_path / "pub.npz", cfg, prefix="module.")
+    for k in w:
+        assert np.array_equal(w[k], w2[k]) and np.array_equal(w[k], w3[k])
+    # errors name the PUBLIC tensor
+    bad = dict(pub); del bad["mfa.conv.conv.weight"]
+    with pytest.raises(ValueError, match="mfa.conv.conv.weight"):
+        W.from_public_state_dict(bad, cfg)
+    bad = dict(pub); bad["blocks.2.tdnn1.conv.conv.weight"] = torch.zeros(3, 3, 1)
+    with pytest.raises(ValueError, match="blocks.2.tdnn1.conv.conv.weight"):
+        W.from_public_state_dict(bad, cfg)
+    # the same model through the native loader of the reference cross-check agrees too (two independent routes into EcapaNN)
+    with torch.no_grad():
+        ref2 = load_from_dict(EcapaNN(c=256, se=32, attn=64, mfa=768, emb=48), w)(feats)
+    assert float((ref2 - ref).abs().max()) < 1e-6
