@@ -66,7 +66,7 @@ def test_pcm_to_score_against_the_fp32_oracle(engine, both):
     assert rep["max_abs_top1_score_vs_own_embedding"] <= 1e-5
 
 
-def near_tie_report(engine, Et, Eo, P, bound, eps_list=(1e-4, 1e-3, 1e-2, 0.1, 0.4, 1.0)):
+def near_tie_report(engine, Et, Eo, P, bound, eps_list=(1e-4, 3e-4, 1e-3, 3e-3, 1e-2, 3e-2, 0.1, 0.4)):
     """Profiles built as p + eps * q around each segment's fp32 winner: the decision between a profile and its perturbed twin is held by
     a margin of order eps * 1, so sweeping eps samples how often the bf16 path keeps the fp32 model's ID as a function of that margin."""
     rng = np.random.default_rng(7)
@@ -104,13 +104,14 @@ def test_near_tie_id_agreement_vs_fp32_margin(engine, both):
     bound = float(np.abs(S_gpu - Eo.astype(np.float64) @ P.astype(np.float64).T).max())
     rep = near_tie_report(engine, Et, Eo, P, bound)
     print("\nnear-tie ID agreement vs fp32 margin:", json.dumps(rep))
-    assert sum(rep["rows"]) == 6 * N_SEG
+    assert sum(rep["rows"]) == 8 * N_SEG
     assert rep["rows"][1] + rep["rows"][2] + rep["rows"][3] > 1000, "the sweep must actually sample margins below the deviation"
     # the promise: every decision the fp32 model holds by more than twice the measured deviation is kept
     assert rep["largest_fp32_margin_of_a_changed_id"] <= 2.0 * bound
     assert rep["rows"][-1] > 100 and rep["agreement_rate"][-1] == 1.0
-    # ... below that the rate is what it is (measured round 3: 99.0 % under 1e-5, 99.8 % in [1e-5, 1e-4), 100 % from 1e-4 up: the
+    # ... below that the rate is what it is (measured round 3, twins per segment: 99.0 % under 1e-5, 99.8 % in [1e-5, 1e-4), 100 % from 1e-4 up; twins
+    # per profile: 100 % in every bin but one row at 7.7e-4: the
     # deviation of an embedding moves the scores of a profile and of its near twin almost equally, so near-tie decisions survive far
     # better than the worst-case bound says); only sanity is asserted
-    rates = [r for r in rep["agreement_rate"] if r is not None]
+    rates = [r for r, n in zip(rep["agreement_rate"], rep["rows"]) if n >= 100]
     assert rates[-1] >= rates[0] and min(rates) > 0.9

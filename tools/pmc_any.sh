@@ -1,5 +1,5 @@
 #!/bin/bash
-# PMC counters of any kernel family: tools/pmc_any.sh <python script> <kernel-name substring> [tag]
+# PMC counters of any kernel family: tools/pmc_any.sh <python script (+ args, quoted)> <kernel-name regex> [tag]
 # One rocprofv3 --pmc pass per counter set (only --kernel-trace beside it), the script run once per pass; per-kernel AVERAGES
 # per dispatch are printed and written to gpurun_out/pmc_<tag>.json.  FETCH_SIZE / WRITE_SIZE are in KB as rocprofv3 reports them
 # (gfx950: double FETCH_SIZE for wide streaming reads, MI355X_MICROARCH.md 'HBM').
@@ -14,12 +14,12 @@ for set in "SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE
   timeout -k 10 400 rocprofv3 --kernel-trace --pmc $set --output-format csv -d $OUT/s$i -o p -- python3 $SCRIPT > $OUT/s$i.log 2>&1 || { echo "set $i failed"; tail -3 $OUT/s$i.log; }
 done
 python3 - "$OUT" "$PAT" "$TAG" <<'PY'
-import csv, glob, json, sys, collections
+import csv, glob, json, re, sys, collections
 out_dir, pat, tag = sys.argv[1:4]
 per = collections.defaultdict(lambda: collections.defaultdict(list))
 for f in sorted(glob.glob(f"{out_dir}/s*/*counter_collection.csv")):
     for r in csv.DictReader(open(f)):
-        if pat not in r["Kernel_Name"]: continue
+        if not re.search(pat, r["Kernel_Name"]): continue
         name = r["Kernel_Name"].replace("(anonymous namespace)::", "").split("(")[0].split("<")[0].split()[-1]
         per[name][r["Counter_Name"]].append(float(r["Counter_Value"]))
 res = {k: {c: sum(v) / len(v) for c, v in d.items()} | {"dispatches_seen": max(len(v) for v in d.values())} for k, d in per.items()}
