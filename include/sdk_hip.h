@@ -23,7 +23,7 @@
  *     sdk_abi_version  sdk_init  sdk_shutdown  sdk_last_error  sdk_get_device_info
  *     sdk_resample_out_len  sdk_resample_s16                                   audio -> AudioProfile format
  *     sdk_fbank_tables_bytes  sdk_fbank_tables_fill  sdk_fbank_workspace_bytes  sdk_fbank              k1
- *     sdk_ecapa_workspace_bytes  sdk_ecapa_forward                                                      k2
+ *     sdk_ecapa_workspace_bytes  sdk_ecapa_forward  sdk_xvector_workspace_bytes  sdk_xvector_forward          k2
  *     sdk_l2norm                                                                                        k3
  *     sdk_affinity_workspace_bytes  sdk_affinity_topk                                                   k4
  *     sdk_affinity_matvec_workspace_bytes  sdk_affinity_matvec  sdk_rows_gram_workspace_bytes  sdk_rows_gram
@@ -238,6 +238,22 @@ size_t sdk_ecapa_workspace_bytes(const sdk_ecapa_desc* d, int B, int T);
 int sdk_ecapa_forward(sdk_ctx* ctx, const void* wblob, const sdk_ecapa_desc* wdesc,
                       const uint16_t* feats, int ldf, int B, int T,
                       void* ws, size_t ws_bytes, float* emb, void* stream);
+
+/* ---- x-vector (plain TDNN) forward - north_star names "ECAPA-TDNN/x-vector".  Frame layers l = 0..n_frame_layers-1:
+ *      dilated conv (kernel[l], dilation[l], "same" length by segment-local reflection) -> ReLU -> BatchNorm(eval), bf16 layer-boundary
+ *      storage, all on sdk_conv_gemm (layer 0 with its taps packed along K when the feature width is not a multiple of 64); then statistics
+ *      pooling (mean | std over frames, sdk_asp_stats) and the embedding layer (fp32, sdk_rows_fc).  feats as sdk_fbank writes them
+ *      ([B*T, ldf] bf16); emb [B, embed_dim] fp32 (pre-activation of the first segment layer, the usual x-vector).
+ *      off[4 l + {0,1,2,3}] = W (bf16 [cout][K]), bias, BN scale, BN shift of frame layer l; off[60] = FC weight (fp32 [2 cout_last, embed_dim],
+ *      transposed), off[61] = FC bias.  cout[] are multiples of 128 (pad a 1500-wide layer to 1536 with zero weights). */
+typedef struct sdk_xvector_desc {
+  int32_t n_frame_layers, n_feats, embed_dim, first_tap_pack;
+  int32_t kernel[8], dilation[8], cin[8], cout[8];
+  int64_t off[64];
+} sdk_xvector_desc;
+size_t sdk_xvector_workspace_bytes(const sdk_xvector_desc* d, int B, int T);
+int sdk_xvector_forward(sdk_ctx* ctx, const void* wblob, const sdk_xvector_desc* d, const uint16_t* feats, int ldf, int B, int T,
+                        void* ws, size_t ws_bytes, float* emb, void* stream);
 
 /* ---- audio conversion to the AudioProfile: replaces the ffmpeg subprocess the reference's backends
  *      run before upload (audio_profiles.py:70-100 `format_ffmpeg_args`; speechmatics_backend.py:231-281).

@@ -444,3 +444,76 @@ extern "C" int sdk_ecapa_forward(sdk_ctx* ctx, const void* wblob, const sdk_ecap
   return sdk_rows_fc(ctx, w.pooled, 2 * Cm, P32(tb + EL_ASPBN_SCALE), P32(tb + EL_ASPBN_SHIFT), P32(tb + EL_FC_WT),
                      P32(tb + EL_FC_B), emb, d->embed_dim, B, 2 * Cm, d->embed_dim, 0, stream);
 }
+
+// ------------------------------------------------------------------------------ x-vector forward
+// The plain TDNN embedding extractor (Snyder et al. 2018) composed from the same pieces: every frame layer is one sdk_conv_gemm
+// (conv -> ReLU -> folded BN -> bf16), the pooled statistics and the embedding layer are fp32.
+namespace {
+int check_xdesc(const sdk_xvector_desc* d) {
+  SDK_REQUIRE(d, "xvector desc is null");
+  SDK_REQUIRE(d->n_frame_layers >= 1 && d->n_frame_layers <= 8, "xvector desc: n_frame_layers=%d", d->n_frame_layers);
+  SDK_REQUIRE(d->embed_dim > 0 && d->n_feats > 0, "xvector desc: embed_dim=%d n_feats=%d", d->embed_dim, d->n_feats);
+  for (int l = 0; l < d->n_frame_layers; ++l) {
+    SDK_REQUIRE((d->kernel[l] & 1) == 1 && d->dilation[l] >= 1 && d->cout[l] % 128 == 0 && d->cout[l] > 0, "xvector desc: layer %d kernel=%d dil=%d cout=%d", l,
+                d->kernel[l], d->dilation[l], d->cout[l]);
+    if (l > 0) SDK_REQUIRE(d->cin[l] == d->cout[l - 1] && d->cin[l] % 64 == 0, "xvector desc: layer %d cin=%d does not follow cout=%d", l, d->cin[l], d->cout[l - 1]);
+    for (int q = 0; q < 4; ++q) SDK_REQUIRE(d->off[4 * l + q] >= 0, "xvector desc: slot %d of layer %d missing", q, l);
+  }
+  SDK_REQUIRE(d->cin[0] == d->n_feats && (d->first_tap_pack == 0 ? d->n_feats % 64 == 0 : (d->first_tap_pack == d->n_feats && d->n_feats % 8 == 0 && d->kernel[0] > 1)),
+              "xvector desc: first layer over %d features needs them to be a multiple of 64, or its taps packed (first_tap_pack = n_feats, a multiple of 8)", d->n_feats);
+  SDK_REQUIRE(d->off[60] >= 0 && d->off[61] >= 0, "xvector desc: embedding layer slots missing");
+  return 0;
+}
+size_t xv_layout(const sdk_xvector_desc* d, int B, int T, char* base, uint16_t** buf0, uint16_t** buf1, float** stats) {
+  size_t cmax = 0;
+  for (int l = 0; l < d->n_frame_layers; ++l) cmax = (size_t)d->cout[l] > cmax ? (size_t)d->cout[l] : cmax;
+  const size_t M = (size_t)B * T;
+  size_t off = 0;
+  auto take = [&](size_t bytes) { char* p = base ? base + off : nullptr; off += a256(bytes); return p; };
+  char* a = take(M * cmax * 2);
+  char* b = take(M * cmax * 2);
+  char* c = take((size_t)B * 2 * d->cout[d->n_frame_layers - 1] * 4);
+  if (buf0) { *buf0 = (uint16_t*)a; *buf1 = (uint16_t*)b; *stats = (float*)c; }
+  return off;
+}
+}  // namespace
+
+extern "C" size_t sdk_xvector_workspace_bytes(const sdk_xvector_desc* d, int B, int T) {
+  if (!d || B <= 0 || T <= 0 || d->n_frame_layers < 1 || d->n_frame_layers > 8) return 0;
+  return xv_layout(d, B, T, nullptr, nullptr, nullptr, nullptr);
+}
+
+extern "C" int sdk_xvector_forward(sdk_ctx* ctx, const void* wblob, const sdk_xvector_desc* d, const uint16_t* feats, int ldf, int B, int T,
+                                   void* ws, size_t ws_bytes, float* emb, void* stream) {
+  SDK_REQUIRE(ctx && wblob && feats && ws && emb, "sdk_xvector_forward: null argument");
+  if (int rc = check_xdesc(d)) return rc;
+  SDK_REQUIRE(ctx->precision == 0, "sdk_xvector_forward: the x-vector extractor exists in the default (bf16-operand) mode only");
+  SDK_REQUIRE(B > 0 && T > 0 && (int64_t)B * T < (1ll << 31), "sdk_xvector_forward: bad batch (B=%d T=%d)", B, T);
+  SDK_REQUIRE(ldf >= d->n_feats && ldf % 8 == 0, "sdk_xvector_forward: ldf=%d < feature width %d", ldf, d->n_feats);
+  for (int l = 0; l < d->n_frame_layers; ++l)
+    SDK_REQUIRE(T > (d->kernel[l] / 2) * d->dilation[l], "sdk_xvector_forward: segments of %d frames are shorter than layer %d's halo", T, l);
+  SDK_REQUIRE(ws_bytes >= sdk_xvector_workspace_bytes(d, B, T) && ((uintptr_t)ws % 256) == 0 && ((uintptr_t)wblob % 256) == 0, "sdk_xvector_forward: workspace too small or misaligned");
+  uint16_t *b0, *b1;
+  float* stats;
+  xv_layout(d, B, T, (char*)ws, &b0, &b1, &stats);
+  const char* wb = (const char*)wblob;
+  const uint16_t* in = feats;
+  int64_t ldin = ldf;
+  const int M = B * T;
+  for (int l = 0; l < d->n_frame_layers; ++l) {
+    uint16_t* out = (l & 1) ? b1 : b0;
+    sdk_conv_gemm_args g;
+    memset(&g, 0, sizeof(g));
+    g.A = in; g.lda = ldin; g.W = (const uint16_t*)(wb + d->off[4 * l]); g.C = out; g.ldc = d->cout[l];
+    g.bias = (const float*)(wb + d->off[4 * l + 1]); g.scale = (const float*)(wb + d->off[4 * l + 2]); g.shift = (const float*)(wb + d->off[4 * l + 3]);
+    g.M = M; g.N = d->cout[l]; g.Cin = d->cin[l]; g.taps = d->kernel[l]; g.dil = d->dilation[l]; g.T = T; g.flags = SDK_GEMM_RELU;
+    if (l == 0 && d->first_tap_pack) g.tap_pack = d->first_tap_pack;
+    if (int rc = sdk_conv_gemm(ctx, &g, stream)) return rc;
+    in = out;
+    ldin = d->cout[l];
+  }
+  const int Cl = d->cout[d->n_frame_layers - 1];
+  if (int rc = sdk_asp_stats(ctx, in, ldin, B, T, Cl, stats, stream)) return rc;
+  return sdk_rows_fc(ctx, stats, 2 * Cl, nullptr, nullptr, (const float*)(wb + d->off[60]), (const float*)(wb + d->off[61]), emb, d->embed_dim, B, 2 * Cl,
+                     d->embed_dim, 0, stream);
+}

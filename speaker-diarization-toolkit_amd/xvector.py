@@ -1,0 +1,158 @@
+"""x-vector (plain TDNN) embedding extractor - the second model family north_star names ("ECAPA-TDNN/x-vector forward pass").
+
+The reference has no local embedding model at all (speaker_detection_backends/backends.yaml:22-31 lists them as "future"); like the
+ECAPA-TDNN it is the PUBLIC architecture (Snyder et al. 2018, "X-vectors: robust DNN embeddings for speaker recognition"): five frame
+layers (contexts k5 / k3 dil 2 / k3 dil 3 / k1 / k1, 512-512-512-512-1500 channels, each affine -> ReLU -> BatchNorm), statistics
+pooling (mean | std over frames), and the first segment layer whose pre-activation is the embedding.  Differences stated: "same"-length
+frame layers by segment-local reflection (the toolkit cuts fixed windows; Kaldi shrinks the context instead), the front-end is this
+build's 80-bin log-mel fbank, and the default embedding width is 192 (not 512) so that k3 / k4 / the .npy store - specialised for 192-d -
+serve both model families.  PARITY UNPINNED (no reference implementation, no checkpoint).
+
+Everything runs in libsdk_hip.so through ONE C call per batch (sdk_xvector_forward: sdk_conv_gemm per frame layer, the first with its
+taps packed along K; sdk_asp_stats; sdk_rows_fc).  Weights: fp32 host dict, keys  frame{l}.conv.{w,b}  frame{l}.bn.{gamma,beta,mean,var}
+embed.{w,b}.
+"""
+from __future__ import annotations
+
+import ctypes as C
+from dataclasses import dataclass
+from typing import Dict, Tuple
+
+import numpy as np
+
+from .weights import bn_affine
+from .weights_pack import ALIGN, conv_weight_kmajor
+
+
+@dataclass(frozen=True)
+class XVectorConfig:
+    n_feats: int = 80
+    kernels: Tuple[int, ...] = (5, 3, 3, 1, 1)
+    dilations: Tuple[int, ...] = (1, 2, 3, 1, 1)
+    channels: Tuple[int, ...] = (512, 512, 512, 512, 1500)
+    embed_dim: int = 192
+
+    def padded_channels(self) -> Tuple[int, ...]:
+        return tuple((c + 127) // 128 * 128 for c in self.channels)
+
+    def macs_per_frame(self) -> int:
+        cin = (self.n_feats,) + self.channels[:-1]
+        return sum(k * ci * co for k, ci, co in zip(self.kernels, cin, self.channels))
+
+
+DEFAULT_XVECTOR = XVectorConfig()
+
+
+class XVectorDesc(C.Structure):
+    _fields_ = [("n_frame_layers", C.c_int32), ("n_feats", C.c_int32), ("embed_dim", C.c_int32), ("first_tap_pack", C.c_int32),
+                ("kernel", C.c_int32 * 8), ("dilation", C.c_int32 * 8), ("cin", C.c_int32 * 8), ("cout", C.c_int32 * 8), ("off", C.c_int64 * 64)]
+
+
+def param_shapes(cfg: XVectorConfig = DEFAULT_XVECTOR) -> Dict[str, Tuple[int, ...]]:
+    sh: Dict[str, Tuple[int, ...]] = {}
+    cin = (cfg.n_feats,) + cfg.channels[:-1]
+    for l, (k, ci, co) in enumerate(zip(cfg.kernels, cin, cfg.channels)):
+        sh[f"frame{l}.conv.w"] = (co, ci, k)
+        sh[f"frame{l}.conv.b"] = (co,)
+        for f in ("gamma", "beta", "mean", "var"):
+            sh[f"frame{l}.bn.{f}"] = (co,)
+    sh["embed.w"] = (cfg.embed_dim, 2 * cfg.channels[-1])
+    sh["embed.b"] = (cfg.embed_dim,)
+    return sh
+
+
+def synthetic_weights(seed: int = 0, cfg: XVectorConfig = DEFAULT_XVECTOR) -> Dict[str, np.ndarray]:
+    rng = np.random.default_rng(seed)
+    out: Dict[str, np.ndarray] = {}
+    for name, shape in param_shapes(cfg).items():
+        if name.endswith(".w"):
+            fan_in = int(np.prod(shape[1:]))
+            gain = 1.0 if name.startswith("embed") else 2.0
+            a = rng.standard_normal(shape, dtype=np.float32) * np.float32(np.sqrt(gain / fan_in))
+        elif name.endswith((".b", ".beta", ".mean")):
+            a = rng.standard_normal(shape, dtype=np.float32) * np.float32(0.1)
+        elif name.endswith(".gamma"):
+            a = rng.uniform(0.8, 1.2, shape).astype(np.float32)
+        else:
+            a = rng.uniform(0.5, 1.5, shape).astype(np.float32)
+        out[name] = np.ascontiguousarray(a, dtype=np.float32)
+    return out
+
+
+def pack_weights(weights: Dict[str, np.ndarray], cfg: XVectorConfig = DEFAULT_XVECTOR):
+    """-> (blob uint8, XVectorDesc).  Channel counts are padded to multiples of 128 with zero weights / bias, BN scale 1, shift 0 (a padded
+    channel is exactly 0 after ReLU; its pooled mean is 0, its std the 1e-6 floor, and the embedding layer's weights for it are zero)."""
+    for k, s in param_shapes(cfg).items():
+        if k not in weights or tuple(weights[k].shape) != s:
+            raise ValueError(f"x-vector weight {k}: expected shape {s}, got {None if k not in weights else tuple(weights[k].shape)}")
+    pc = cfg.padded_channels()
+    cin_real = (cfg.n_feats,) + cfg.channels[:-1]
+    cin_pad = (cfg.n_feats,) + pc[:-1]
+    d = XVectorDesc()
+    d.n_frame_layers, d.n_feats, d.embed_dim = len(cfg.kernels), cfg.n_feats, cfg.embed_dim
+    d.first_tap_pack = cfg.n_feats if cfg.n_feats % 64 else 0
+    off = [-1] * 64
+    chunks, cur = [], 0
+
+    def put(slot, arr):
+        nonlocal cur
+        a = np.ascontiguousarray(arr)
+        assert off[slot] == -1 and a.dtype in (np.uint16, np.float32)
+        off[slot] = cur
+        chunks.append((cur, a.view(np.uint8).reshape(-1)))
+        cur += (a.nbytes + ALIGN - 1) // ALIGN * ALIGN
+
+    for l in range(len(cfg.kernels)):
+        w = np.zeros((pc[l], cin_pad[l], cfg.kernels[l]), np.float32)
+        w[:cfg.channels[l], :cin_real[l], :] = weights[f"frame{l}.conv.w"]
+        wk = conv_weight_kmajor(w)                                          # bf16 bits [cout, k * cin]
+        if l == 0 and d.first_tap_pack:
+            kp = (wk.shape[1] + 63) // 64 * 64
+            wp = np.zeros((wk.shape[0], kp), np.uint16)
+            wp[:, :wk.shape[1]] = wk
+            wk = wp
+        put(4 * l, wk)
+        b = np.zeros(pc[l], np.float32); b[:cfg.channels[l]] = weights[f"frame{l}.conv.b"]
+        s, sh = bn_affine(weights, f"frame{l}.bn")
+        sp = np.ones(pc[l], np.float32); sp[:cfg.channels[l]] = s
+        shp = np.zeros(pc[l], np.float32); shp[:cfg.channels[l]] = sh
+        put(4 * l + 1, b); put(4 * l + 2, sp); put(4 * l + 3, shp)
+        d.kernel[l], d.dilation[l], d.cin[l], d.cout[l] = cfg.kernels[l], cfg.dilations[l], cin_pad[l], pc[l]
+    cl, cr = pc[-1], cfg.channels[-1]
+    wt = np.zeros((2 * cl, cfg.embed_dim), np.float32)                        # [mean | std] inputs, transposed for rows_fc
+    wt[:cr] = weights["embed.w"][:, :cr].T
+    wt[cl:cl + cr] = weights["embed.w"][:, cr:].T
+    put(60, wt)
+    put(61, weights["embed.b"].astype(np.float32))
+    d.off = (C.c_int64 * 64)(*off)
+    blob = np.zeros(cur, np.uint8)
+    for o, a in chunks:
+        blob[o:o + a.size] = a
+    return blob, d
+
+
+class XVector:
+    """Resident x-vector extractor on an ops.Engine (device blob + descriptor); embed_pcm mirrors Engine.embed_pcm."""
+
+    def __init__(self, engine, weights: Dict[str, np.ndarray] = None, cfg: XVectorConfig = DEFAULT_XVECTOR, seed: int = 0):
+        import torch
+        self.eng, self.cfg = engine, cfg
+        blob, self.desc = pack_weights(weights if weights is not None else synthetic_weights(seed, cfg), cfg)
+        self.blob = torch.from_numpy(blob).to(engine.device)
+
+    def forward(self, feats, B: int, T: int):
+        """feats [B*T, ldf] bf16 (as Engine.fbank writes them) -> raw embeddings [B, embed_dim] fp32."""
+        import torch
+        from ._lib import check
+        from .ops import _stream
+        lib = self.eng.lib
+        ws = self.eng._scratch_bytes("xvector", lib.sdk_xvector_workspace_bytes(C.byref(self.desc), B, T))
+        emb = torch.empty((B, self.cfg.embed_dim), dtype=torch.float32, device=self.eng.device)
+        check(lib.sdk_xvector_forward(self.eng.ctx, self.blob.data_ptr(), C.byref(self.desc), feats.data_ptr(), feats.stride(0), B, T,
+                                      ws.data_ptr(), ws.numel(), emb.data_ptr(), _stream()), "sdk_xvector_forward")
+        return emb
+
+    def embed_pcm(self, pcm):
+        from .ops import num_frames
+        B, S = pcm.shape
+        return self.eng.l2norm(self.forward(self.eng.fbank(pcm), B, num_frames(S)))

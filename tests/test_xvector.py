@@ -1,0 +1,108 @@
+"""The x-vector (plain TDNN) family - north_star: "ECAPA-TDNN/x-vector forward pass".  CPU: the oracle against an independently composed
+torch.nn model (Conv1d with reflect padding, BatchNorm1d.eval()), the packer's padding rules.  GPU: sdk_xvector_forward (one C call:
+sdk_conv_gemm per frame layer - the first with its taps packed along K -, sdk_asp_stats, sdk_rows_fc) against the oracle's bf16 model,
+at the 2-s window (T = 201) and at short / odd lengths, and through fbank -> L2 -> cosine k4 on the shared 192-d back end."""
+import ctypes as C
+
+import numpy as np
+import pytest
+import torch
+
+from conftest import sub
+from oracle import xvector as oxv
+from oracle import ecapa as oecapa
+from oracle import scoring as oscoring
+
+XV = sub("xvector")
+
+
+def test_xvector_oracle_against_torch_nn():
+    cfg = XV.XVectorConfig(channels=(128, 128, 128, 128, 384), embed_dim=64)
+    w = XV.synthetic_weights(3, cfg)
+    feats = torch.randn(2, 60, 80, generator=torch.Generator().manual_seed(1), dtype=torch.float64) * 3
+    x = feats.transpose(1, 2)
+    cin = (80,) + cfg.channels[:-1]
+    with torch.no_grad():
+        for l, (k, dil) in enumerate(zip(cfg.kernels, cfg.dilations)):
+            conv = torch.nn.Conv1d(cin[l], cfg.channels[l], k, dilation=dil, padding=dil * (k - 1) // 2, padding_mode="reflect").double()
+            conv.weight.data = torch.from_numpy(w[f"frame{l}.conv.w"]).double(); conv.bias.data = torch.from_numpy(w[f"frame{l}.conv.b"]).double()
+            bn = torch.nn.BatchNorm1d(cfg.channels[l], eps=1e-5).double().eval()
+            bn.weight.data = torch.from_numpy(w[f"frame{l}.bn.gamma"]).double(); bn.bias.data = torch.from_numpy(w[f"frame{l}.bn.beta"]).double()
+            bn.running_mean.data = torch.from_numpy(w[f"frame{l}.bn.mean"]).double(); bn.running_var.data = torch.from_numpy(w[f"frame{l}.bn.var"]).double()
+            x = bn(torch.relu(conv(x)))
+        stats = torch.cat([x.mean(dim=2), x.std(dim=2, unbiased=False)], dim=1)
+        ref = stats @ torch.from_numpy(w["embed.w"]).double().T + torch.from_numpy(w["embed.b"]).double()
+    got = oxv.xvector_embed(w, feats.float(), cfg.kernels, cfg.dilations, mode="fp32")
+    assert got.shape == (2, 64) and float((got.double() - ref).abs().max()) < 1e-4 * float(ref.abs().max())
+
+
+def test_xvector_packer_pads_channels_and_packs_the_first_layer():
+    WP = sub("weights_pack")
+    cfg = XV.DEFAULT_XVECTOR
+    w = XV.synthetic_weights(1, cfg)
+    blob, d = XV.pack_weights(w, cfg)
+    assert list(d.cout)[:5] == [512, 512, 512, 512, 1536] and d.first_tap_pack == 80 and d.n_frame_layers == 5 and d.embed_dim == 192
+    assert cfg.macs_per_frame() == 80 * 5 * 512 + 2 * 3 * 512 * 512 + 512 * 512 + 512 * 1500
+    w0 = blob[d.off[0]:d.off[0] + 512 * 448 * 2].view(np.uint16).reshape(512, 448)
+    assert not w0[:, 400:].any()
+    assert np.array_equal(w0[:, :400].reshape(512, 5, 80), WP.f32_to_bf16_bits(np.transpose(w["frame0.conv.w"], (0, 2, 1))))
+    w4 = blob[d.off[16]:d.off[16] + 1536 * 512 * 2].view(np.uint16).reshape(1536, 512)
+    assert not w4[1500:].any()                                               # padded output channels: zero weights ...
+    s4 = blob[d.off[18]:d.off[18] + 1536 * 4].view(np.float32)
+    assert (s4[1500:] == 1).all() and not blob[d.off[19]:d.off[19] + 1536 * 4].view(np.float32)[1500:].any()   # ... BN scale 1, shift 0
+    fc = blob[d.off[60]:d.off[60] + 3072 * 192 * 4].view(np.float32).reshape(3072, 192)
+    assert not fc[1500:1536].any() and not fc[3036:].any()                   # the embedding layer ignores the padded statistics
+    assert np.array_equal(fc[:1500], w["embed.w"][:, :1500].T) and np.array_equal(fc[1536:3036], w["embed.w"][:, 1500:].T)
+    with pytest.raises(ValueError):
+        XV.pack_weights({k: v for k, v in w.items() if k != "embed.b"}, cfg)
+
+
+def _cos(a, b):
+    a, b = a.double(), b.double()
+    return (a * b).sum(1) / (a.norm(dim=1) * b.norm(dim=1))
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("B,T", [(4, 201), (3, 50), (2, 301), (1, 9)])
+def test_xvector_forward_matches_oracle(engine, B, T):
+    """Full-size x-vector (512-512-512-512-1500, 192-d embedding) vs the oracle's bf16 layer-boundary model: same tolerance as the
+    ECAPA-TDNN forward (fp32-vs-float64 accumulation and rare last-bit bf16 flips only)."""
+    WP = sub("weights_pack")
+    w = XV.synthetic_weights(0)
+    xv = XV.XVector(engine, w)
+    feats = torch.randn(B, T, 80, generator=torch.Generator().manual_seed(T)) * 3.0
+    f = torch.zeros(B * T, WP.N_MELS_PADDED, dtype=torch.bfloat16)
+    f[:, :80] = feats.reshape(-1, 80).to(torch.bfloat16)
+    f[:, 80:] = 5.0                                                          # must never be read as data (packed taps read 80 wide)
+    emb = xv.forward(f.cuda(), B, T).cpu()
+    torch.cuda.synchronize()
+    want = oxv.xvector_embed(w, feats, mode="bf16")
+    assert (_cos(emb, want) > 1 - 2e-5).all(), _cos(emb, want)
+    assert torch.allclose(emb, want, rtol=0, atol=2e-3 * float(want.abs().max())), float((emb - want).abs().max())
+    assert (_cos(emb, oxv.xvector_embed(w, feats, mode="fp32")) > 0.999).all()
+
+
+@pytest.mark.gpu
+def test_xvector_pcm_to_assignment(engine):
+    """PCM -> fbank -> x-vector -> L2 -> cosine argmax vs profiles: the 192-d embeddings go through the SAME k3 / k4 as the ECAPA ones;
+    IDs identical to and scores within 1e-5 of the exact scan of the GPU's own embeddings; refuses precise mode loudly."""
+    import importlib, sys
+    from conftest import ROOT
+    sys.path.insert(0, str(ROOT))
+    bench = importlib.import_module("bench")
+    xv = XV.XVector(engine, seed=2)
+    pcm = torch.from_numpy(bench.synth_pcm(40, seed=5)).cuda()
+    E, Eb, re = xv.embed_pcm(pcm)
+    assert E.shape == (40, 192) and float((E.double().norm(dim=1) - 1).abs().max()) < 1e-6
+    P = bench.unit_rows(30, 192, seed=6)
+    Pn, Pb, rp = engine.l2norm(torch.from_numpy(P).cuda())
+    idx, sc = engine.affinity_topk(E, Eb, re, Pn, Pb, rp.max().reshape(1), k=1)
+    torch.cuda.synchronize()
+    oidx, osc = oscoring.affinity_topk(E.cpu().numpy(), Pn.cpu().numpy(), 1)
+    assert np.array_equal(idx.cpu().numpy(), oidx) and np.abs(sc.cpu().numpy() - osc).max() <= 1e-5
+    engine.set_precision(1)
+    try:
+        with pytest.raises(sub("_lib").SdkError, match="default .* mode only"):
+            xv.forward(torch.zeros(201, 192, dtype=torch.float16, device="cuda"), 1, 201)
+    finally:
+        engine.set_precision(0)
