@@ -14,6 +14,9 @@ Environment:
   SDK_ECAPA_LAYOUT    "public": SDK_ECAPA_WEIGHTS is a checkpoint in the public ECAPA-TDNN state-dict naming (.ckpt / .pt via
                       torch.load(weights_only=True), .safetensors, .npz); SDK_ECAPA_PREFIX strips a key prefix
   SDK_WINDOW_S / SDK_HOP_S   analysis window / hop in seconds (default 2.0 / 1.0)
+  SDK_PRECISION       0 (default: bf16 operands, scores within ~4e-3 of the fp32 model) / 1 (precise mode: fp16 hi+lo planes, within 1e-5,
+                      ~3.6x the step time).  Both modes embed into the SAME space (they differ from each other at the 4e-3 level), so
+                      model_version does not depend on it
 """
 from __future__ import annotations
 
@@ -104,6 +107,9 @@ class Backend(EmbeddingBackend):
             from .ops import Engine   # imports torch + dlopens libsdk_hip.so; raises SdkError if absent
             dev = int(os.environ.get("SDK_DEVICE", os.environ.get("LOCAL_RANK", "0")))
             self._engine = Engine(dev, cache_key=self._cache_key(), weights_fn=self._host_weights, digest_fn=self._weights_digest)
+            prec = int(os.environ.get("SDK_PRECISION", "0"))
+            if prec:
+                self._engine.set_precision(prec)
         return self._engine
 
     # ---- the GPU path ----------------------------------------------------------------------

@@ -167,10 +167,16 @@ class Engine:
         return y
 
     # ------------------------------------------------------------------ k1
+    def _sync_precision(self) -> None:
+        """The library context is shared by every Engine of a device (one per process and GPU): make it agree with THIS engine's numerical
+        contract before a call whose format depends on it (a host-side store, no device work)."""
+        check(self.lib.sdk_set_option(self.ctx, b"precision", self.precision), "sdk_set_option")
+
     def fbank(self, pcm: torch.Tensor, ldf: Optional[int] = None) -> torch.Tensor:
         """pcm [B, S] int16 (device) -> feats [B*T, ldf] bf16 (channels >= 80 are zero); in precise mode fp16 planes
         [B*T, 2 x 96]: hi values in columns [0, 96), lo values (times 2^11) in [96, 192)."""
         _need(pcm, torch.int16, "pcm")
+        self._sync_precision()
         pcm = pcm.contiguous()
         B, S = pcm.shape
         T = num_frames(S)
@@ -187,6 +193,7 @@ class Engine:
     def ecapa_forward(self, feats: torch.Tensor, B: int, T: int) -> torch.Tensor:
         """feats [B*T, ldf] bf16 (precise mode: fp16 planes) -> raw embeddings [B, 192] fp32."""
         _need(feats, torch.float16 if self.precision == 1 else torch.bfloat16, "feats")
+        self._sync_precision()
         if feats.shape[0] != B * T or feats.stride(1) != 1:
             raise SdkError(f"feats must be [B*T={B * T}, ldf] row-major, got {tuple(feats.shape)}")
         d = self.desc

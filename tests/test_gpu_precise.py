@@ -161,3 +161,26 @@ def test_pcm_to_score_within_1e5_in_precise_mode(precise):
     assert rep["max_abs_dscore_all_pairs"] <= PRECISE_SCORE_BOUND and rep["max_abs_dscore_top1"] <= PRECISE_SCORE_BOUND
     assert rep["id_mismatches"] == 0
     assert rep["min_cos_embedding"] > 1 - 1e-11
+
+
+def test_backend_in_precise_mode_end_to_end(tmp_path, monkeypatch):
+    """SDK_PRECISION=1 through the plug-in API: enroll under the precise mode, identify under both - the two modes embed into the same
+    space (scores differ at the 4e-3 level), so a vector enrolled in one is found by the other."""
+    monkeypatch.setenv("SPEAKERS_EMBEDDINGS_DIR", str(tmp_path))
+    wav, B = sub("wav"), sub("backend")
+    t = np.arange(16000 * 6) / 16000.0
+    rng = np.random.default_rng(1)
+    x = sum((0.5 / h) * np.sin(2 * np.pi * 130.0 * h * t + rng.uniform(0, 6.28)) for h in range(1, 10)) * (0.6 + 0.4 * np.sin(2 * np.pi * 3.1 * t))
+    wav.write_wav_s16(tmp_path / "a.wav", np.clip(np.round(x / np.abs(x).max() * 0.5 * 32767), -32768, 32767).astype(np.int16))
+    monkeypatch.setenv("SDK_PRECISION", "1")
+    be1 = B.Backend()
+    rec = be1.enroll_speaker(tmp_path / "a.wav")
+    cand = [{"id": "a", "embeddings": {"mi355x": [{"id": "emb-a", "external_id": rec["external_id"], "model_version": rec["model_version"]}]}}]
+    rows1 = be1.identify_speaker(tmp_path / "a.wav", cand)
+    assert be1.engine().precision == 1 and rows1 and rows1[0]["speaker_id"] == "a" and rows1[0]["similarity"] > 0.95
+    # (every Backend owns its Engine; the library context they share is re-synchronised per call: ops.Engine._sync_precision)
+    monkeypatch.setenv("SDK_PRECISION", "0")
+    be0 = B.Backend()
+    assert be0.model_version == be1.model_version
+    rows0 = be0.identify_speaker(tmp_path / "a.wav", cand)
+    assert be0.engine().precision == 0 and rows0[0]["speaker_id"] == "a" and abs(rows0[0]["similarity"] - rows1[0]["similarity"]) < 2e-2
