@@ -31,8 +31,9 @@
  * BUILDING BLOCKS AND KNOBS - exported for the parity tests and the A/B tools, free to change between rounds, not for binding:
  *     sdk_conv_gemm*  sdk_colstats_finish  sdk_res2net_chain*  sdk_se_*  sdk_asp_*  sdk_rows_fc  (pieces of sdk_ecapa_forward)
  *     sdk_set_option  sdk_set_gemm_variant  sdk_profile_begin / _end  sdk_debug_set_ptr  sdk_affinity_plan  sdk_affinity_matvec_plan  sdk_conv_gemm_hp
- * k5 (the embedding all-gather) is NOT here by design: the library holds no communicator; the exchange is one
- * torch.distributed all_gather_into_tensor (backend "nccl" = RCCL over xGMI) in the host layer (dist.py).
+ *     sdk_allgather  sdk_laplacian_topk_workspace_bytes  sdk_laplacian_topk        k5 / k6 drivers for a non-Python host (the library holds no
+ *                                                                                     communicator: the caller passes its ncclComm_t; the Python
+ *                                                                                     host layer uses torch.distributed, dist.py / cluster.py)
  */
 #ifndef SDK_HIP_H
 #define SDK_HIP_H
@@ -314,6 +315,22 @@ size_t sdk_affinity_matvec_workspace_bytes(int N);
 int sdk_affinity_matvec_plan(int rows, int N, int num_cu, int32_t* out4, int64_t* units);
 int sdk_affinity_matvec(sdk_ctx* ctx, const uint16_t* Eb, int N, int d, int row0, int rows, const float* X,
                         const float* xscale, int kv, float* Y, void* ws, size_t ws_bytes, void* stream);
+/* ---- k5 / k6 for a non-Python host.  The Python host layer uses torch.distributed for the same collectives (dist.py).
+ *   sdk_allgather       : ONE RCCL all-gather of equal shards (bytes_per_rank each) on the caller's communicator (an ncclComm_t passed as
+ *                         void*) and stream: the [N/G, 192] embedding exchange over xGMI.  RCCL is resolved at first use (the copy already in
+ *                         the process, else librccl.so.1); the library does not link it.
+ *   sdk_laplacian_topk  : top-k eigenpairs of S = D^-1/2 A D^-1/2, A = max(E E^T, 0), by row-sharded subspace iteration (the loop of
+ *                         cluster.spectral_cluster: degrees, CholeskyQR2, n_iter x [V all-gather, recomputed-affinity mat-vec, scaling,
+ *                         CholeskyQR2], Ritz with a device-side k x k Jacobi eigh): never synchronises with the host.
+ *                         Eb_all [N,192] bf16 = ALL embeddings (already gathered); this call owns rows [row0, row0 + rows); V [rows, k] fp32
+ *                         in: any full-rank start block (e.g. seeded gaussian), out: the Ritz vectors (columns = eigenvectors, eigenvalue
+ *                         descending; signs fixed by a deterministic rule on the k x k Ritz eigenvectors); eigvals DEVICE [k]; not_spd as sdk_chol_inverse (sticky, may be NULL).
+ *                         comm NULL: single GPU (rows == N).  comm != NULL: every rank owns N / world rows (equal shards) and calls with the
+ *                         same arguments; collectives: all-gather of D^-1/2 and of V per iteration, all-reduce of the k x k Gram matrices. */
+int sdk_allgather(sdk_ctx* ctx, const void* shard, void* out, size_t bytes_per_rank, void* comm, void* stream);
+size_t sdk_laplacian_topk_workspace_bytes(int N, int k);
+int sdk_laplacian_topk(sdk_ctx* ctx, const uint16_t* Eb_all, int N, int row0, int rows, int k, int n_iter, float* V, float* eigvals,
+                       int32_t* not_spd, void* ws, size_t ws_bytes, void* comm, int world, void* stream);
 size_t sdk_rows_gram_workspace_bytes(int n, int k);
 int sdk_rows_gram(sdk_ctx* ctx, const float* X, const float* Y, int n, int k, float* G, void* ws, size_t ws_bytes, void* stream);
 int sdk_rows_apply(sdk_ctx* ctx, const float* X, const float* R, const float* scale, int n, int k, float* Y, void* stream);

@@ -402,6 +402,22 @@ class Engine:
                                            Y.data_ptr(), ws.data_ptr(), ws.numel(), _stream()), "sdk_affinity_matvec")
         return Y
 
+    def laplacian_topk(self, Eb_all, V0, n_iter: int, row0: int = 0, rows: Optional[int] = None, comm: Optional[int] = None, world: int = 1,
+                       flag: Optional[torch.Tensor] = None):
+        """The C-ABI spectral driver for non-Python hosts (sdk_laplacian_topk): top-k Ritz pairs of D^-1/2 A D^-1/2 by subspace iteration,
+        never leaving the stream.  V0 [rows, k] fp32 start block (not modified) -> (U [rows, k], eigenvalues [k] device, descending).
+        comm: an ncclComm_t as an integer (or None on one GPU)."""
+        _need(Eb_all, torch.bfloat16, "Eb_all"); _need(V0, torch.float32, "V0")
+        N = Eb_all.shape[0]
+        rows = N - row0 if rows is None else rows
+        k = V0.shape[1]
+        V = V0.contiguous().clone()
+        lam = torch.empty((k,), dtype=torch.float32, device=self.device)
+        ws = self._scratch_bytes("laplacian", self.lib.sdk_laplacian_topk_workspace_bytes(N, k))
+        check(self.lib.sdk_laplacian_topk(self.ctx, Eb_all.data_ptr(), N, row0, rows, k, n_iter, V.data_ptr(), lam.data_ptr(), _ptr(flag), ws.data_ptr(),
+                                          ws.numel(), comm, world, _stream()), "sdk_laplacian_topk")
+        return V, lam
+
     def rows_gram(self, X, Y):
         n, k = X.shape
         G = torch.empty((k, k), dtype=torch.float32, device=self.device)

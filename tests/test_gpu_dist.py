@@ -139,3 +139,58 @@ def test_rccl_single_rank(tmp_path):
     assert rep["backend"] == "nccl" and rep["nccl_version"][0] >= 2
     assert rep["gather_into_equal"] and rep["gather_rows_equal"] and rep["all_reduce_equal"]
     assert rep["labels_equal"] and rep["eigs_equal"] and rep["ari_truth"] == 1.0
+
+
+def _c_abi_rccl_worker(rank, world, port, out_dir):
+    """sdk_allgather / sdk_laplacian_topk on a communicator this process creates with RCCL's own C API (ctypes) - what a non-Python host does."""
+    import ctypes as C
+    import importlib
+    import json
+    import sys
+    sys.path.insert(0, str(ROOT))
+    os.environ["HSA_ENABLE_IPC_MODE_LEGACY"] = "0"
+    torch.cuda.set_device(0)
+    eng = importlib.import_module(f"{PKG}.ops").get_engine(0)
+    _lib = importlib.import_module(f"{PKG}._lib")
+    from oracle import spectral as ospec
+    rccl = C.CDLL("librccl.so.1")
+
+    class UniqueId(C.Structure):
+        _fields_ = [("internal", C.c_char * 128)]
+    uid = UniqueId()
+    assert rccl.ncclGetUniqueId(C.byref(uid)) == 0
+    comm = C.c_void_p()
+    rccl.ncclCommInitRank.argtypes = [C.POINTER(C.c_void_p), C.c_int, UniqueId, C.c_int]
+    assert rccl.ncclCommInitRank(C.byref(comm), 1, uid, 0) == 0
+    st = torch.cuda.current_stream().cuda_stream
+    rep = {}
+    x = torch.randn(1000, 192, device="cuda", generator=torch.Generator(device="cuda").manual_seed(3))
+    out = torch.zeros_like(x)
+    _lib.check(eng.lib.sdk_allgather(eng.ctx, x.data_ptr(), out.data_ptr(), x.numel() * 4, comm, st), "sdk_allgather")
+    torch.cuda.synchronize()
+    rep["allgather_equal"] = bool(torch.equal(out, x))
+    rep["allgather_null_comm_refused"] = eng.lib.sdk_allgather(eng.ctx, x.data_ptr(), out.data_ptr(), x.numel() * 4, None, st) != 0
+    N, k = 1536, 5
+    E, _ = ospec.vmf_mixture(N, 192, k, seed=4, noise=0.6)
+    _, Eb, _ = eng.l2norm(torch.from_numpy(E).cuda())
+    V0 = torch.from_numpy(np.random.default_rng(0).standard_normal((N, k)).astype(np.float32)).cuda()
+    U0, l0 = eng.laplacian_topk(Eb, V0, 12)
+    U1, l1 = eng.laplacian_topk(Eb, V0, 12, comm=comm.value, world=1)                   # every collective through RCCL
+    torch.cuda.synchronize()
+    rep["laplacian_equal"] = bool(torch.equal(U0, U1) and torch.equal(l0, l1))
+    rep["eigs"] = [round(float(v), 5) for v in l1.cpu()]
+    rccl.ncclCommDestroy.argtypes = [C.c_void_p]
+    rccl.ncclCommDestroy(comm)
+    with open(os.path.join(out_dir, "cabi.json"), "w") as f:
+        json.dump(rep, f)
+
+
+def test_c_abi_collectives_on_a_raw_rccl_communicator(tmp_path):
+    """SURVEY 8b's sdk_allgather / sdk_laplacian_topk exports: a spawned child creates a one-rank communicator with RCCL's C API and hands the
+    ncclComm_t to the library - the path a Go / C++ host would take (the Python host uses torch.distributed, tested above)."""
+    import json
+    mp.spawn(_c_abi_rccl_worker, args=(1, _free_port(), str(tmp_path)), nprocs=1, join=True)
+    rep = json.loads((tmp_path / "cabi.json").read_text())
+    print("\nC-ABI collectives on a raw RCCL communicator:", rep)
+    assert rep["allgather_equal"] and rep["allgather_null_comm_refused"] and rep["laplacian_equal"]
+    assert rep["eigs"][0] > 0.99 and all(a >= b for a, b in zip(rep["eigs"], rep["eigs"][1:]))

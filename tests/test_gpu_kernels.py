@@ -563,6 +563,36 @@ def test_spectral_cluster_raises_when_k_exceeds_the_rank(engine):
 
 
 @pytest.mark.parametrize("N,k", [(2000, 6), (5000, 16)])
+def test_laplacian_topk_c_driver_matches_the_host_driver(engine, N, k):
+    """sdk_laplacian_topk (the k6 driver a non-Python host binds) runs cluster.spectral_cluster's subspace iteration in ONE C call
+    with a device-side Ritz step.  Same seeded start block -> the same eigenvalues (1e-5), the same invariant subspace (projector difference
+    ~1e-4), and - fed to the exported k-means primitives exactly as cluster.py does - the same integer labels as the oracle."""
+    E, truth = ospec.vmf_mixture(N, 192, k, seed=N + k, noise=0.6)
+    En, Eb, _ = engine.l2norm(dev(E))
+    res = CL.spectral_cluster(engine, En, Eb, N, k, n_iter=25, n_kmeans=20, seed=0)
+    V0 = dev(np.random.default_rng(0).standard_normal((N, k)).astype(np.float32))
+    flag = torch.zeros(1, dtype=torch.int32, device="cuda")
+    U, lam = engine.laplacian_topk(Eb, V0, 25, flag=flag)
+    torch.cuda.synchronize()
+    assert int(flag.item()) == 0
+    lam = lam.cpu().numpy()
+    assert np.all(np.diff(lam) <= 1e-7) and np.abs(lam - res.eigenvalues).max() < 1e-5, (lam, res.eigenvalues)
+    Ud = U.double().cpu()
+    assert float((Ud.T @ Ud - torch.eye(k, dtype=torch.float64)).abs().max()) < 1e-4          # orthonormal Ritz vectors
+    # k-means on the driver's rows, through cluster.py's own (exported-primitive) routine: labels of the oracle
+    R = engine.rows_unit(U)
+    lab = CL.canonical_labels(CL._kmeans(engine, CL._Comm(None), R, 0, N, k, 20).cpu().numpy())
+    olab, _ = ospec.spectral_cluster(Eb.float().cpu().numpy(), k, n_iter=25, n_kmeans=20, seed=0)
+    assert np.array_equal(lab, olab) and np.array_equal(lab, res.labels)
+    # k greater than the rank: the sticky flag, no exception, no hang
+    base = _unit(3, 192, 5)
+    _, Eb3, _ = engine.l2norm(dev(np.repeat(base, 100, axis=0)))
+    flag.zero_()
+    engine.laplacian_topk(Eb3, dev(np.random.default_rng(1).standard_normal((300, 6)).astype(np.float32)), 4, flag=flag)
+    assert int(flag.item()) == 1
+
+
+@pytest.mark.parametrize("N,k", [(2000, 6), (5000, 16)])
 def test_spectral_cluster_matches_oracle(engine, N, k):
     """Config #5 scaled down: mixture-of-clusters embeddings, GPU pipeline vs the CPU oracle run on the
     same bf16-rounded rows.  Integer labels must be identical (canonical order of first appearance)."""
