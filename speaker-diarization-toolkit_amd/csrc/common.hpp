@@ -41,6 +41,7 @@ struct sdk_ctx {
   int aff_whole_groups = 0;       // A/B knob: allow "one whole group per workgroup" when sweeps are short (affinity_rowcol.hip plan_geometry).
                                   // Off: at config #3 it takes 2.3 us off the coarse pass (49.0 -> 46.7) and adds 3.8 us to the rescan (one part per
                                   // group = a weaker certificate: 202 instead of 88 uncertain rows), 87.2 vs 84.9 us end to end
+  int hp_gemm_variant = 0;        // A/B + test knob: 1 = the precise mode's GEMM always as the 128^2 register-staged kernel
   int matvec_variant = 0;         // A/B + test knob: 1 = round 1's affinity_matvec_kernel (one 32-row block per wave, a barrier per tile)
   int aff_variant = 0;            // A/B knob: workgroup shape of the row/column kernel (see affinity_rowcol.hip)
   std::vector<const void*> lds_optin;   // kernels of THIS context's device already opted in to > 64 KiB dynamic LDS

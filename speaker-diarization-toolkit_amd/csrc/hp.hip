@@ -225,6 +225,312 @@ __global__ __launch_bounds__(NT, 2) void conv_gemm_hp_kernel(HpParams p) {
   }
 }
 
+// ================================================================================================ the same GEMM as a 256 x 256 LDS-DMA tile
+// The big layers of the precise forward (blk0, the six 1024^2 TDNN layers, the 3072^2 MFA layer: 86 % of its flops) in the structure of
+// conv_gemm256_kernel (conv_gemm.hip): 8 waves (2 x 4, 128 x 64 each), persistent workgroups in the unit tile order, operands by LDS-DMA
+// into two 64-KiB stages, counted waits, one raw barrier per K-step placed before the last MFMA sub-phase, epilogue in registers.
+// What differs: a K-step is 32 REAL k; an LDS row (128 B) holds [hi 32 k | lo 32 k] of one tile row, so the 16-byte chunks 0-3 / 4-7 of a
+// row come from the hi / lo plane (per-lane DMA source address) and the fragment read at chunk offset c0 / c1 is the hi / lo fragment;
+// six MFMA sub-phases of 32 per K-step:  Ah.Wh (both row halves), Al.(Wh 2^-11) (Wh is scaled IN PLACE once its last use has issued),
+// Ah.Wl (the hi fragments are read from LDS a second time: cheaper than 32 more live registers);  the epilogue keeps the fp32 results in
+// the accumulators and sends first the hi plane, then the lo plane through the bf16-sized tile image.  Plain planes output only
+// (bias / ReLU / BN affine); fp32 / residual-sum / per-segment-bias / tanh outputs stay with the 128^2 kernel above.
+constexpr int BM2 = 256, BN2 = 256, NT2 = 512;
+constexpr int HSTAGE = (BM2 + BN2) * 128;            // 65536
+constexpr int HLDS = 2 * HSTAGE;                     // 131072 = one fp16 plane image of a finished tile
+constexpr int HLDS_TOTAL = HLDS + 3 * BN2 * 4;
+static_assert(BM2 * BN2 * 2 <= HLDS, "a plane image of the tile must fit in the two pipeline stages");
+
+typedef const void __attribute__((address_space(1)))* gptr_t;
+typedef void __attribute__((address_space(3)))* lptr_t;
+
+template <bool TAPS>
+__global__ __launch_bounds__(NT2, 2) void conv_gemm_hp256_kernel(HpParams p) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
+  const int wm = wid >> 2, wn = wid & 3;
+  const int nbn = p.N / BN2, nbm = (p.M + BM2 - 1) / BM2, ntiles = nbn * nbm;
+  const int Ktot = p.taps * p.Cin;
+  const int ksteps_per_tap = p.Cin / BK;
+  const int nk = p.taps * ksteps_per_tap;
+  const int half = p.taps >> 1;
+
+  // tile schedule: units of 8 m-tiles x 4 n-tiles = the 32 workgroups of one XCD per round (conv_gemm256_kernel: every A block is fetched
+  // into one L2 once); other shapes: XCD-contiguous runs in groups of 8 m-tiles
+  const int G = gridDim.x;
+  const bool unit_order = G == 256 && (nbn & 3) == 0 && nbm >= 64;
+  const int xcd = blockIdx.x & 7, slot = blockIdx.x >> 3;
+  const int nch = nbn >> 2, mg_full = nbm >> 3;
+  const int full_units = mg_full * nch, R = full_units >> 3, rem_units = full_units - 8 * R;
+  const int gm_tail = nbm & 7, tail_tiles = gm_tail * nbn;
+  const int nrounds = unit_order ? R + (rem_units + (tail_tiles + 31) / 32 + 7) / 8 : (ntiles + G - 1) / G;
+  auto tile_coords = [&](int i, int& tm0, int& tn0) -> bool {
+    if (unit_order) {
+      int u;
+      if (i < R) {
+        u = xcd * R + i;
+      } else {
+        const int q = (i - R) * 8 + xcd;
+        if (q >= rem_units) {
+          const int pj = (q - rem_units) * 32 + slot;
+          if (pj >= tail_tiles) return false;
+          tm0 = (mg_full * 8 + pj % gm_tail) * BM2;
+          tn0 = (pj / gm_tail) * BN2;
+          return true;
+        }
+        u = 8 * R + q;
+      }
+      const int mg = u / nch, ch = u - mg * nch;
+      tm0 = (mg * 8 + (slot & 7)) * BM2;
+      tn0 = (ch * 4 + (slot >> 3)) * BN2;
+      return true;
+    }
+    const int vt = blockIdx.x + G * i;
+    if (vt >= ntiles) return false;
+    const int tile = xcd_remap(vt, ntiles);
+    constexpr int GM = 8;
+    const int per_group = GM * nbn;
+    const int grp = tile / per_group, in_grp = tile - grp * per_group;
+    const int gm = min(nbm - grp * GM, GM);
+    tm0 = (grp * GM + in_grp % gm) * BM2;
+    tn0 = (in_grp / gm) * BN2;
+    return true;
+  };
+
+  // DMA assignment: wave w fills rows [32 w, 32 w + 32) of A and of W, 8 rows per wave-instruction.  Lane (rin = row in the piece, pos = chunk
+  // position in the 128-byte LDS row) fetches source chunk pos ^ rin (the swizzle lives on the source side): chunks 0-3 = hi plane, 4-7 = lo plane
+  const int rin = lane >> 3, pos = lane & 7;
+  const int sch = pos ^ rin;
+  const uint32_t kch = (uint32_t)(sch & 3) * 8u;                           // element offset of the chunk inside the 32-wide K-step
+  const uint32_t a_pl = (sch & 4) ? (uint32_t)p.a_lo : 0u;                 // plane offsets (elements)
+  const uint32_t w_pl = (sch & 4) ? (uint32_t)p.N * (uint32_t)Ktot : 0u;   // (the host checks 2 planes x N x Ktot x 2 B < 2^32)
+  const int wu = __builtin_amdgcn_readfirstlane(wid);
+  // !TAPS: ONE per-lane byte offset (row of piece 0); pieces 1-3 are 8, 16, 24 rows further = a scalar stride on the uniform base.  Only a
+  // tile that reaches past row M (the last m-tile) clamps per row, recomputed per K-step there (four 64-bit offset pairs live across the
+  // K loop cost the registers the loop does not have: a scratch reload + vmcnt(0) in front of every DMA issue)
+  uint32_t aoff0 = 0;
+  int arow0 = 0;
+  bool interior = true;
+  int aseg0 = 0, atl0 = 0;
+  uint32_t woff;
+  const size_t astride = (size_t)8 * (size_t)p.lda * 2u;
+  auto setup_dma = [&](int tm0, int tn0) {
+    const int row = 32 * wu + rin;
+    if constexpr (TAPS) {
+      const int mm = min(tm0 + row, p.M - 1);
+      aseg0 = (mm / p.T) * p.T;
+      atl0 = mm - aseg0;
+    } else {
+      arow0 = tm0 + row;
+      interior = tm0 + BM2 <= p.M;
+      aoff0 = ((uint32_t)min(arow0, p.M - 1) * (uint32_t)p.lda + kch + a_pl) * 2u;
+    }
+    woff = ((uint32_t)(tn0 + row) * (uint32_t)Ktot + kch + w_pl) * 2u;
+  };
+  auto issue = [&](int t, int stage) {
+    const int j = t / ksteps_per_tap;
+    const int kc = (t - j * ksteps_per_tap) * BK;
+    char* sA = smem + stage * HSTAGE + (32 * wu) * 128;
+    char* sB = sA + BM2 * 128;
+    const char* abase = reinterpret_cast<const char*>(p.A + kc);
+    if constexpr (TAPS) {
+      const int off = (j - half) * p.dil;
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        int tl = atl0 + 8 * i, sb = aseg0;
+        if (tl >= p.T) { tl -= p.T; sb += p.T; }
+        const uint32_t src = (uint32_t)min(sb + reflect_idx(tl + off, p.T), p.M - 1);
+        __builtin_amdgcn_global_load_lds((gptr_t)(abase + (size_t)((src * (uint32_t)p.lda + kch + a_pl) * 2u)), (lptr_t)(sA + i * 1024), 16, 0, 0);
+      }
+    } else if (interior) {
+#pragma unroll
+      for (int i = 0; i < 4; ++i)
+        __builtin_amdgcn_global_load_lds((gptr_t)(abase + i * astride + (size_t)aoff0), (lptr_t)(sA + i * 1024), 16, 0, 0);
+    } else {
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        const uint32_t o = ((uint32_t)min(arow0 + 8 * i, p.M - 1) * (uint32_t)p.lda + kch + a_pl) * 2u;
+        __builtin_amdgcn_global_load_lds((gptr_t)(abase + (size_t)o), (lptr_t)(sA + i * 1024), 16, 0, 0);
+      }
+    }
+    const char* wbase = reinterpret_cast<const char*>(p.W + (j * p.Cin + kc));
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+      __builtin_amdgcn_global_load_lds((gptr_t)(wbase + (size_t)i * 16 * Ktot + (size_t)woff), (lptr_t)(sB + i * 1024), 16, 0, 0);
+  };
+
+  const int fr = lane & 15, fq = lane >> 4, sw = lane & 7;
+  const uint32_t a_base = (wm * 128 + fr) * 128;
+  const uint32_t b_base = BM2 * 128 + (wn * 64 + fr) * 128;
+  const uint32_t c0 = ((0 * 4 + fq) ^ sw) << 4, c1 = ((1 * 4 + fq) ^ sw) << 4;       // hi / lo fragment of the row
+  const bool dma_early = wu < 4;
+  const bool relu = p.flags & SDK_GEMM_RELU;
+  const float winv = *p.winv;
+  float* par = reinterpret_cast<float*>(smem + HLDS);
+
+  for (int rnd = 0; rnd < nrounds; ++rnd) {
+    int m0, n0;
+    if (!tile_coords(rnd, m0, n0)) continue;
+    setup_dma(m0, n0);
+    float pb = 0.f, psc = 1.f, psh = 0.f;
+    if (tid < BN2) {
+      if (p.bias) pb = p.bias[n0 + tid];
+      if (p.scale) { psc = p.scale[n0 + tid]; psh = p.shift[n0 + tid]; }
+    }
+    f32x4 acc[8][4];
+#pragma unroll
+    for (int mi = 0; mi < 8; ++mi)
+#pragma unroll
+      for (int ni = 0; ni < 4; ++ni) acc[mi][ni] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+    f16x8 b0[4], b1[4], a0[4], a1[4];
+    auto ldB = [&](const char* st, f16x8* dst, uint32_t coff) {
+#pragma unroll
+      for (int ni = 0; ni < 4; ++ni) dst[ni] = *reinterpret_cast<const f16x8*>(st + b_base + ni * 2048 + coff);
+    };
+    auto ldA = [&](const char* st, f16x8* dst, int mh, uint32_t coff) {
+#pragma unroll
+      for (int mi = 0; mi < 4; ++mi) dst[mi] = *reinterpret_cast<const f16x8*>(st + a_base + (mh * 4 + mi) * 2048 + coff);
+    };
+    // the WEIGHT fragment is the MFMA's row operand: a lane holds 4 CONSECUTIVE output columns of one output row
+    auto mma_half = [&](const f16x8* af, const f16x8* bf, int mh, int part) {
+      __builtin_amdgcn_s_setprio(1);
+#pragma unroll
+      for (int mi = 2 * part; mi < 2 * part + 2; ++mi)
+#pragma unroll
+        for (int ni = 0; ni < 4; ++ni)
+          acc[mh * 4 + mi][ni] = __builtin_amdgcn_mfma_f32_16x16x32_f16(bf[ni], af[mi], acc[mh * 4 + mi][ni], 0, 0, 0);
+      __builtin_amdgcn_s_setprio(0);
+    };
+
+    issue(0, 0);
+    if (nk > 1) {
+      issue(1, 1);
+      asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+    } else {
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    }
+    if (tid < BN2) { par[tid] = pb; par[BN2 + tid] = psc; par[2 * BN2 + tid] = psh; }
+    __builtin_amdgcn_s_barrier();
+    ldB(smem, b0, c0);
+    ldA(smem, a0, 0, c0);
+    for (int t = 0; t < nk; ++t) {
+      const char* st = smem + (t & 1) * HSTAGE;
+      __builtin_amdgcn_sched_barrier(0);
+      mma_half(a0, b0, 0, 0);                           // P0: Ah[0] . Wh
+      __builtin_amdgcn_sched_barrier(0);
+      ldA(st, a1, 1, c0);
+      __builtin_amdgcn_sched_barrier(0);
+      mma_half(a0, b0, 0, 1);
+      __builtin_amdgcn_sched_barrier(0);
+      mma_half(a1, b0, 1, 0);                           // P1: Ah[1] . Wh
+      __builtin_amdgcn_sched_barrier(0);
+      ldB(st, b1, c1);
+      ldA(st, a0, 0, c1);
+      __builtin_amdgcn_sched_barrier(0);
+      mma_half(a1, b0, 1, 1);
+      __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+      for (int ni = 0; ni < 4; ++ni) b0[ni] = b0[ni] * (_Float16)(1.0f / HP_LOSCALE);     // Wh -> Wh 2^-11 in place (exact)
+      __builtin_amdgcn_sched_barrier(0);
+      mma_half(a0, b0, 0, 0);                           // P2: Al[0] . Wh 2^-11
+      __builtin_amdgcn_sched_barrier(0);
+      ldA(st, a1, 1, c1);
+      __builtin_amdgcn_sched_barrier(0);
+      mma_half(a0, b0, 0, 1);
+      __builtin_amdgcn_sched_barrier(0);
+      mma_half(a1, b0, 1, 0);                           // P3: Al[1] . Wh 2^-11
+      __builtin_amdgcn_sched_barrier(0);
+      ldA(st, a0, 0, c0);                               // the hi fragments once more, for the W lo term
+      __builtin_amdgcn_sched_barrier(0);
+      mma_half(a1, b0, 1, 1);
+      __builtin_amdgcn_sched_barrier(0);
+      mma_half(a0, b1, 0, 0);                           // P4: Ah[0] . Wl
+      __builtin_amdgcn_sched_barrier(0);
+      ldA(st, a1, 1, c0);
+      __builtin_amdgcn_sched_barrier(0);
+      mma_half(a0, b1, 0, 1);
+      __builtin_amdgcn_sched_barrier(0);
+      if (t + 1 < nk) {
+        asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");     // own reads of this stage done, own DMA of step t + 1 landed
+        __builtin_amdgcn_s_barrier();
+        if (dma_early && t + 2 < nk) issue(t + 2, t & 1);
+        const char* sn = smem + ((t + 1) & 1) * HSTAGE;
+        ldB(sn, b0, c0);
+        ldA(sn, a0, 0, c0);
+      }
+      __builtin_amdgcn_sched_barrier(0);
+      mma_half(a1, b1, 1, 0);                           // P5: Ah[1] . Wl
+      mma_half(a1, b1, 1, 1);
+      __builtin_amdgcn_sched_barrier(0);
+      if (!dma_early && t + 2 < nk) issue(t + 2, t & 1);
+    }
+
+    // ------------------------------------------------------------------ epilogue: fp32 in the accumulators, hi plane then lo plane through the image
+    f32x4 qb[4], qs[4], qt[4];
+#pragma unroll
+    for (int ni = 0; ni < 4; ++ni) {
+      const int c = wn * 64 + ni * 16 + fq * 4;
+      qb[ni] = *reinterpret_cast<const f32x4*>(par + c);
+      qs[ni] = *reinterpret_cast<const f32x4*>(par + BN2 + c);
+      qt[ni] = *reinterpret_cast<const f32x4*>(par + 2 * BN2 + c);
+    }
+#pragma unroll
+    for (int mi = 0; mi < 8; ++mi)
+#pragma unroll
+      for (int ni = 0; ni < 4; ++ni) {
+        f32x4 v = acc[mi][ni] * winv + qb[ni];
+        if (relu) {
+#pragma unroll
+          for (int e = 0; e < 4; ++e) v[e] = fmaxf(v[e], 0.f);
+        }
+        v = v * qs[ni] + qt[ni];
+#pragma unroll
+        for (int e = 0; e < 4; ++e) v[e] = fminf(fmaxf(v[e], -HP_MAX), HP_MAX);
+        acc[mi][ni] = v;
+      }
+#pragma unroll
+    for (int plane = 0; plane < 2; ++plane) {
+      lds_barrier();                                    // every wave is done with the last stage / with the previous plane's image
+#pragma unroll
+      for (int mi = 0; mi < 8; ++mi) {
+        const int row = wm * 128 + mi * 16 + fr;
+        char* rowp = smem + row * (BN2 * 2);
+#pragma unroll
+        for (int ni = 0; ni < 4; ++ni) {
+          const f32x4 v = acc[mi][ni];
+          _Float16 h[4];
+#pragma unroll
+          for (int e = 0; e < 4; ++e) {
+            const _Float16 hi = (_Float16)v[e];
+            h[e] = plane == 0 ? hi : (_Float16)((v[e] - (float)hi) * HP_LOSCALE);
+          }
+          uint2 pk;
+          pk.x = (uint32_t)__builtin_bit_cast(uint16_t, h[0]) | ((uint32_t)__builtin_bit_cast(uint16_t, h[1]) << 16);
+          pk.y = (uint32_t)__builtin_bit_cast(uint16_t, h[2]) | ((uint32_t)__builtin_bit_cast(uint16_t, h[3]) << 16);
+          const int u8 = (wn * 16 + ni * 4 + fq) ^ (fr << 1);
+          *reinterpret_cast<uint2*>(rowp + u8 * 8) = pk;
+        }
+      }
+      lds_barrier();
+      {
+        const int r0 = tid >> 5, cc = tid & 31;
+        const char* src = smem + r0 * (BN2 * 2) + ((cc ^ (r0 & 15)) << 4);
+        uint16_t* dst = p.C + (int64_t)(m0 + r0) * p.ldc + n0 + cc * 8 + (plane ? p.c_lo : 0);
+        const int rows_left = p.M - m0 - r0;
+#pragma unroll
+        for (int i = 0; i < 16; ++i) {
+          if (16 * i < rows_left) {
+            const u32x4 v = *reinterpret_cast<const u32x4*>(src + i * 16 * (BN2 * 2));
+            __builtin_nontemporal_store(v, reinterpret_cast<u32x4*>(dst + (int64_t)(16 * i) * p.ldc));
+          }
+        }
+      }
+    }
+    lds_barrier();                                      // the image is free: the next tile's DMA may overwrite it
+  }
+}
+
 // ================================================================================================ sweeps (HBM-bound, planes in / out)
 // per-segment channel means of z (SE squeeze): grid (B, C / 512), 256 threads = 64 chunk-columns x 4 frame groups
 __global__ __launch_bounds__(256) void seg_mean_hp_kernel(const uint16_t* __restrict__ z, int64_t ldz, int64_t z_lo, int T, int C,
@@ -354,6 +660,8 @@ extern "C" int sdk_conv_gemm_hp(sdk_ctx* ctx, const sdk_conv_gemm_hp_args* a, vo
   if (a->C32) SDK_REQUIRE(a->ldc32 >= a->N && a->ldc32 % 4 == 0 && ((uintptr_t)a->C32 % 16) == 0, "sdk_conv_gemm_hp: bad C32");
   if (a->ubias) SDK_REQUIRE(a->ldub >= a->N, "sdk_conv_gemm_hp: bad ldub");
   if (sdk_lds_optin(ctx, (const void*)conv_gemm_hp_kernel, LDS_BYTES)) return 1;
+  if (sdk_lds_optin(ctx, (const void*)conv_gemm_hp256_kernel<false>, HLDS_TOTAL)) return 1;
+  if (sdk_lds_optin(ctx, (const void*)conv_gemm_hp256_kernel<true>, HLDS_TOTAL)) return 1;
   HpParams p;
   p.A = a->A; p.lda = a->lda; p.a_lo = a->a_lo; p.W = a->W + HP_WHDR; p.winv = reinterpret_cast<const float*>(a->W);
   p.C = a->C; p.ldc = a->ldc; p.c_lo = a->c_lo; p.C32 = a->C32; p.ldc32 = a->ldc32;
@@ -363,7 +671,18 @@ extern "C" int sdk_conv_gemm_hp(sdk_ctx* ctx, const sdk_conv_gemm_hp_args* a, vo
   const double kk = (double)a->taps * a->Cin;
   ProfScope ps(ctx, stream, SDK_K_CONV_GEMM_HP, 3 * 2.0 * a->M * a->N * kk,
                4.0 * a->M * a->Cin + 4.0 * a->N * kk + (a->C ? 4.0 : 0.0) * a->M * a->N + (a->C32 ? 4.0 : 0.0) * a->M * a->N + (a->S ? 8.0 : 0.0) * a->M * a->N);
-  hipLaunchKernelGGL(conv_gemm_hp_kernel, dim3((a->N / BN) * ceil_div(a->M, BM)), dim3(NT), LDS_BYTES, (hipStream_t)stream, p);
+  // the 256^2 LDS-DMA kernel takes the plain layer shape (planes out, bias / ReLU / BN affine); it addresses A by 32-bit byte offsets
+  const bool use256 = ctx->hp_gemm_variant != 1 && a->N % BN2 == 0 && a->M >= BM2 && a->C && !a->C32 && !a->S && !a->ubias && !(a->flags & SDK_GEMM_TANH) &&
+                      (a->taps == 1 || a->T >= 64) && (uint64_t)a->M * (uint64_t)a->lda * 2u < (1ull << 32) &&
+                      (!a->bias || ((uintptr_t)a->bias % 16) == 0) && (!a->scale || (a->shift && (((uintptr_t)a->scale | (uintptr_t)a->shift) % 16) == 0));
+  if (use256) {
+    const int ntiles = (a->N / BN2) * ceil_div(a->M, BM2);
+    const int cus = ctx->num_cu > 0 ? (ctx->num_cu / 8) * 8 : 256;
+    const int grid = ntiles < cus ? ntiles : cus;
+    hipLaunchKernelGGL(a->taps > 1 ? conv_gemm_hp256_kernel<true> : conv_gemm_hp256_kernel<false>, dim3(grid), dim3(NT2), HLDS_TOTAL, (hipStream_t)stream, p);
+  } else {
+    hipLaunchKernelGGL(conv_gemm_hp_kernel, dim3((a->N / BN) * ceil_div(a->M, BM)), dim3(NT), LDS_BYTES, (hipStream_t)stream, p);
+  }
   SDK_LAUNCH_CHECK();
   return 0;
 }

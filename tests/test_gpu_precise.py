@@ -74,6 +74,45 @@ def test_conv_gemm_hp_matches_float64(precise, M, T, N, Cin, taps, dil, scale_a,
     assert float((back - C32.cpu()).abs().max()) <= 2.0 ** -21 * float(C32.abs().max())
 
 
+@pytest.mark.parametrize("M,T,N,Cin,taps,dil", [
+    (1005, 201, 1024, 96, 5, 1),          # blk0: taps, 15 K-steps of 32, partial last m-tile (the per-row clamp path)
+    (2010, 201, 1024, 1024, 1, 1),        # a TDNN layer: 8 m-tiles x 4 n-tiles
+    (515, 515, 256, 3072, 1, 1),          # long K, M = 2 tiles + 3 rows
+    (256, 256, 512, 64, 1, 1),            # two K-steps: prologue / last-step paths only
+    (768, 256, 256, 32, 1, 1),            # a single K-step
+    (603, 201, 256, 128, 3, 2),           # dilated taps across segment boundaries inside a tile
+])
+def test_conv_gemm_hp_256_tile_kernel(precise, M, T, N, Cin, taps, dil):
+    """The precise mode's big layers run on a 256 x 256 LDS-DMA tile (conv_gemm_hp256_kernel: hi | lo halves of a 128-byte LDS row, six MFMA
+    sub-phases per 32-wide K-step, hi then lo plane through the tile image).  Planes out vs float64 on the values the planes hold, and
+    against the 128^2 register-staged kernel (knob hp_gemm_variant 1) on the same operands."""
+    eng = precise
+    g = torch.Generator().manual_seed(M + N + Cin + taps)
+    a = torch.randn(M, Cin, generator=g) * 2.0
+    w = torch.randn(N, taps * Cin, generator=g) * 0.04
+    bias, sc, sh = torch.randn(N, generator=g), torch.rand(N, generator=g) + 0.5, torch.randn(N, generator=g)
+    Ap = OPS.Engine.to_planes(a)
+    slot = WP.hp_weight_planes(w.numpy())
+    Wd = torch.from_numpy(slot.view(np.int16)).cuda()
+    dv = lambda t: t.cuda()
+    out = {}
+    for variant in (0, 1):
+        eng.set_option("hp_gemm_variant", variant)
+        try:
+            Cp, _, _ = eng.conv_gemm_hp(dv(Ap), Wd, N, Cin, taps=taps, dil=dil, T=T, bias=dv(bias), scale=dv(sc), shift=dv(sh), relu=True)
+            torch.cuda.synchronize()
+        finally:
+            eng.set_option("hp_gemm_variant", 0)
+        out[variant] = OPS.Engine.from_planes(Cp.cpu()).double()
+    pre, mag = _conv_ref64(OPS.Engine.from_planes(Ap), torch.from_numpy(WP.hp_planes_to_f64(slot, N, taps * Cin)), Cin, taps, dil, T)
+    want = torch.relu(pre + bias.double()) * sc.double() + sh.double()
+    tol = 1.5e-6 * mag * sc.double() + 2.0 ** -21 * want.abs() + 1e-7
+    for variant in (0, 1):
+        err = (out[variant] - want).abs()
+        assert (err <= tol).all(), (variant, float((err / tol).max()), float(err.max()))
+    assert float((out[0] - out[1]).abs().max()) <= 3e-6 * float(want.abs().max())
+
+
 def test_conv_gemm_hp_epilogue_and_residual_sum(precise):
     eng = precise
     M, T, N, Cin = 402, 201, 128, 128
