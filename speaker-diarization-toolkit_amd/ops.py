@@ -109,7 +109,11 @@ class Engine:
                     d.off = (C.c_int64 * 256)(*v)
                 else:
                     setattr(d, k, v)
-            self._packed[self.precision] = (torch.from_numpy(np.asarray(blob)).to(self.device), d)
+            import warnings
+            with warnings.catch_warnings():          # a cache hit is a read-only memory map: it is only read (uploaded) here
+                warnings.simplefilter("ignore", UserWarning)
+                host = torch.from_numpy(np.asarray(blob))
+            self._packed[self.precision] = (host.to(self.device), d)
         self._wblob, self._desc = self._packed[self.precision]
 
     def set_precision(self, precision: int) -> None:
