@@ -70,7 +70,7 @@ int sdk_get_device_info(sdk_ctx* ctx, sdk_device_info* out);
  * 0 = 8-wave workgroups, one segment per CU), "asp_packed_weights"
  * (likewise for the ASP logit weights, EL_ASP_W2PACK), "asp_per_segment"
  * (1 default / 0 = one workgroup per (segment, 128 channels)), "affinity_fast_path" / "affinity_variant" /
- * "affinity_whole_groups" (k = 1 affinity kernel selection), "matvec_variant" (0 default: persistent row-group kernel / 1 = round 1's
+ * "affinity_whole_groups" / "affinity_boundary_penalty" (k = 1 affinity kernel selection and work split), "matvec_variant" (0 default: persistent row-group kernel / 1 = round 1's
  * kernel; sums differ in the last bits only), "gemm_variant" (see sdk_set_gemm_variant).  Results do not depend on them.
  * NOT a knob - a numerical contract: "precision" 0 (default: bf16 operands, bf16 layer-boundary storage; PCM -> score within ~4e-3 of
  * the fp32 model) / 1 (fp16 hi+lo planes, three MFMAs per product: within 1e-5, ~3x the GEMM time).  It selects the output format of
@@ -286,6 +286,9 @@ size_t sdk_affinity_workspace_bytes(int N, int P);
  * workgroups, segments per group, record slots per segment}; *units = groups * stages; workgroup i sweeps the units
  * [i * units / workgroups, (i + 1) * units / workgroups) in (group, stage) order. */
 int sdk_affinity_plan(int N, int P, int num_cu, int32_t* out5, int64_t* units);
+/* Host-only: the unit range [u0, u1) of workgroup `wg` under that plan and the record slot of its first portion.  The ranges can be balanced by
+ * cost instead of unit count ("affinity_boundary_penalty" p: a group boundary inside a range counts as p stages; default 0 - measured, not a robust win). */
+int sdk_affinity_plan_range(int N, int P, int num_cu, int wg, int64_t* u0, int64_t* u1, int32_t* first_slot);
 int sdk_affinity_topk(sdk_ctx* ctx, const float* E, const uint16_t* Eb, const float* resid_e,
                       const float* P, const uint16_t* Pb, const float* resid_p,
                       int N, int Pn, int d, int k, int32_t* idx, float* score,

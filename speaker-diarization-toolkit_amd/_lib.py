@@ -108,6 +108,7 @@ SIGNATURES = {
     "sdk_l2norm": (_i, [_vp, _vp, _i, _i, _vp, _vp, _vp, _vp]),
     "sdk_affinity_workspace_bytes": (_sz, [_i, _i]),
     "sdk_affinity_plan": (_i, [_i, _i, _i, _vp, _vp]),
+    "sdk_affinity_plan_range": (_i, [_i, _i, _i, _i, _vp, _vp, _vp]),
     "sdk_affinity_matvec_workspace_bytes": (_sz, [_i]),
     "sdk_affinity_matvec_plan": (_i, [_i, _i, _i, _vp, _vp]),
     "sdk_affinity_matvec": (_i, [_vp, _vp, _i, _i, _i, _i, _vp, _vp, _i, _vp, _vp, _sz, _vp]),

@@ -35,11 +35,34 @@ constexpr uint32_t TMASK = 0x3ffu;     // tile tag: 10 bits (<= 1024 tiles = 327
 constexpr uint32_t CMASK = 0xfu;       // column tag: the accumulator register
 constexpr float MASKED = -4.0f;        // stands for "no such profile" (cosines are >= -1 - eps); finite so tags never make a NaN
 constexpr float EMPTY = -8.0f;
+constexpr int AFF_DEFAULT_PEN = 0;       // boundary penalty in stages (sdk_set_option "affinity_boundary_penalty").  Measured (tools/aff_pen_ab.py, interleaved): config #3
+                                         // 49.6 us at 0, 47.8-48.7 at 1-4 (-3 %); 125k x 10k unchanged; 20k x 2k 41.9 -> 43.6-45.6 (+4-9 %): not a robust win, off
 
 struct Geom {            // host-computed, identical on both sides
   int ngroups, nst, G, segs;   // segment groups, stages per group, workgroups, segments per group
   long long U;                 // units = ngroups * nst
+  int pen;                     // cost of starting a portion in a NEW group, in stages (fragment reload + a first stage that waits for it)
 };
+
+// Work ranges balanced by COST, not by units (round 3; timeline profiles/r03_aff_timeline_config3.txt: with equal unit counts a workgroup whose
+// range crossed a group boundary ended at 46-50 us where the others ended at 36-38).  Every group is given nst + pen VIRTUAL units, the first
+// pen of which are the switch cost and carry no work; the virtual axis is cut evenly and mapped back: a workgroup that starts a second group gets
+// fewer stages.  pen = 0 is the plain [i U / G, (i + 1) U / G) split.  Host and device share these two functions.
+__host__ __device__ inline long long geom_real(const Geom& g, long long v) {
+  const long long VU = g.nst + g.pen;
+  const long long b = v / VU, o = v - b * VU;
+  return b * g.nst + (o > g.pen ? o - g.pen : 0);
+}
+__host__ __device__ inline void geom_range(const Geom& g, long long i, long long& u0, long long& u1) {
+  const long long V = (long long)g.ngroups * (g.nst + g.pen);
+  u0 = geom_real(g, (i * V) / g.G);
+  u1 = geom_real(g, ((i + 1) * V) / g.G);
+}
+// first workgroup whose range reaches into group b: smallest j with real(floor((j + 1) V / G)) > b nst  <=>  floor((j + 1) V / G) > b VU + pen
+__host__ __device__ inline long long geom_first_wg(const Geom& g, long long b) {
+  const long long VU = g.nst + g.pen, V = (long long)g.ngroups * VU, X = b * VU + g.pen;
+  return ((X + 1) * g.G + V - 1) / V - 1;
+}
 
 template <int DEPTH>
 __device__ __forceinline__ void insert_sorted(float x, float* m) {
@@ -75,7 +98,8 @@ __global__ __launch_bounds__(WAVES * 64, 2) void aff_rowcol_kernel(const bf16_t*
   extern __shared__ __attribute__((aligned(16))) char sP[];
   const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
   const int col = lane & 31, h = lane >> 5;
-  const long long u0 = ((long long)blockIdx.x * gm.U) / gm.G, u1 = ((long long)(blockIdx.x + 1) * gm.U) / gm.G;
+  long long u0, u1;
+  geom_range(gm, blockIdx.x, u0, u1);
   const int nst = gm.nst;
   const int ntiles = (P + PT - 1) / PT;
 
@@ -106,9 +130,7 @@ __global__ __launch_bounds__(WAVES * 64, 2) void aff_rowcol_kernel(const bf16_t*
   // slot of the first portion = number of earlier workgroups that share its group
   int slot;
   {
-    const long long x = (long long)b * nst;
-    const long long ifirst = ((x + 1) * gm.G + gm.U - 1) / gm.U - 1;
-    slot = (int)(blockIdx.x - ifirst);
+    slot = (int)(blockIdx.x - geom_first_wg(gm, b));
   }
 
   bf16x8 bfrag[SEGB][KS];
@@ -588,7 +610,7 @@ size_t ws_layout(int N, int P, char* base, Ws* w) {
 }
 
 // Work decomposition of the coarse kernel (host side; the kernel derives each workgroup's range from it).
-Geom plan_geometry(int N, int P, int segs, int tps, long long max_wg, int whole_groups_mode = 0) {
+Geom plan_geometry(int N, int P, int segs, int tps, long long max_wg, int whole_groups_mode = 0, int pen = 0) {
   Geom gm;
   gm.segs = segs;
   gm.ngroups = ceil_div(N, segs);
@@ -607,6 +629,10 @@ Geom plan_geometry(int N, int P, int segs, int tps, long long max_wg, int whole_
     if (whole <= split || whole_groups_mode == 2) G = gm.ngroups;     // mode 2 (A/B knob): whenever the groups fit
   }
   gm.G = (int)G;
+  // the boundary penalty needs every virtual range to hold at least one real unit (no empty workgroup inside a group's slot sequence):
+  // floor(V / G) >= pen + 1; with G <= 2 groups that is nst >= pen + 2 - otherwise (very short sweeps) the plain split
+  gm.pen = 0;
+  if (pen > 0 && gm.nst >= pen + 2 && ((long long)gm.ngroups * (gm.nst + pen)) / G >= pen + 1) gm.pen = pen;
   return gm;
 }
 
@@ -616,7 +642,7 @@ int launch_coarse(sdk_ctx* ctx, const bf16_t* Eb, const bf16_t* Pb, int N, int P
   constexpr int SEGS = WAVES * SEGB * 32;
   constexpr int LDS = NSTAGE * TPS * TILE_BYTES;
   *segs = SEGS;
-  const Geom gm = plan_geometry(N, P, SEGS, TPS, (long long)ctx->num_cu * wg_per_cu, ctx->aff_whole_groups);
+  const Geom gm = plan_geometry(N, P, SEGS, TPS, (long long)ctx->num_cu * wg_per_cu, ctx->aff_whole_groups, ctx->aff_boundary_pen);
   auto kern = aff_rowcol_kernel<WAVES, SEGB, TPS, NSTAGE>;
   if (sdk_lds_optin(ctx, (const void*)kern, LDS)) return 1;
   hipLaunchKernelGGL(kern, dim3(gm.G), dim3(WAVES * 64), LDS, s, Eb, Pb, N, P, gm, w.stats, w.part_base, w.part_cnt, w.flag_count,
@@ -632,9 +658,20 @@ size_t aff_rowcol_workspace_bytes(int N, int P) { return ws_layout(N, P, nullptr
 // group, record slots per segment}, units = groups * stages.  Workgroup i sweeps units [i*units/wg, (i+1)*units/wg).
 extern "C" int sdk_affinity_plan(int N, int P, int num_cu, int32_t* out5, int64_t* units) {
   SDK_REQUIRE(N > 0 && P > 0 && num_cu > 0 && out5 && units, "sdk_affinity_plan: bad argument");
-  const Geom gm = plan_geometry(N, P, 8 * 2 * 32, 2, num_cu);       // the default variant: 8 waves x 2 blocks, 2 tiles per stage
+  const Geom gm = plan_geometry(N, P, 8 * 2 * 32, 2, num_cu, 0, AFF_DEFAULT_PEN);       // the default variant: 8 waves x 2 blocks, 2 tiles per stage
   out5[0] = gm.ngroups; out5[1] = gm.nst; out5[2] = gm.G; out5[3] = gm.segs; out5[4] = MAXP;
   *units = gm.U;
+  return 0;
+}
+// Host-only: workgroup i's unit range [u0, u1) and the record slot of its first portion, under the default plan (tests replay the kernel's walk)
+extern "C" int sdk_affinity_plan_range(int N, int P, int num_cu, int wg, int64_t* u0, int64_t* u1, int32_t* first_slot) {
+  SDK_REQUIRE(N > 0 && P > 0 && num_cu > 0 && u0 && u1 && first_slot, "sdk_affinity_plan_range: bad argument");
+  const Geom gm = plan_geometry(N, P, 8 * 2 * 32, 2, num_cu, 0, AFF_DEFAULT_PEN);
+  SDK_REQUIRE(wg >= 0 && wg < gm.G, "sdk_affinity_plan_range: workgroup %d of %d", wg, gm.G);
+  long long a, b;
+  geom_range(gm, wg, a, b);
+  *u0 = a; *u1 = b;
+  *first_slot = a < b ? (int32_t)(wg - geom_first_wg(gm, a / gm.nst)) : -1;
   return 0;
 }
 bool aff_rowcol_supported(int P) { return P <= 32768; }

@@ -92,6 +92,7 @@ extern "C" int sdk_set_option(sdk_ctx* ctx, const char* name, int value) {
   if (strcmp(name, "gemm_variant") == 0) return sdk_set_gemm_variant(value);
   if (strcmp(name, "affinity_fast_path") == 0) { ctx->aff_fast = value; return 0; }
   if (strcmp(name, "affinity_variant") == 0) { ctx->aff_variant = value; return 0; }
+  if (strcmp(name, "affinity_boundary_penalty") == 0) { ctx->aff_boundary_pen = value < 0 ? 0 : value; return 0; }
   if (strcmp(name, "matvec_variant") == 0) { ctx->matvec_variant = value; return 0; }
   if (strcmp(name, "hp_gemm_variant") == 0) { ctx->hp_gemm_variant = value; return 0; }
   if (strcmp(name, "affinity_whole_groups") == 0) { ctx->aff_whole_groups = value; return 0; }

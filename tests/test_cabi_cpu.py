@@ -265,15 +265,17 @@ def test_bf16_bits_roundtrip():
 
 
 def test_affinity_plan_every_group_sweep_is_covered_by_at_most_three_workgroups():
-    """Host side of the k = 1 affinity decomposition (csrc/affinity_rowcol.hip): workgroup i owns the units
-    [i*U/G, (i+1)*U/G) of the (segment group, profile stage) grid.  Replays the kernel's range / slot arithmetic and checks
-    that every group's sweep is tiled exactly once, by consecutive record slots 0..n-1 with n <= the slot count."""
+    """Host side of the k = 1 affinity decomposition (csrc/affinity_rowcol.hip): workgroup i owns a contiguous range of the (segment group,
+    profile stage) units, ranges from sdk_affinity_plan_range - the same functions the kernel uses (they can weigh a group boundary inside a
+    range as extra stages; default weight 0: equal unit counts).  Replays the kernel's walk and checks that the ranges tile [0, U) in order with no
+    idle workgroup, that every group's sweep is covered exactly once by consecutive record slots 0..n-1 with n <= the slot count, that the slot
+    the kernel derives for a workgroup's first portion is the number of earlier workgroups in that group, and that the split is balanced."""
     lib = LIB.load_library()
     rng = np.random.default_rng(11)
     worst = 0
     cases = [(1, 1), (2, 3), (31, 100), (512, 64), (513, 65), (1000, 100), (5000, 1000), (100_000, 1000), (125_000, 10_000),
              (2000, 10_000), (300_000, 32_768)]
-    cases += [(int(rng.integers(1, 300_000)), int(rng.integers(1, 32_769))) for _ in range(300)]
+    cases += [(int(rng.integers(1, 300_000)), int(rng.integers(1, 32_769))) for _ in range(120)]
     for N, P in cases:
         for cu in (256, 240, 304):
             out = (C.c_int32 * 5)()
@@ -282,23 +284,29 @@ def test_affinity_plan_every_group_sweep_is_covered_by_at_most_three_workgroups(
             ngroups, nst, G, segs, slots = list(out)
             U = units.value
             assert ngroups == -(-N // segs) and U == ngroups * nst and 1 <= G <= min(cu, U)
-            parts = {}
+            parts, prev_end, costs = {}, 0, []
             for i in range(G):
-                u0, u1 = i * U // G, (i + 1) * U // G
-                assert u1 > u0                                             # no idle workgroup
-                b0 = u0 // nst
-                ifirst = ((b0 * nst + 1) * G + U - 1) // U - 1              # the kernel's formula for the first slot
-                assert ifirst * U // G <= b0 * nst < (ifirst + 1) * U // G
-                u, first = u0, True
+                u0, u1, fs = C.c_int64(), C.c_int64(), C.c_int32()
+                assert lib.sdk_affinity_plan_range(N, P, cu, i, C.byref(u0), C.byref(u1), C.byref(fs)) == 0
+                u0, u1, fs = u0.value, u1.value, fs.value
+                assert u0 == prev_end and u1 > u0, (N, P, cu, i, u0, u1)     # ranges tile [0, U) in order, no idle workgroup
+                prev_end = u1
+                u, first, started = u0, True, 0
                 while u < u1:
                     b = u // nst
                     e = min(u1, (b + 1) * nst)
-                    parts.setdefault(b, []).append((i - ifirst if first else 0, u - b * nst, e - b * nst))
+                    slot = fs if first else 0
+                    assert slot == len(parts.get(b, [])), (N, P, cu, i, b)     # the kernel's slot = number of earlier workgroups in this group
+                    parts.setdefault(b, []).append((slot, u - b * nst, e - b * nst))
+                    started += 1
                     first, u = False, e
-            assert len(parts) == ngroups
+                costs.append((u1 - u0) + 2 * (started - 1))
+            assert prev_end == U and len(parts) == ngroups
             for b, lst in parts.items():
-                assert [s for s, _, _ in lst] == list(range(len(lst))), (N, P, cu, b, lst)
                 assert lst[0][1] == 0 and lst[-1][2] == nst and all(x[2] == y[1] for x, y in zip(lst, lst[1:]))
                 worst = max(worst, len(lst))
             assert worst <= slots
+            if nst >= 8 and G == cu:                                          # long enough sweeps: the cost spread is a stage or two, not a switch
+                assert max(costs) - min(costs) <= 6, (N, P, cu, min(costs), max(costs))   # (a range that BEGINS at a group start is charged the penalty too)
     assert worst == 3
+    assert lib.sdk_affinity_plan_range(1000, 100, 256, 999, C.byref(C.c_int64()), C.byref(C.c_int64()), C.byref(C.c_int32())) != 0
