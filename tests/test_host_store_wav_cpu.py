@@ -288,6 +288,21 @@ def test_packed_blob_cache_roundtrip_and_backend_digest(tmp_path, monkeypatch):
         got, gf = wc.load_blob(key, prec)
         assert np.array_equal(np.asarray(got), blob) and gf == f and isinstance(got, np.memmap)
     assert wc.load_meta(key)["digest"] == "abc123abc123" and set(wc.load_meta(key)["fields"]) == {"0", "1"}
+    # a flipped byte in the blob, or an offset table that points outside it, is a miss (the offsets are dereferenced on the device)
+    fn = tmp_path / "cache" / f"{key}.p1.npy"
+    raw = bytearray(fn.read_bytes()); raw[-7] ^= 0x40; fn.write_bytes(bytes(raw))
+    assert wc.load_blob(key, 1) is None and wc.load_blob(key, 0) is not None
+    raw[-7] ^= 0x40; fn.write_bytes(bytes(raw))
+    assert wc.load_blob(key, 1) is not None
+    meta = json.loads((tmp_path / "cache" / f"{key}.json").read_text())
+    good = list(meta["fields"]["1"]["off"])
+    for bad_off in (meta["fields"]["1"]["_bytes"], 128, -2):
+        meta["fields"]["1"]["off"][5] = bad_off
+        (tmp_path / "cache" / f"{key}.json").write_text(json.dumps(meta))
+        assert wc.load_blob(key, 1) is None
+    meta["fields"]["1"]["off"] = good
+    (tmp_path / "cache" / f"{key}.json").write_text(json.dumps(meta))
+    assert wc.load_blob(key, 1) is not None
     # a truncated blob or another format version is a miss
     meta = json.loads((tmp_path / "cache" / f"{key}.json").read_text())
     meta["fields"]["0"]["_bytes"] += 1
