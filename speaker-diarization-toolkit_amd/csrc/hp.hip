@@ -618,19 +618,24 @@ __global__ __launch_bounds__(256) void asp_stats_hp_kernel(const uint16_t* __res
 }
 
 // attentive statistics pooling from fp32 logits: softmax over frames per channel, weighted mean / std of h.  One thread per channel
-// (grid (B, C / 256)): three passes over the segment's column (max; sum of exp and weighted sums around a shift; nothing else), all fp32.
+// (grid (B, C / 256)), ONE pass over the segment's column: online softmax (running maximum, the three running sums rescaled when it grows),
+// moments around the first frame's value, all fp32.
 __global__ __launch_bounds__(256) void asp_pool_hp_kernel(const float* __restrict__ logits, int64_t ldl, const uint16_t* __restrict__ h,
                                                          int64_t ldh, int64_t h_lo, int T, int C, float* __restrict__ pooled) {
   const int c = blockIdx.y * 256 + threadIdx.x;
   if (c >= C) return;
   const int64_t base = (int64_t)blockIdx.x * T;
-  float mx = -INFINITY;
-  for (int t = 0; t < T; ++t) mx = fmaxf(mx, logits[(base + t) * ldl + c]);
   const float K = load1(h + base * ldh + c, h_lo);
-  float se = 0.f, s1 = 0.f, s2 = 0.f;
+  float mx = -INFINITY, se = 0.f, s1 = 0.f, s2 = 0.f;
   for (int t = 0; t < T; ++t) {
-    const float w = expf(logits[(base + t) * ldl + c] - mx);
+    const float l = logits[(base + t) * ldl + c];
     const float d = load1(h + (base + t) * ldh + c, h_lo) - K;
+    if (l > mx) {                                     // rescale what has been summed so far to the new maximum
+      const float r = expf(mx - l);                   // exp(-inf) = 0 on the first frame
+      se *= r; s1 *= r; s2 *= r;
+      mx = l;
+    }
+    const float w = expf(l - mx);
     se += w;
     s1 = fmaf(w, d, s1);
     s2 = fmaf(w * d, d, s2);
