@@ -23,7 +23,8 @@
  *     sdk_abi_version  sdk_init  sdk_shutdown  sdk_last_error  sdk_get_device_info
  *     sdk_resample_out_len  sdk_resample_s16                                   audio -> AudioProfile format
  *     sdk_fbank_tables_bytes  sdk_fbank_tables_fill  sdk_fbank_workspace_bytes  sdk_fbank              k1
- *     sdk_ecapa_workspace_bytes  sdk_ecapa_forward  sdk_xvector_workspace_bytes  sdk_xvector_forward          k2
+ *     sdk_ecapa_workspace_bytes  sdk_ecapa_forward  sdk_ecapa_calib_floats  sdk_ecapa_forward_calib            k2
+ *     sdk_xvector_workspace_bytes  sdk_xvector_forward                                                  k2 (second model family)
  *     sdk_l2norm                                                                                        k3
  *     sdk_affinity_workspace_bytes  sdk_affinity_topk                                                   k4
  *     sdk_affinity_matvec_workspace_bytes  sdk_affinity_matvec  sdk_rows_gram_workspace_bytes  sdk_rows_gram
@@ -239,6 +240,14 @@ size_t sdk_ecapa_workspace_bytes(const sdk_ecapa_desc* d, int B, int T);
 int sdk_ecapa_forward(sdk_ctx* ctx, const void* wblob, const sdk_ecapa_desc* wdesc,
                       const uint16_t* feats, int ldf, int B, int T,
                       void* ws, size_t ws_bytes, float* emb, void* stream);
+
+/* Calibration pass for the host's BIAS CORRECTION of the bf16 weight rounding (weights_pack.bias_corrections): the same
+ * forward (Res2Net chain unfused), additionally writing the per-segment mean | std ([B, 2 C_l] fp32, sdk_asp_stats layout) of the INPUT of every
+ * corrected GEMM layer into `calib`, slots in this order: per block {tdnn1 [C], Res2Net conv 0..scale-2 [sub_channels each], tdnn2 [C]}, then
+ * MFA [mfa_channels], ASP hidden [mfa_channels]; sdk_ecapa_calib_floats() = total floats.  Default-mode blobs only. */
+size_t sdk_ecapa_calib_floats(const sdk_ecapa_desc* d, int B);
+int sdk_ecapa_forward_calib(sdk_ctx* ctx, const void* wblob, const sdk_ecapa_desc* wdesc, const uint16_t* feats, int ldf, int B, int T,
+                            void* ws, size_t ws_bytes, float* emb, float* calib, void* stream);
 
 /* ---- x-vector (plain TDNN) forward - north_star names "ECAPA-TDNN/x-vector".  Frame layers l = 0..n_frame_layers-1:
  *      dilated conv (kernel[l], dilation[l], "same" length by segment-local reflection) -> ReLU -> BatchNorm(eval), bf16 layer-boundary

@@ -35,6 +35,7 @@ def _bf16(x: torch.Tensor) -> torch.Tensor:
 
 
 # every place where the bf16 layer-boundary model rounds
+WEIGHT_GROUPS = ("blk0", "tdnn1", "res2net", "tdnn2", "mfa", "asp")       # "w:<group>" overrides "w" for that group of layers
 ROUNDING_SITES = (
     "w",            # weights of every MFMA GEMM (blk0, tdnn1, Res2Net convs, tdnn2, MFA, attention hidden, attention logits)
     "feats",        # the normalised log-mel features as the first conv's A operand
@@ -81,7 +82,7 @@ class EcapaOracle:
             sites = {s: 8 for s in ROUNDING_SITES} if mode == "bf16" else {}
         elif not isinstance(sites, dict):
             sites = {s: 8 for s in sites}
-        unknown = set(sites) - set(ROUNDING_SITES)
+        unknown = set(sites) - set(ROUNDING_SITES) - {f"w:{g}" for g in WEIGHT_GROUPS}
         assert not unknown, f"unknown rounding sites {sorted(unknown)}"
         self.sites = dict(sites)
 
@@ -90,6 +91,17 @@ class EcapaOracle:
         """Round at `site` (a member of ROUNDING_SITES) to that site's significand width; identity where the site is off."""
         bits = self.sites.get(site)
         return x if bits is None else round_significand(x, bits)
+
+    def qw(self, W: torch.Tensor, group: str) -> torch.Tensor:
+        """Round the weights of one layer group: "w:<group>" if given (24 = exact), else "w"."""
+        bits = self.sites.get(f"w:{group}", self.sites.get("w"))
+        return W if bits is None else round_significand(W, bits)
+
+    @staticmethod
+    def weight_group(name: str) -> str:
+        if "res2net" in name:
+            return "res2net"
+        return "blk0" if name.startswith("blk0") else name.split(".")[-2]      # blk1.tdnn1.conv -> tdnn1, mfa.conv -> mfa
 
     def bn(self, name: str):
         g, b, m, v = (self.w[f"{name}.{f}"].double() for f in ("gamma", "beta", "mean", "var"))
@@ -101,7 +113,7 @@ class EcapaOracle:
         W = self.w[f"{name}.w"]                      # [Cout, Cin, k]
         Cout, Cin, k = W.shape
         B, T, _ = x.shape
-        Wq = self.q(W, "w").to(self.acc)
+        Wq = self.qw(W, self.weight_group(name)).to(self.acc)
         xa = x.to(self.acc)
         out = torch.zeros(B, T, Cout, dtype=self.acc)
         t = torch.arange(T)
@@ -158,14 +170,14 @@ class EcapaOracle:
         sd = torch.sqrt(((hd - mu[:, None, :]) ** 2).mean(dim=1).clamp_min(STD_EPS))
         Wt = self.w["asp.tdnn.conv.w"][:, :, 0]                              # [128, 9216]
         Cm = h.shape[-1]
-        Wh = self.q(Wt[:, :Cm], "w").to(self.acc)
+        Wh = self.qw(Wt[:, :Cm], "asp").to(self.acc)
         ctx = torch.cat([mu, sd], dim=-1).float()                           # [B, 6144] fp32
         ubias = (ctx.double() @ Wt[:, Cm:].double().T).float() + self.w["asp.tdnn.conv.b"]
         s, sh = self.bn("asp.tdnn.bn")
         pre = (h.to(self.acc) @ Wh.T).float() + ubias[:, None, :]
         a = self.q(torch.tanh(torch.relu(pre) * s + sh), "attn_hidden")    # [B,T,128]
         inter["attn_hidden"] = a
-        W2 = self.q(self.w["asp.conv.w"][:, :, 0], "w").to(self.acc)         # [3072,128]
+        W2 = self.qw(self.w["asp.conv.w"][:, :, 0], "asp").to(self.acc)      # [3072,128]
         logits = (a.to(self.acc) @ W2.T).float() + self.w["asp.conv.b"]     # [B,T,3072] fp32
         wgt = torch.softmax(logits.double(), dim=1)
         wmu = (wgt * hd).sum(dim=1)

@@ -101,6 +101,8 @@ SIGNATURES = {
     "sdk_asp_fused": (_i, [_vp, _vp, _i64, _vp, _vp, _vp, _i64, _i, _i, _i, _i, _vp, _vp]),
     "sdk_ecapa_workspace_bytes": (_sz, [C.POINTER(EcapaDesc), _i, _i]),
     "sdk_ecapa_forward": (_i, [_vp, _vp, C.POINTER(EcapaDesc), _vp, _i, _i, _i, _vp, _sz, _vp, _vp]),
+    "sdk_ecapa_calib_floats": (_sz, [C.POINTER(EcapaDesc), _i]),
+    "sdk_ecapa_forward_calib": (_i, [_vp, _vp, C.POINTER(EcapaDesc), _vp, _i, _i, _i, _vp, _sz, _vp, _vp, _vp]),
     "sdk_xvector_workspace_bytes": (_sz, [_vp, _i, _i]),
     "sdk_xvector_forward": (_i, [_vp, _vp, _vp, _vp, _i, _i, _i, _vp, _sz, _vp, _vp]),
     "sdk_resample_out_len": (_i64, [_i64, _i, _i]),

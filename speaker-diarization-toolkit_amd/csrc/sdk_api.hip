@@ -310,8 +310,42 @@ extern "C" size_t sdk_ecapa_workspace_bytes(const sdk_ecapa_desc* d, int B, int 
   return fwd_layout(d, B, T, nullptr, nullptr);
 }
 
+// Calibration slots (sdk_ecapa_forward_calib): per-segment mean | std (sdk_asp_stats layout [B, 2 C_l]) of the INPUT of every bf16 GEMM layer whose
+// weight rounding the host corrects in the bias (weights_pack.bias_corrections): per block tdnn1, the Res2Net convs, tdnn2; then MFA, ASP hidden.
+static size_t calib_offset(const sdk_ecapa_desc* d, int B, int block, int layer) {   // block < n_blocks: layer 0 = tdnn1, 1..scale-1 = Res2Net conv
+  const size_t C = d->channels, S = d->sub_channels, Cm = d->mfa_channels, nr = d->scale - 1;   // layer - 1, scale = tdnn2; block == n_blocks: 0 = MFA,
+  const size_t per_block = 2 * C + nr * 2 * S + 2 * C;                                            // 1 = ASP hidden, 2 = end
+  size_t off;
+  if (block < d->n_blocks) {
+    off = (size_t)block * per_block;
+    if (layer >= 1) off += 2 * C + (size_t)(layer - 1) * 2 * S;        // (layer == scale: behind the nr Res2Net slots)
+  } else {
+    off = (size_t)d->n_blocks * per_block + (size_t)layer * 2 * Cm;
+  }
+  return off * (size_t)B;
+}
+
+extern "C" size_t sdk_ecapa_calib_floats(const sdk_ecapa_desc* d, int B) {
+  if (!d || B <= 0) return 0;
+  return calib_offset(d, B, d->n_blocks, 2);
+}
+
+static int ecapa_forward_impl(sdk_ctx* ctx, const void* wblob, const sdk_ecapa_desc* d, const uint16_t* feats, int ldf,
+                              int B, int T, void* ws, size_t ws_bytes, float* emb, float* calib, void* stream);
+
 extern "C" int sdk_ecapa_forward(sdk_ctx* ctx, const void* wblob, const sdk_ecapa_desc* d, const uint16_t* feats, int ldf,
                                  int B, int T, void* ws, size_t ws_bytes, float* emb, void* stream) {
+  return ecapa_forward_impl(ctx, wblob, d, feats, ldf, B, T, ws, ws_bytes, emb, nullptr, stream);
+}
+
+extern "C" int sdk_ecapa_forward_calib(sdk_ctx* ctx, const void* wblob, const sdk_ecapa_desc* d, const uint16_t* feats, int ldf,
+                                       int B, int T, void* ws, size_t ws_bytes, float* emb, float* calib, void* stream) {
+  SDK_REQUIRE(calib && d && d->precision == 0, "sdk_ecapa_forward_calib: calib is null or the blob is not a default-mode blob");
+  return ecapa_forward_impl(ctx, wblob, d, feats, ldf, B, T, ws, ws_bytes, emb, calib, stream);
+}
+
+static int ecapa_forward_impl(sdk_ctx* ctx, const void* wblob, const sdk_ecapa_desc* d, const uint16_t* feats, int ldf,
+                              int B, int T, void* ws, size_t ws_bytes, float* emb, float* calib, void* stream) {
   SDK_REQUIRE(ctx && wblob && feats && ws && emb, "sdk_ecapa_forward: null argument");
   if (int rc = check_desc(d)) return rc;
   SDK_REQUIRE(B > 0 && T > 0, "sdk_ecapa_forward: empty batch (B=%d T=%d)", B, T);
@@ -370,10 +404,12 @@ extern "C" int sdk_ecapa_forward(sdk_ctx* ctx, const void* wblob, const sdk_ecap
   int64_t ldx = C;
   for (int i = 1; i <= d->n_blocks; ++i) {
     const int base = EL_BLOCK_BASE(i), dil = d->dilation[i - 1];
+    if (calib)
+      if (int rc = sdk_asp_stats(ctx, xin, ldx, B, T, C, calib + calib_offset(d, B, i - 1, 0), stream)) return rc;
     if (int rc = tdnn(xin, ldx, C, 1, 1, base + EL_TDNN1, C, w.U, C, nullptr, 0, nullptr, 0)) return rc;
     // Res2Net: chunk 0 passes through, chunk c>=1 = TDNN(chunk c + y_{c-1})
     const uint16_t* r2out = w.R;
-    if (S == 128 && d->scale - 1 <= 7 && T <= sdk_res2net_chain_max_frames() && !ctx->no_chain_fusion) {
+    if (S == 128 && d->scale - 1 <= 7 && T <= sdk_res2net_chain_max_frames() && !ctx->no_chain_fusion && !calib) {
       // the seven dependent convolutions in ONE launch, the running tile resident in LDS per segment.  The chain runs
       // IN PLACE on the tdnn1 output: a workgroup has read u_c (into LDS / registers) before it writes y_c over it, and
       // segments do not overlap - so chunk 0 needs no copy
@@ -398,9 +434,13 @@ extern "C" int sdk_ecapa_forward(sdk_ctx* ctx, const void* wblob, const sdk_ecap
         const bool more = j + 1 < d->scale - 1;
         uint16_t* Sout = more ? ((j & 1) ? w.Sb : w.Sa) : nullptr;
         const uint16_t* X2 = more ? w.U + (int64_t)S * (j + 2) : nullptr;
+        if (calib)
+          if (int rc = sdk_asp_stats(ctx, Ain, lda, B, T, S, calib + calib_offset(d, B, i - 1, 1 + j), stream)) return rc;
         if (int rc = tdnn(Ain, lda, S, 3, dil, base + EL_RES2NET(j), S, w.R + (int64_t)S * (j + 1), C, X2, C, Sout, S)) return rc;
       }
     }
+    if (calib)
+      if (int rc = sdk_asp_stats(ctx, r2out, C, B, T, C, calib + calib_offset(d, B, i - 1, d->scale), stream)) return rc;
     // the SE squeeze (per-segment channel means of z) comes out of the tdnn2 epilogue where the shape allows it
     const bool fuse_se = sdk_conv_gemm_stats_fusable(M, C, T) != 0;
     if (int rc = tdnn(r2out, C, C, 1, 1, base + EL_TDNN2, C, w.Z, C, nullptr, 0, nullptr, 0, fuse_se ? 1 : 0)) return rc;
@@ -418,7 +458,11 @@ extern "C" int sdk_ecapa_forward(sdk_ctx* ctx, const void* wblob, const sdk_ecap
   // attentive statistics pooling with global context; the context (mean | std of h over frames) comes out of
   // the MFA epilogue where the shape allows it, else from a separate sweep of h
   const bool fuse_ctx = sdk_conv_gemm_stats_fusable(M, Cm, T) != 0;
+  if (calib)
+    if (int rc = sdk_asp_stats(ctx, w.CAT, Cm, B, T, Cm, calib + calib_offset(d, B, d->n_blocks, 0), stream)) return rc;
   if (int rc = tdnn(w.CAT, Cm, Cm, 1, 1, tb + EL_MFA, Cm, w.H, Cm, nullptr, 0, nullptr, 0, fuse_ctx ? 2 : 0)) return rc;
+  if (calib)
+    if (int rc = sdk_asp_stats(ctx, w.H, Cm, B, T, Cm, calib + calib_offset(d, B, d->n_blocks, 1), stream)) return rc;
   if (fuse_ctx) {
     if (int rc = sdk_colstats_finish(ctx, w.stats, M, Cm, T, 2, w.ctx, stream)) return rc;
   } else {

@@ -45,9 +45,14 @@ def num_frames(n_samples: int) -> int:
 
 class Engine:
     def __init__(self, device: int = 0, weights: Optional[Dict[str, np.ndarray]] = None,
-                 cfg: EcapaConfig = DEFAULT_CONFIG, seed: int = 0, cache_key: Optional[str] = None, weights_fn=None, digest_fn=None):
+                 cfg: EcapaConfig = DEFAULT_CONFIG, seed: int = 0, cache_key: Optional[str] = None, weights_fn=None, digest_fn=None,
+                 bias_correction: Optional[bool] = None):
         """weights: host dict (weights.py naming) or None; weights_fn: called only when the dict is really needed (cache miss);
-        cache_key / digest_fn: identity of the weights for the packed-blob cache (weights_cache.py) - None = no caching."""
+        cache_key / digest_fn: identity of the weights for the packed-blob cache (weights_cache.py) - None = no caching.
+        bias_correction (default mode only): fold the constant part of the bf16 weight-rounding error of every GEMM layer into its bias,
+        from a calibration pass on built-in synthetic audio (weights_pack.bias_corrections; PCM -> score deviation from the fp32 model
+        4.3e-3 -> ~8e-4 at no run-time cost).  False = the plain bf16 layer-boundary model (kernel parity tests).  None = $SDK_BIAS_CORRECTION
+        (default "1")."""
         self.lib = _lib.load_library()
         self.ctx = _lib.get_ctx(device)        # raises SdkError without a gfx950 device
         self.device = torch.device("cuda", device)
@@ -57,6 +62,9 @@ class Engine:
         self._cache_key = cache_key
         self._digest_fn = digest_fn
         self.cache_hit = False
+        import os
+        self.bias_correction = (os.environ.get("SDK_BIAS_CORRECTION", "1") != "0") if bias_correction is None else bool(bias_correction)
+        self._bias_host: Dict[str, np.ndarray] = {}        # layer name -> corrected bias (default mode), for effective_weights()
         self._seed = seed
         self._wblob = None
         self._desc = None
@@ -91,7 +99,10 @@ class Engine:
             self._cache_key = None                      # explicit weights: their identity is unknown to the cache
         if self.precision not in self._packed:
             from . import weights_cache
-            hit = weights_cache.load_blob(self._cache_key, self.precision) if self._cache_key else None
+            correct = self.bias_correction and self.precision == 0
+            ckey = "0c" if correct else self.precision            # a bias-corrected blob is its own cache entry
+            hit = weights_cache.load_blob(self._cache_key, ckey) if self._cache_key else None
+            need_store = False
             if hit is not None:
                 blob, f = hit                            # memory-mapped: the upload below is the only pass over the bytes
                 self.cache_hit = True
@@ -99,8 +110,7 @@ class Engine:
                 if self._weights_host is None:
                     self._weights_host = self._weights_fn() if self._weights_fn else synthetic_weights(self._seed, self.cfg)
                 blob, f = pack_weights(self._weights_host, self.cfg, precision=self.precision)
-                if self._cache_key and self._digest_fn:
-                    weights_cache.store(self._cache_key, self._digest_fn(), self.precision, blob, f)
+                need_store = bool(self._cache_key and self._digest_fn)
             d = EcapaDesc()
             for k, v in f.items():
                 if k == "dilation":
@@ -114,7 +124,73 @@ class Engine:
                 warnings.simplefilter("ignore", UserWarning)
                 host = torch.from_numpy(np.asarray(blob))
             self._packed[self.precision] = (host.to(self.device), d)
+            if correct and hit is None:
+                blob = self._apply_bias_correction(np.array(blob, copy=True), f)
+            if need_store:
+                weights_cache.store(self._cache_key, self._digest_fn(), ckey, blob, f)
         self._wblob, self._desc = self._packed[self.precision]
+
+    # ------------------------------------------------------------------ bias correction of the bf16 weight rounding (default mode)
+    @staticmethod
+    def calibration_pcm(n: int = 16, seed: int = 20240) -> np.ndarray:
+        """Built-in calibration audio: n two-second segments of noise at several levels plus two tones each (deterministic).  Only the
+        per-channel MEANS of the layer inputs are taken from it; a quiet-noise set gives nearly the same correction."""
+        rng = np.random.default_rng(seed)
+        t = np.arange(32000, dtype=np.float32) / 16000.0
+        level = rng.uniform(0.02, 0.2, (n, 1)).astype(np.float32)
+        x = rng.standard_normal((n, 32000)).astype(np.float32) * level
+        x += 0.2 * np.sin(2 * np.pi * rng.uniform(90, 400, (n, 1)).astype(np.float32) * t) + 0.1 * np.sin(2 * np.pi * rng.uniform(800, 3500, (n, 1)).astype(np.float32) * t)
+        return np.clip(np.round(x * 32768.0), -32768, 32767).astype(np.int16)
+
+    def _apply_bias_correction(self, blob: np.ndarray, fields: dict) -> np.ndarray:
+        """One calibration forward with the plain blob (already uploaded), corrected biases computed on the host from the measured channel means of
+        every GEMM layer's input, written into the device blob and into `blob` (returned, for the cache)."""
+        from .weights_pack import bias_corrections, bias_slot, calib_layout
+        wdev, d = self._packed[0]
+        pcm = torch.from_numpy(self.calibration_pcm()).to(self.device)
+        B, S = pcm.shape
+        T = num_frames(S)
+        saved = (self._wblob, self._desc)
+        self._wblob, self._desc = wdev, d
+        try:
+            feats = self.fbank(pcm)
+            nfl = self.lib.sdk_ecapa_calib_floats(C.byref(d), B)
+            calib = torch.zeros((nfl,), dtype=torch.float32, device=self.device)
+            ws = self._scratch_bytes("ecapa", self.lib.sdk_ecapa_workspace_bytes(C.byref(d), B, T))
+            emb = torch.empty((B, self.cfg.embed_dim), dtype=torch.float32, device=self.device)
+            check(self.lib.sdk_ecapa_forward_calib(self.ctx, wdev.data_ptr(), C.byref(d), feats.data_ptr(), feats.stride(0), B, T, ws.data_ptr(),
+                                                   ws.numel(), emb.data_ptr(), calib.data_ptr(), _stream()), "sdk_ecapa_forward_calib")
+            cal = calib.cpu().numpy().astype(np.float64)
+        finally:
+            self._wblob, self._desc = saved
+        layout, per_seg = calib_layout(self.cfg)
+        assert per_seg * B == nfl, (per_seg, B, nfl)
+        means = {name: cal[off * B:(off + 2 * ch) * B].reshape(B, 2 * ch)[:, :ch].mean(axis=0) for name, ch, off in layout}
+        self._bias_host = bias_corrections(self._weights_host, means, self.cfg)
+        for name, bias in self._bias_host.items():
+            o = fields["off"][bias_slot(name, self.cfg)]
+            raw = np.ascontiguousarray(bias, dtype=np.float32).view(np.uint8)
+            blob[o:o + raw.size] = raw
+            wdev[o:o + raw.size] = torch.from_numpy(raw.copy()).to(self.device)
+        return blob
+
+    def effective_weights(self) -> Dict[str, np.ndarray]:
+        """The weight dictionary whose bf16 layer-boundary model the default mode computes: the loaded weights with the corrected biases
+        (identical to the loaded weights when bias_correction is off).  For checkers (tests, smoke): the product never needs it."""
+        self.desc
+        if self._weights_host is None:
+            self._weights_host = self._weights_fn() if self._weights_fn else synthetic_weights(self._seed, self.cfg)
+        w = dict(self._weights_host)
+        if self.bias_correction and self.precision == 0:
+            if not self._bias_host:                   # cache hit: read the corrected biases back from the device blob
+                from .weights_pack import bias_slot, calib_layout
+                for name, ch, _ in calib_layout(self.cfg)[0]:
+                    n_out = self._weights_host[f"{name}.conv.b"].shape[0]
+                    o = int(self._desc.off[bias_slot(name, self.cfg)])
+                    self._bias_host[name] = self._wblob[o:o + 4 * n_out].cpu().numpy().view(np.float32).copy()
+            for name, b in self._bias_host.items():
+                w[f"{name}.conv.b"] = b
+        return w
 
     def set_precision(self, precision: int) -> None:
         """0 (default): bf16 GEMM operands, bf16 layer-boundary storage - PCM -> cosine score within ~4e-3 of the fp32 model.

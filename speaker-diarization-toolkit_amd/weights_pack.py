@@ -224,3 +224,50 @@ def pack_weights(weights: Dict[str, np.ndarray], cfg: EcapaConfig = DEFAULT_CONF
                   mfa_channels=cfg.mfa_channels, embed_dim=cfg.embed_dim, n_blocks=nb, kernel0=cfg.kernel0,
                   dilation=list(cfg.dilations) + [0] * (4 - nb), off=off)
     return blob, fields
+
+
+# ---------------------------------------------------------------------------------------------------------------------------------
+# Bias correction of the bf16 WEIGHT rounding (round 3, DESIGN.md section 3).  The error budget (profiles/r03_error_budget.md) says the default
+# mode's 4.3e-3 score deviation is almost all weight rounding, and tools/ experiments say that error is almost all a per-output-channel
+# CONSTANT: (W - bf16(W)) . mean(x) with a channel mean of the layer input that barely depends on the utterance (the input is a BatchNorm
+# output).  Folding that constant into the layer's bias - standard post-training-quantisation bias correction - removes it at no run-time cost.
+# The means come from a calibration pass on the GPU (sdk_ecapa_forward_calib on built-in synthetic audio; ops.Engine), never from the oracle.
+def calib_layout(cfg: EcapaConfig = DEFAULT_CONFIG):
+    """[(layer name, channels, float offset per segment)] in the slot order of sdk_ecapa_forward_calib (each slot = mean | std, 2 C floats)."""
+    out, off = [], 0
+    for i in range(1, len(cfg.dilations) + 1):
+        out.append((f"blk{i}.tdnn1", cfg.channels, off)); off += 2 * cfg.channels
+        for j in range(cfg.res2net_scale - 1):
+            out.append((f"blk{i}.res2net.{j}", cfg.sub_channels, off)); off += 2 * cfg.sub_channels
+        out.append((f"blk{i}.tdnn2", cfg.channels, off)); off += 2 * cfg.channels
+    out.append(("mfa", cfg.mfa_channels, off)); off += 2 * cfg.mfa_channels
+    out.append(("asp.tdnn", cfg.mfa_channels, off)); off += 2 * cfg.mfa_channels
+    return out, off
+
+
+def bias_corrections(weights: Dict[str, np.ndarray], means: Dict[str, np.ndarray], cfg: EcapaConfig = DEFAULT_CONFIG) -> Dict[str, np.ndarray]:
+    """layer name -> corrected fp32 bias  b + (W - bf16(W)) . mu  (float64 inside; every tap of a k3 conv sees the same channel means)."""
+    out = {}
+    for name, mu in means.items():
+        w = weights[f"{name}.conv.w"].astype(np.float64)                     # [C_out, C_in(, k)]
+        if name == "asp.tdnn":
+            w = w[:, :cfg.mfa_channels]                                       # the per-frame part of the attention hidden layer (the context part is fp32)
+        dw = w - bf16_bits_to_f32(f32_to_bf16_bits(w.astype(np.float32))).astype(np.float64)
+        corr = np.tensordot(dw.sum(axis=2) if dw.ndim == 3 else dw, np.asarray(mu, np.float64)[:dw.shape[1]], axes=([1], [0]))
+        out[name] = (weights[f"{name}.conv.b"].astype(np.float64) + corr).astype(np.float32)
+    return out
+
+
+def bias_slot(name: str, cfg: EcapaConfig = DEFAULT_CONFIG) -> int:
+    """descriptor slot that holds the fp32 bias of a corrected layer"""
+    if name == "mfa":
+        return tail_base(len(cfg.dilations)) + EL_MFA + EL_B
+    if name == "asp.tdnn":
+        return tail_base(len(cfg.dilations)) + EL_ASP_B
+    blk, kind = name.split(".", 1)
+    b = block_base(int(blk[3:]))
+    if kind == "tdnn1":
+        return b + EL_TDNN1 + EL_B
+    if kind == "tdnn2":
+        return b + EL_TDNN2 + EL_B
+    return b + res2net_slot(int(kind.split(".")[1])) + EL_B

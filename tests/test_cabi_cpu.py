@@ -310,3 +310,36 @@ def test_affinity_plan_every_group_sweep_is_covered_by_at_most_three_workgroups(
                 assert max(costs) - min(costs) <= 6, (N, P, cu, min(costs), max(costs))   # (a range that BEGINS at a group start is charged the penalty too)
     assert worst == 3
     assert lib.sdk_affinity_plan_range(1000, 100, 256, 999, C.byref(C.c_int64()), C.byref(C.c_int64()), C.byref(C.c_int32())) != 0
+
+
+def test_bias_correction_host_side():
+    """weights_pack.bias_corrections / calib_layout / bias_slot (round 3): the slot walk matches sdk_ecapa_forward_calib's, the correction is
+    b + (W - bf16(W)) . mu in float64 with every tap of a k3 conv seeing the same means, and the bias slots it patches are the layers' own."""
+    W, WP = sub("weights"), sub("weights_pack")
+    cfg = W.DEFAULT_CONFIG
+    lay, per = WP.calib_layout(cfg)
+    assert len(lay) == 3 * 9 + 2 and per == 3 * (2 * 1024 + 7 * 2 * 128 + 2 * 1024) + 2 * 2 * 3072
+    assert [n for n, _, _ in lay[:10]] == ["blk1.tdnn1"] + [f"blk1.res2net.{j}" for j in range(7)] + ["blk1.tdnn2", "blk2.tdnn1"]
+    lib = LIB.load_library()
+    d = LIB.EcapaDesc()
+    d.channels, d.sub_channels, d.scale, d.mfa_channels, d.n_blocks = 1024, 128, 8, 3072, 3
+    assert lib.sdk_ecapa_calib_floats(C.byref(d), 5) == per * 5
+    small = W.EcapaConfig(channels=256, mfa_channels=768)
+    w = W.synthetic_weights(4, small)
+    rng = np.random.default_rng(0)
+    lay_s, _ = WP.calib_layout(small)
+    means = {n: rng.uniform(0, 1, c) for n, c, _ in lay_s}
+    bc = WP.bias_corrections(w, means, small)
+    name = "blk2.res2net.3"
+    wk = w[f"{name}.conv.w"].astype(np.float64)
+    dw = wk - WP.bf16_bits_to_f32(WP.f32_to_bf16_bits(w[f"{name}.conv.w"])).astype(np.float64)
+    want = w[f"{name}.conv.b"].astype(np.float64) + np.einsum("nkj,k->n", dw, means[name])
+    assert np.allclose(bc[name], want, rtol=0, atol=1e-7)
+    wa = w["asp.tdnn.conv.w"][:, :768, 0].astype(np.float64)
+    dwa = wa - WP.bf16_bits_to_f32(WP.f32_to_bf16_bits(wa.astype(np.float32))).astype(np.float64)
+    assert np.allclose(bc["asp.tdnn"], w["asp.tdnn.conv.b"] + dwa @ means["asp.tdnn"], rtol=0, atol=1e-7)
+    blob, f = WP.pack_weights(w, small)
+    for n in ("blk1.tdnn1", "blk3.res2net.6", "blk2.tdnn2", "mfa", "asp.tdnn"):
+        o = f["off"][WP.bias_slot(n, small)]
+        nb = w[f"{n}.conv.b"].shape[0]
+        assert np.array_equal(blob[o:o + 4 * nb].view(np.float32), w[f"{n}.conv.b"]), n

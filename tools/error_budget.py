@@ -44,6 +44,11 @@ def budget(n_seg=64, n_prof=100, verbose=True, rows=None):
     plan += [(f"only {s} at bf16", {s: 8}, torch.float64, feats) for s in S]
     plan += [(f"all but {s} at bf16", {t: 8 for t in S if t != s}, torch.float64, feats) for s in S]
     plan += [("ALL sites at bf16 (= the model the kernels implement)", {t: 8 for t in S}, torch.float64, feats)]
+    # which LAYERS' weights: every site at bf16, but one group of weights as a bf16 hi+lo pair (16 bits) - and the reverse
+    allb = {t: 8 for t in S}
+    plan += [(f"all at bf16, but the {g} weights as hi+lo pairs (16 bits)", dict(allb, **{f"w:{g}": 16}), torch.float64, feats) for g in oe.WEIGHT_GROUPS]
+    plan += [("all at bf16, but the res2net + tdnn2 + tdnn1 weights as hi+lo pairs", dict(allb, **{"w:res2net": 16, "w:tdnn2": 16, "w:tdnn1": 16}), torch.float64, feats)]
+    plan += [("all at bf16, ALL weights as hi+lo pairs EXCEPT res2net", dict(allb, w=16, **{"w:res2net": 8}), torch.float64, feats)]
     plan += [(f"ALL sites at {b} significand bits ({what})", {t: b for t in S}, torch.float64, feats)
              for b, what in ((11, "fp16 storage and operands"), (16, "bf16 hi+lo pairs"), (19, "for scale"), (22, "fp16 hi+lo pairs"))]
     plan += [("weights at 22 bits, activations exact (fp16 hi+lo weights, fp32 activations)", {"w": 22}, torch.float64, feats)]
