@@ -14,7 +14,9 @@ Environment:
   SDK_ECAPA_LAYOUT    "public": SDK_ECAPA_WEIGHTS is a checkpoint in the public ECAPA-TDNN state-dict naming (.ckpt / .pt via
                       torch.load(weights_only=True), .safetensors, .npz); SDK_ECAPA_PREFIX strips a key prefix
   SDK_WINDOW_S / SDK_HOP_S   analysis window / hop in seconds (default 2.0 / 1.0)
-  SDK_PRECISION       0 (default: bf16 operands, scores within ~4e-3 of the fp32 model) / 1 (precise mode: fp16 hi+lo planes, within 1e-5,
+  SDK_BIAS_CORRECTION 1 (default) / 0: fold the constant part of the bf16 weight-rounding error into the layer biases (one calibration pass at the
+                      first load of a weight set, cached): scores within ~8e-4 of the fp32 model instead of ~4e-3, no run-time cost
+  SDK_PRECISION       0 (default: bf16 operands) / 1 (precise mode: fp16 hi+lo planes, within 1e-5,
                       ~3.6x the step time).  Both modes embed into the SAME space (they differ from each other at the 4e-3 level), so
                       model_version does not depend on it
 """

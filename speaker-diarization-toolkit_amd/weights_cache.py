@@ -57,8 +57,8 @@ def load_meta(key: str) -> Optional[dict]:
         return None
 
 
-def load_blob(key: str, precision: int) -> Optional[Tuple[np.ndarray, dict]]:
-    """(memory-mapped blob, descriptor fields) or None."""
+def load_blob(key: str, precision) -> Optional[Tuple[np.ndarray, dict]]:
+    """(memory-mapped blob, descriptor fields) or None.  `precision`: 0 / 1, or "0c" for the default mode's bias-corrected blob."""
     m = load_meta(key)
     if not m or str(precision) not in m.get("fields", {}):
         return None
@@ -72,7 +72,7 @@ def load_blob(key: str, precision: int) -> Optional[Tuple[np.ndarray, dict]]:
     # the descriptor's offsets are dereferenced on the device: never trust an entry whose table points outside the blob, and never a blob
     # whose bytes are not the ones the table was written for (one SHA-256 pass over ~50 MB: 30 ms, against 2 s of generate + digest + pack)
     off = f.get("off")
-    if (not isinstance(off, list) or len(off) != 256 or f.get("precision") != precision
+    if (not isinstance(off, list) or len(off) != 256 or f.get("precision") != int(str(precision).rstrip("c"))      # ("0c" = default mode, bias-corrected)
             or any(not isinstance(o, int) or o < -1 or (o >= 0 and (o % 256 or o >= blob.size)) for o in off)):
         return None
     if hashlib.sha256(blob).hexdigest() != f.get("_sha256"):

@@ -288,6 +288,10 @@ def test_packed_blob_cache_roundtrip_and_backend_digest(tmp_path, monkeypatch):
         got, gf = wc.load_blob(key, prec)
         assert np.array_equal(np.asarray(got), blob) and gf == f and isinstance(got, np.memmap)
     assert wc.load_meta(key)["digest"] == "abc123abc123" and set(wc.load_meta(key)["fields"]) == {"0", "1"}
+    blob0, f0 = WP.pack_weights(w, cfg, precision=0)
+    wc.store(key, "abc123abc123", "0c", blob0, f0)                          # the bias-corrected blob of the default mode: its own entry
+    got, gf = wc.load_blob(key, "0c")
+    assert np.array_equal(np.asarray(got), blob0) and gf["precision"] == 0 and set(wc.load_meta(key)["fields"]) == {"0", "1", "0c"}
     # a flipped byte in the blob, or an offset table that points outside it, is a miss (the offsets are dereferenced on the device)
     fn = tmp_path / "cache" / f"{key}.p1.npy"
     raw = bytearray(fn.read_bytes()); raw[-7] ^= 0x40; fn.write_bytes(bytes(raw))
