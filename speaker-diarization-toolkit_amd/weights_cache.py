@@ -19,7 +19,7 @@ from typing import Dict, Optional, Tuple
 
 import numpy as np
 
-FORMAT = 4          # bump when weights_pack.py's layout changes: old entries are then ignored
+FORMAT = 5          # bump when weights_pack.py's layout changes: old entries are then ignored
 
 
 def enabled() -> bool:
