@@ -77,7 +77,18 @@ __device__ __forceinline__ void insert_sorted(float x, float* m) {
 __device__ __forceinline__ float max3(float a, float b, float c) { return fmaxf(fmaxf(a, b), c); }
 
 // WAVES waves x SEGB blocks of 32 segments; TPS tiles per LDS stage; NSTAGE stages.
-template <int WAVES, int SEGB, int TPS, int NSTAGE>
+// PIPE (round 3, A/B knob `affinity_variant` 3, NOT the default): the row/column-maxima arithmetic of tile t-1 issued in the shadow of tile t's
+// MFMAs.  Plain form: a tile is 24 MFMAs, then ~60 vector instructions that need the last MFMA's result.  PIPE carries the finished accumulators
+// to the next tile (across the stage barrier too; two register sets written alternately) and deals the 58 reduction operations out by hand, 2-3
+// behind every MFMA, each slice closed by a sched_barrier.  Same operations on the same values in the same tile order: records bit-identical
+// (tests/test_gpu_kernels.py::test_affinity_pipelined_variant_is_bit_identical).  Measured, interleaved A/B (tools/aff_bench.py,
+// profiles/r03_aff_pipelined_ab.txt): config #3 50.5 vs 48.4 us, 125k x 10k 398 vs 377 us - SLOWER by 4-6 %.  The two waves of a SIMD already
+// overlap one wave's vector phase with the other's MFMAs (MI355X_MICROARCH.md "Two waves per SIMD": moving work between them is zero-sum), and the
+// per-MFMA issue budget (8 cycles for the MFMA + 4 per vector instruction, both waves) has no room for the extra address arithmetic the 256-register
+// budget forces (DMA source offsets re-derived per stage instead of kept in 6 registers).  A 4-wave form with 128 segments per wave and 512 registers
+// (one wave per SIMD, each fragment read feeding 4 MFMAs) was built too: hipcc keeps the segment fragments in AGPRs and copies them out before every MFMA
+// (4 v_accvgpr_read per MFMA, 18 registers spilled): 63 us / 582 us, removed.
+template <int WAVES, int SEGB, int TPS, int NSTAGE, bool PIPE>
 __global__ __launch_bounds__(WAVES * 64, 2) void aff_rowcol_kernel(const bf16_t* __restrict__ Eb, const bf16_t* __restrict__ Pb,
                                                                int N, int P, Geom gm, float* __restrict__ stats,
                                                                int32_t* __restrict__ part_base, int32_t* __restrict__ part_cnt,
@@ -104,22 +115,33 @@ __global__ __launch_bounds__(WAVES * 64, 2) void aff_rowcol_kernel(const bf16_t*
   const int ntiles = (P + PT - 1) / PT;
 
   // DMA assignment: a stage is DMA_PER_STAGE wave-instructions of 1 KiB; wave w issues instructions w*DPW .. w*DPW+DPW-1
+  // PIPE has no registers to spare for the per-lane source offsets (they were spilled and re-read from scratch after every barrier - and a
+  // scratch read waits on vmcnt in order, i.e. for the DMAs in flight): there they are re-derived from the lane number at every issue (~25
+  // vector instructions per stage; the empty asm keeps the compiler from hoisting them out of the loop again).
   int drow[DPW], dsrc[DPW];
+  auto dma_geom = [&](int ln, int i, int& row, int& src) {
+    const int id = (wid * DPW + i) * 64 + ln;
+    row = id / 24;
+    const int pos = id - row * 24;
+    src = ((pos & ~7) | ((pos & 7) ^ ((row >> 1) & 7))) * 8;    // source chunk (elements)
+  };
+  if constexpr (!PIPE) {
 #pragma unroll
-  for (int i = 0; i < DPW; ++i) {
-    const int id = (wid * DPW + i) * 64 + lane;
-    const int row = id / 24, pos = id - row * 24;
-    drow[i] = row;
-    dsrc[i] = ((pos & ~7) | ((pos & 7) ^ ((row >> 1) & 7))) * 8;    // source chunk (elements)
+    for (int i = 0; i < DPW; ++i) dma_geom(lane, i, drow[i], dsrc[i]);
   }
   int s_issue = (int)(u0 % nst), k_issue = 0;
   auto issue = [&]() {                                               // next stage of the running sequence
     char* st = sP + (k_issue % NSTAGE) * STAGE_BYTES;
+    int ln = lane;
+    if constexpr (PIPE) asm volatile("" : "+v"(ln));
 #pragma unroll
     for (int i = 0; i < DPW; ++i) {
-      int pr = s_issue * (TPS * PT) + drow[i];
+      int row, src;
+      if constexpr (PIPE) dma_geom(ln, i, row, src);
+      else { row = drow[i]; src = dsrc[i]; }
+      int pr = s_issue * (TPS * PT) + row;
       pr = pr < P ? pr : P - 1;
-      __builtin_amdgcn_global_load_lds((const void __attribute__((address_space(1)))*)(Pb + (int64_t)pr * D + dsrc[i]),
+      __builtin_amdgcn_global_load_lds((const void __attribute__((address_space(1)))*)(Pb + (int64_t)pr * D + src),
                                        (void __attribute__((address_space(3)))*)(st + (wid * DPW + i) * 1024), 16, 0, 0);
     }
     ++k_issue;
@@ -136,6 +158,27 @@ __global__ __launch_bounds__(WAVES * 64, 2) void aff_rowcol_kernel(const bf16_t*
   bf16x8 bfrag[SEGB][KS];
   float C[SEGB][16], tl[SEGB][4];
   int ltile = 0;
+  f32x16 accp[SEGB], accq[SEGB];         // PIPE: accp = the previous stage's last tile, not yet reduced (2 EMPTY = nothing pending: reducing it changes nothing)
+  int ptag = 0;
+  auto clear_pending = [&]() {
+#pragma unroll
+    for (int sb = 0; sb < SEGB; ++sb)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) accp[sb][r] = 2.f * EMPTY;      // below every list entry: inserting it is a no-op
+    ptag = 0;
+  };
+  auto reduce = [&](const f32x16* ac, int tag) {
+#pragma unroll
+    for (int sb = 0; sb < SEGB; ++sb) {
+      const f32x16& a = ac[sb];
+      const float m0 = max3(a[0], a[1], a[2]), m1 = max3(a[3], a[4], a[5]), m2 = max3(a[6], a[7], a[8]);
+      const float m3 = max3(a[9], a[10], a[11]), m4 = max3(a[12], a[13], a[14]);
+      const float T = fmaxf(max3(m0, m1, m2), max3(m3, m4, a[15]));
+#pragma unroll
+      for (int r = 0; r < 16; ++r) C[sb][r] = fmaxf(C[sb][r], a[r]);
+      insert_sorted<4>(__uint_as_float((__float_as_uint(T) & ~TMASK) | (uint32_t)tag), tl[sb]);
+    }
+  };
   auto begin_portion = [&]() {
 #pragma unroll
     for (int sb = 0; sb < SEGB; ++sb) {
@@ -150,6 +193,7 @@ __global__ __launch_bounds__(WAVES * 64, 2) void aff_rowcol_kernel(const bf16_t*
       for (int q = 0; q < 4; ++q) tl[sb][q] = EMPTY;
     }
     ltile = 0;
+    if constexpr (PIPE) clear_pending();
     if (tid == 0) {
       if (slot < MAXP) part_base[b * MAXP + slot] = s * TPS;    // (a 4th part cannot happen - plan_geometry, tests/test_cabi_cpu.py - and would
                                                                 //  not go unnoticed: part_cnt > MAXP sends the group's rows to the exact rescan)
@@ -184,6 +228,70 @@ __global__ __launch_bounds__(WAVES * 64, 2) void aff_rowcol_kernel(const bf16_t*
   int aoff[4];
 #pragma unroll
   for (int q = 0; q < 4; ++q) aoff[q] = col * PROWB + (((2 * q + h) ^ rsw) << 4);
+  auto mask_partial = [&](int tile, f32x16* acc) {
+    if ((tile + 1) * PT > P) {                     // last, partial tile: rows past the last profile never count
+#pragma unroll
+      for (int sb = 0; sb < SEGB; ++sb)
+#pragma unroll
+        for (int r = 0; r < 16; ++r)
+          if (tile * PT + (r & 3) + 8 * (r >> 2) + 4 * h >= P) acc[sb][r] = MASKED;
+    }
+  };
+  const char* sq[4];
+  // PIPE: the MFMAs of `tile` into out[], the reduction of prev[] (tile - 1, tag ptg) between their issues.  The reduction is written as
+  // 29 single operations per segment block and dealt out by hand, 2-3 behind every MFMA, each slice closed by a sched_barrier: the compiler's own
+  // interleaving (sched_group_barrier over the whole tile) filled the first ten MFMA shadows and left 35 operations after the last MFMA.
+  auto pipe_tile = [&](const int tt, const int tile, f32x16* out, const f32x16* prev, const int ptg) {
+    float t[SEGB][8], nl[SEGB][4];
+    auto op = [&](const int sb, const int j) {       // j is a compile-time constant after unrolling
+      const f32x16& a = prev[sb];
+      float* c = C[sb];
+      float* m = tl[sb];
+      if (j < 16) c[j] = fmaxf(c[j], a[j]);
+      else if (j < 21) t[sb][j - 16] = max3(a[3 * (j - 16)], a[3 * (j - 16) + 1], a[3 * (j - 16) + 2]);
+      else if (j == 21) t[sb][5] = max3(t[sb][0], t[sb][1], t[sb][2]);
+      else if (j == 22) t[sb][6] = max3(t[sb][3], t[sb][4], a[15]);
+      else if (j == 23) t[sb][7] = fmaxf(t[sb][5], t[sb][6]);
+      else if (j == 24) t[sb][7] = __uint_as_float((__float_as_uint(t[sb][7]) & ~TMASK) | (uint32_t)ptg);
+      else if (j == 25) nl[sb][3] = __builtin_amdgcn_fmed3f(t[sb][7], m[2], m[3]);
+      else if (j == 26) nl[sb][2] = __builtin_amdgcn_fmed3f(t[sb][7], m[1], m[2]);
+      else if (j == 27) nl[sb][1] = __builtin_amdgcn_fmed3f(t[sb][7], m[0], m[1]);
+      else { nl[sb][0] = fmaxf(t[sb][7], m[0]); m[0] = nl[sb][0]; m[1] = nl[sb][1]; m[2] = nl[sb][2]; m[3] = nl[sb][3]; }
+    };
+    constexpr int NOPS = 29 * SEGB, NMF = KS * SEGB, AHEADR = 2;
+    bf16x8 a[KS];
+#pragma unroll
+    for (int ks = 0; ks < AHEADR; ++ks) a[ks] = *reinterpret_cast<const bf16x8*>(sq[ks & 3] + tt * TILE_BYTES + (ks >> 2) * 128);
+    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+    for (int i = 0; i < NMF; ++i) {
+      const int ks = i / SEGB, sb = i % SEGB;
+      if (sb == 0 && ks + AHEADR < KS)
+        a[ks + AHEADR] = *reinterpret_cast<const bf16x8*>(sq[(ks + AHEADR) & 3] + tt * TILE_BYTES + ((ks + AHEADR) >> 2) * 128);
+      if (ks == 0) {
+        f32x16 z;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) z[r] = 0.f;
+        out[sb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[ks], bfrag[sb][ks], z, 0, 0, 0);
+      } else {
+        out[sb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[ks], bfrag[sb][ks], out[sb], 0, 0, 0);
+      }
+      // operations [i NOPS / NMF, (i + 1) NOPS / NMF) of the flat list (block 0's 29, then block 1's ...)
+#pragma unroll
+      for (int o = i * NOPS / NMF; o < (i + 1) * NOPS / NMF; ++o) op(o / 29, o % 29);
+      __builtin_amdgcn_sched_barrier(0);
+    }
+    // pins: the reduction ends HERE (IR-level sinking would otherwise move it to its uses, past the next branch)
+#pragma unroll
+    for (int sb = 0; sb < SEGB; ++sb) {
+      float* c = C[sb];
+      asm volatile("" : "+v"(c[0]), "+v"(c[1]), "+v"(c[2]), "+v"(c[3]), "+v"(c[4]), "+v"(c[5]), "+v"(c[6]), "+v"(c[7]), "+v"(c[8]), "+v"(c[9]),
+                   "+v"(c[10]), "+v"(c[11]), "+v"(c[12]), "+v"(c[13]), "+v"(c[14]), "+v"(c[15]), "+v"(tl[sb][0]), "+v"(tl[sb][1]), "+v"(tl[sb][2]),
+                   "+v"(tl[sb][3]), "+v"(out[sb]));
+    }
+    __builtin_amdgcn_sched_barrier(0);
+    mask_partial(tile, out);
+  };
   int k = 0;
   long long u = u0;
   while (u < u1) {                                 // one portion = this workgroup's share of one group's sweep
@@ -213,47 +321,48 @@ __global__ __launch_bounds__(WAVES * 64, 2) void aff_rowcol_kernel(const bf16_t*
       // Fragment addresses: chunk c = 2 ks + h of this lane's row sits at 16 * ((c & ~7) | ((c & 7) ^ rsw)); its low three
       // bits depend only on ks & 3, so four per-lane offsets + compile-time immediates (tile, ks >> 2) cover all 12 reads of
       // every tile.  (Left to the compiler, the XOR was re-derived per read: ~50 of the ~118 vector instructions per tile.)
-      const char* sq[4];
 #pragma unroll
       for (int q = 0; q < 4; ++q) sq[q] = sP + (k % NSTAGE) * STAGE_BYTES + aoff[q];
+      if constexpr (PIPE) {
+        // two named accumulator sets, written alternately (no register copies): tile 2 s -> accq while accp is reduced, tile 2 s + 1 -> accp
+        // while accq is reduced.  A stage exists only if its first tile does.
+        static_assert(!PIPE || TPS == 2, "the pipelined form alternates two accumulator sets");
+        const int tile0 = s * TPS;
+        pipe_tile(0, tile0, accq, accp, ptag);
+        const int tag0 = ltile++;
+        if (tile0 + 1 < ntiles) {                    // wave-uniform
+          pipe_tile(1, tile0 + 1, accp, accq, tag0);
+          ptag = ltile++;
+        } else {                                     // odd tile count: nothing follows in this sweep - reduce now, leave "nothing pending"
+          reduce(accq, tag0);
+          clear_pending();
+        }
+      } else {
 #pragma unroll
-      for (int tt = 0; tt < TPS; ++tt) {
-        const int tile = s * TPS + tt;
-        if (tile < ntiles) {                         // wave-uniform
-          f32x16 acc[SEGB];
-#pragma unroll
-          for (int sb = 0; sb < SEGB; ++sb)
-#pragma unroll
-            for (int r = 0; r < 16; ++r) acc[sb][r] = 0.f;
-#pragma unroll
-          for (int ks = 0; ks < KS; ++ks) {
-            const bf16x8 a = *reinterpret_cast<const bf16x8*>(sq[ks & 3] + tt * TILE_BYTES + (ks >> 2) * 128);
-#pragma unroll
-            for (int sb = 0; sb < SEGB; ++sb) acc[sb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, bfrag[sb][ks], acc[sb], 0, 0, 0);
-          }
-          if ((tile + 1) * PT > P) {                 // last, partial tile: rows past the last profile never count
+        for (int tt = 0; tt < TPS; ++tt) {
+          const int tile = s * TPS + tt;
+          if (tile < ntiles) {                         // wave-uniform
+            f32x16 acc[SEGB];
 #pragma unroll
             for (int sb = 0; sb < SEGB; ++sb)
 #pragma unroll
-              for (int r = 0; r < 16; ++r)
-                if (tile * PT + (r & 3) + 8 * (r >> 2) + 4 * h >= P) acc[sb][r] = MASKED;
-          }
+              for (int r = 0; r < 16; ++r) acc[sb][r] = 0.f;
 #pragma unroll
-          for (int sb = 0; sb < SEGB; ++sb) {
-            const f32x16& a = acc[sb];
-            const float m0 = max3(a[0], a[1], a[2]), m1 = max3(a[3], a[4], a[5]), m2 = max3(a[6], a[7], a[8]);
-            const float m3 = max3(a[9], a[10], a[11]), m4 = max3(a[12], a[13], a[14]);
-            const float T = fmaxf(max3(m0, m1, m2), max3(m3, m4, a[15]));
+            for (int ks = 0; ks < KS; ++ks) {
+              const bf16x8 a = *reinterpret_cast<const bf16x8*>(sq[ks & 3] + tt * TILE_BYTES + (ks >> 2) * 128);
 #pragma unroll
-            for (int r = 0; r < 16; ++r) C[sb][r] = fmaxf(C[sb][r], a[r]);
-            insert_sorted<4>(__uint_as_float((__float_as_uint(T) & ~TMASK) | (uint32_t)ltile), tl[sb]);
+              for (int sb = 0; sb < SEGB; ++sb) acc[sb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, bfrag[sb][ks], acc[sb], 0, 0, 0);
+            }
+            mask_partial(tile, acc);
+            reduce(acc, ltile);
+            ++ltile;
           }
-          ++ltile;
         }
       }
       ++s;
     }
     stamp();
+    if constexpr (PIPE) reduce(accp, ptag);         // drain the last tile
     end_portion(s == nst);
     if (s == nst) { ++b; s = 0; slot = 0; }         // the next portion starts a new group
   }
@@ -636,14 +745,14 @@ Geom plan_geometry(int N, int P, int segs, int tps, long long max_wg, int whole_
   return gm;
 }
 
-template <int WAVES, int SEGB, int TPS, int NSTAGE>
+template <int WAVES, int SEGB, int TPS, int NSTAGE, bool PIPE = false>
 int launch_coarse(sdk_ctx* ctx, const bf16_t* Eb, const bf16_t* Pb, int N, int P, const Ws& w, hipStream_t s, int wg_per_cu,
                   int* segs) {
   constexpr int SEGS = WAVES * SEGB * 32;
   constexpr int LDS = NSTAGE * TPS * TILE_BYTES;
   *segs = SEGS;
   const Geom gm = plan_geometry(N, P, SEGS, TPS, (long long)ctx->num_cu * wg_per_cu, ctx->aff_whole_groups, ctx->aff_boundary_pen);
-  auto kern = aff_rowcol_kernel<WAVES, SEGB, TPS, NSTAGE>;
+  auto kern = aff_rowcol_kernel<WAVES, SEGB, TPS, NSTAGE, PIPE>;
   if (sdk_lds_optin(ctx, (const void*)kern, LDS)) return 1;
   hipLaunchKernelGGL(kern, dim3(gm.G), dim3(WAVES * 64), LDS, s, Eb, Pb, N, P, gm, w.stats, w.part_base, w.part_cnt, w.flag_count,
                      (unsigned long long*)ctx->dbg_ptr);
@@ -691,6 +800,7 @@ int aff_rowcol_top1(sdk_ctx* ctx, const float* E, const uint16_t* Eb, const floa
     switch (ctx->aff_variant) {
       case 1: rc = launch_coarse<8, 2, 4, 3>(ctx, (const bf16_t*)Eb, (const bf16_t*)Pb, N, Pn, w, s, 1, &segs); break;
       case 2: rc = launch_coarse<4, 2, 2, 3>(ctx, (const bf16_t*)Eb, (const bf16_t*)Pb, N, Pn, w, s, 2, &segs); break;
+      case 3: rc = launch_coarse<8, 2, 2, 4, true>(ctx, (const bf16_t*)Eb, (const bf16_t*)Pb, N, Pn, w, s, 1, &segs); break;
       default: rc = launch_coarse<8, 2, 2, 4>(ctx, (const bf16_t*)Eb, (const bf16_t*)Pb, N, Pn, w, s, 1, &segs); break;
     }
     if (rc) return rc;

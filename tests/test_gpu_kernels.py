@@ -428,6 +428,22 @@ def test_affinity_rescan_is_deterministic_and_sliced(engine):
             assert np.array_equal(idx, ref[0]) and np.array_equal(sc, ref[1]), f"run {rep} differs"
 
 
+@pytest.mark.parametrize("N,P", [(5000, 1000), (2000, 1025), (3001, 31), (700, 2500)])
+def test_affinity_pipelined_variant_is_bit_identical(engine, N, P):
+    """`affinity_variant` 3 issues the row/column-maxima arithmetic of tile t - 1 between the MFMAs of tile t (carried over stage barriers and
+    drained at the end of a portion; odd tile counts take the "nothing pending" branch): same operations on the same values in the same
+    order, so indices, scores and the number of rescanned rows must equal the default kernel's exactly - partial last tile, odd and even
+    tile counts, P below one stage, sweeps split over workgroups."""
+    E, Pm = _unit(N, 192, N + P), _unit(P, 192, 7 * P + 1)
+    ref = _score_gpu(engine, E, Pm, 1)
+    engine.set_option("affinity_variant", 3)
+    try:
+        got = _score_gpu(engine, E, Pm, 1)
+    finally:
+        engine.set_option("affinity_variant", 0)
+    assert np.array_equal(got[0], ref[0]) and np.array_equal(got[1], ref[1]) and got[2] == ref[2]
+
+
 def test_affinity_threshold_assignment(engine):
     """Config #2 shape: 1000 segments x 100 profiles, threshold 0.354 (the ABC default)."""
     E, Pm = _unit(1000, 192, 0), _unit(100, 192, 1)

@@ -7,7 +7,7 @@ import torch
 sys.path.insert(0, str(Path(__file__).resolve().parent.parent))
 ops = importlib.import_module("speaker-diarization-toolkit_amd.ops")
 eng = ops.get_engine(0)
-VARIANTS = [("general", 0, 0, 0), ("rowcol", 1, 0, 0), ("rowcol whole-groups", 1, 0, 1), ("rowcol 4-tile stages", 1, 1, 0)]
+VARIANTS = [("general", 0, 0, 0), ("rowcol", 1, 0, 0), ("rowcol pipelined", 1, 3, 0), ("rowcol pipelined 4-wave", 1, 4, 0), ("rowcol whole-groups", 1, 0, 1)]
 shapes = [(100_000, 1000), (125_000, 10_000)] if len(sys.argv) < 2 else [tuple(int(x) for x in a.split("x")) for a in sys.argv[1:]]
 for N3, P3 in shapes:
     E3, E3b, r3 = eng.l2norm(torch.randn(N3, 192, device="cuda", generator=torch.Generator(device="cuda").manual_seed(3)))
@@ -50,6 +50,6 @@ for N3, P3 in shapes:
         keys = res[name][0].keys()
         med = {k: sorted(r[k] for r in res[name])[len(res[name]) // 2] for k in keys}
         tot = sum(med.values())
-        print(f"{N3}x{P3} {name:10s} " + " ".join(f"{k.replace('affinity_', '')}={v:.1f}" for k, v in med.items()) +
+        print(f"{N3}x{P3} {name:24s} " + " ".join(f"{k.replace('affinity_', '')}={v:.1f}" for k, v in med.items()) +
               f" total={tot:.1f} us  coarse {2 * N3 * P3 * 192 / med['affinity_coarse'] / 1e6:.0f} TF  total {2 * N3 * P3 * 192 / tot / 1e6:.0f} TF", flush=True)
 eng.set_option("affinity_fast_path", 1); eng.set_option("affinity_variant", 0); eng.set_option("affinity_whole_groups", 0)
