@@ -9,6 +9,9 @@ library or without a gfx950 device the first compute call raises (the CLIs print
 
 Environment:
   SDK_DEVICE          GPU index (default: $LOCAL_RANK, else 0)
+  SDK_MODEL           "ecapa" (default: ECAPA-TDNN C = 1024) / "xvector" (plain TDNN x-vector, xvector.py): the second model family north_star names.
+                      Same front end, same 192-d back end (k3 / k4 / store); model_version names the family, so vectors enrolled with one are
+                      refused by the other (store.load_profile_batch).  SDK_XVECTOR_WEIGHTS: .npz in the xvector.py naming (default: seeded synthetic)
   SDK_ECAPA_WEIGHTS   .npz checkpoint in the weights.py naming (default: seeded synthetic weights -
                       there is no network here to fetch a pretrained model; a warning is printed)
   SDK_ECAPA_LAYOUT    "public": SDK_ECAPA_WEIGHTS is a checkpoint in the public ECAPA-TDNN state-dict naming (.ckpt / .pt via
@@ -38,11 +41,16 @@ from .weights import DEFAULT_CONFIG, load_weights, synthetic_weights, weights_di
 
 class Backend(EmbeddingBackend):
     def __init__(self) -> None:
-        if not os.environ.get("SDK_ECAPA_WEIGHTS"):
-            print("mi355x backend: SDK_ECAPA_WEIGHTS not set - using seeded synthetic ECAPA-TDNN weights "
+        self.model = os.environ.get("SDK_MODEL", "ecapa").strip().lower()
+        if self.model not in ("ecapa", "xvector"):
+            raise ValueError(f"SDK_MODEL={self.model!r}: expected 'ecapa' or 'xvector'")
+        wenv = "SDK_XVECTOR_WEIGHTS" if self.model == "xvector" else "SDK_ECAPA_WEIGHTS"
+        if not os.environ.get(wenv):
+            print(f"mi355x backend: {wenv} not set - using seeded synthetic {'x-vector' if self.model == 'xvector' else 'ECAPA-TDNN'} weights "
                   "(scores are self-consistent but not trained)", file=sys.stderr)
         self._cache_hit = False
         self._engine = None
+        self._xvector = None
         self._weights = None
         self._digest: Optional[str] = None
         self.window_s = float(os.environ.get("SDK_WINDOW_S", "2.0"))
@@ -59,10 +67,16 @@ class Backend(EmbeddingBackend):
 
     @property
     def embedding_dim(self) -> Optional[int]:
+        if self.model == "xvector":
+            from .xvector import DEFAULT_XVECTOR
+            return DEFAULT_XVECTOR.embed_dim
         return DEFAULT_CONFIG.embed_dim
 
     @property
     def model_version(self) -> str:
+        if self.model == "xvector":
+            from .xvector import DEFAULT_XVECTOR
+            return f"{self.name}-xvector{DEFAULT_XVECTOR.channels[0]}-{self._weights_digest()}"
         return f"{self.name}-ecapa1024-{self._weights_digest()}"
 
     @property
@@ -71,6 +85,15 @@ class Backend(EmbeddingBackend):
 
     # ---- lazily built state --------------------------------------------------------------
     def _host_weights(self):
+        if self._weights is None and self.model == "xvector":
+            from . import xvector
+            path = os.environ.get("SDK_XVECTOR_WEIGHTS")
+            if path:
+                with np.load(path, allow_pickle=False) as z:             # numpy's non-executing loader
+                    self._weights = {k: np.ascontiguousarray(z[k], dtype=np.float32) for k in z.files}
+                xvector.pack_weights(self._weights)                      # shape check (raises ValueError naming the tensor)
+            else:
+                self._weights = xvector.synthetic_weights(0)
         if self._weights is None:
             path = os.environ.get("SDK_ECAPA_WEIGHTS")
             if path:
@@ -88,6 +111,8 @@ class Backend(EmbeddingBackend):
     def _cache_key(self) -> str:
         """Identity of the weights for the packed-blob cache, without reading them (weights_cache.py)."""
         from . import weights_cache
+        if self.model == "xvector":
+            return None                                  # 4.4 M parameters: packed in ~0.1 s, not cached
         path = os.environ.get("SDK_ECAPA_WEIGHTS")
         return weights_cache.key_for_file(path) if path else weights_cache.key_for_seed(0, DEFAULT_CONFIG)
 
@@ -96,7 +121,8 @@ class Backend(EmbeddingBackend):
         from the cache entry too: no 20.8 M-parameter generate / parse, no SHA-256 over 83 MB, no re-pack (cold start: tools/cold_start.py)."""
         if self._digest is None:
             from . import weights_cache
-            meta = weights_cache.load_meta(self._cache_key())
+            key = self._cache_key()
+            meta = weights_cache.load_meta(key) if key else None
             if meta and meta.get("digest") and self._weights is None:
                 self._digest = meta["digest"]
                 self._cache_hit = True
@@ -108,11 +134,23 @@ class Backend(EmbeddingBackend):
         if self._engine is None:
             from .ops import Engine   # imports torch + dlopens libsdk_hip.so; raises SdkError if absent
             dev = int(os.environ.get("SDK_DEVICE", os.environ.get("LOCAL_RANK", "0")))
+            if self.model == "xvector":
+                if int(os.environ.get("SDK_PRECISION", "0")):
+                    raise ValueError("SDK_PRECISION=1 (precise mode) exists for the ECAPA-TDNN family only")
+                from .xvector import XVector
+                self._engine = Engine(dev)               # front end, k3, k4; its ECAPA weights are never packed (lazy)
+                self._xvector = XVector(self._engine, self._host_weights())
+                return self._engine
             self._engine = Engine(dev, cache_key=self._cache_key(), weights_fn=self._host_weights, digest_fn=self._weights_digest)
             prec = int(os.environ.get("SDK_PRECISION", "0"))
             if prec:
                 self._engine.set_precision(prec)
         return self._engine
+
+    def _embed_pcm(self, pcm_dev):
+        """[B, S] int16 device tensor -> (E fp32, Eb bf16, resid): the selected model family's fbank -> forward -> L2 sequence."""
+        eng = self.engine()
+        return self._xvector.embed_pcm(pcm_dev) if self._xvector is not None else eng.embed_pcm(pcm_dev)
 
     # ---- the GPU path ----------------------------------------------------------------------
     def embed_windows(self, pcm: np.ndarray):
@@ -123,8 +161,8 @@ class Backend(EmbeddingBackend):
         eng = self.engine()
         step = max(1, int(os.environ.get("SDK_MAX_BATCH", "2048")))
         if pcm.shape[0] <= step:
-            return eng.embed_pcm(torch.from_numpy(np.ascontiguousarray(pcm)).to(eng.device))
-        parts = [eng.embed_pcm(torch.from_numpy(np.ascontiguousarray(pcm[a:a + step])).to(eng.device))
+            return self._embed_pcm(torch.from_numpy(np.ascontiguousarray(pcm)).to(eng.device))
+        parts = [self._embed_pcm(torch.from_numpy(np.ascontiguousarray(pcm[a:a + step])).to(eng.device))
                  for a in range(0, pcm.shape[0], step)]
         return tuple(torch.cat([p[i] for p in parts], dim=0) for i in range(3))
 

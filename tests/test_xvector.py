@@ -106,3 +106,82 @@ def test_xvector_pcm_to_assignment(engine):
             xv.forward(torch.zeros(201, 192, dtype=torch.float16, device="cuda"), 1, 201)
     finally:
         engine.set_precision(0)
+
+
+def test_backend_model_selection_metadata(monkeypatch):
+    """SDK_MODEL selects the family behind the SAME plug-in class (base.py:291-293: zero-arg constructible); model_version names it, so the
+    reference's prefix rule (base.py:92-93) accepts both and store.load_profile_batch's exact match keeps the two spaces apart."""
+    B = sub("backend")
+    monkeypatch.setenv("SDK_MODEL", "xvector")
+    be = B.Backend()
+    assert be.model == "xvector" and be.embedding_dim == 192 and be.name == "mi355x"
+    mv = be.model_version
+    assert mv.startswith("mi355x-xvector512-") and len(mv.split("-")[-1]) == 12 and mv == B.Backend().model_version
+    assert be.check_embedding_compatibility({"model_version": mv})["compatible"] is True
+    monkeypatch.setenv("SDK_MODEL", "ecapa")
+    assert B.Backend().model == "ecapa"
+    monkeypatch.setenv("SDK_MODEL", "resnet")
+    with pytest.raises(ValueError, match="SDK_MODEL"):
+        B.Backend()
+
+
+def test_backend_xvector_weight_file(monkeypatch, tmp_path):
+    B = sub("backend")
+    cfg = XV.DEFAULT_XVECTOR
+    w = XV.synthetic_weights(5, cfg)
+    np.savez(tmp_path / "xv.npz", **w)
+    monkeypatch.setenv("SDK_MODEL", "xvector")
+    monkeypatch.setenv("SDK_XVECTOR_WEIGHTS", str(tmp_path / "xv.npz"))
+    be = B.Backend()
+    assert be.model_version == f"mi355x-xvector512-{sub('weights').weights_digest(w)}"
+    bad = dict(w); bad["embed.w"] = bad["embed.w"][:, :-1]
+    np.savez(tmp_path / "bad.npz", **bad)
+    monkeypatch.setenv("SDK_XVECTOR_WEIGHTS", str(tmp_path / "bad.npz"))
+    with pytest.raises(ValueError, match="embed.w"):
+        B.Backend().model_version
+
+
+@pytest.mark.gpu
+def test_backend_xvector_enroll_identify_roundtrip(tmp_path, monkeypatch):
+    """The x-vector family through the drop-in boundary (enroll_speaker / identify_speaker, base.py:107-151): stored vectors and window
+    scores against the oracle's x-vector on the same windows; vectors enrolled with it are refused by the ECAPA-TDNN configuration."""
+    from oracle import fbank as ofbank
+    from test_gpu_backend_e2e import _voice
+    wav = sub("wav")
+    monkeypatch.setenv("SPEAKERS_EMBEDDINGS_DIR", str(tmp_path / "store"))
+    monkeypatch.setenv("SDK_MODEL", "xvector")
+    be = sub("backend").Backend()
+    w = XV.synthetic_weights(0)
+
+    def oracle_embed(pcm):
+        return oecapa.l2_normalise(oxv.xvector_embed(w, torch.from_numpy(ofbank.fbank(pcm)), mode="bf16").numpy())
+
+    profiles = []
+    for i, (sid, f0) in enumerate({"alice": 140.0, "bob": 95.0}.items()):
+        path = tmp_path / f"enroll_{sid}.wav"
+        wav.write_wav_s16(path, _voice(10 + i, 6.0, f0))
+        rec = be.enroll_speaker(path, [(0.5, 5.5)])
+        assert rec["model_version"] == be.model_version and rec["model_version"].startswith("mi355x-xvector512-") and rec["embedding_dim"] == 192
+        profiles.append({"id": sid, "names": {"default": sid}, "embeddings": {"mi355x": [
+            {"id": f"emb-{sid}", "external_id": rec["external_id"], "model_version": rec["model_version"], "trust_level": "high"}]}})
+        pcm, _ = wav.cut_windows(wav.read_wav_s16(path), [(0.5, 5.5)])
+        e = oracle_embed(pcm).astype(np.float64).mean(0)
+        assert float(np.load(rec["file"]) @ (e / np.linalg.norm(e))) > 1 - 1e-4, "stored enrollment vector vs the x-vector oracle"
+    tpath = tmp_path / "meeting.wav"
+    wav.write_wav_s16(tpath, np.concatenate([_voice(40, 4.0, 95.0), _voice(41, 4.0, 140.0)]))
+    rows = be.identify_speaker(tpath, profiles, threshold=-1.0)
+    assert {r["speaker_id"] for r in rows} == {"alice", "bob"} and all(r["confidence"] == r["similarity"] for r in rows)
+    pcm, _ = wav.cut_windows(wav.read_wav_s16(tpath), None)
+    Eo = oracle_embed(pcm)
+    E, Eb, re = be.embed_windows(pcm)
+    assert ((E.cpu().numpy().astype(np.float64) * Eo).sum(1) > 1 - 1e-4).all()
+    batch = sub("store").load_profile_batch(profiles, "mi355x", model_prefix="mi355x-", model_version=be.model_version)
+    gidx, gsc = be.score_windows(E, Eb, re, batch)
+    oidx, osc = oscoring.affinity_topk(Eo, oecapa.l2_normalise(batch.matrix), 1)
+    full = np.sort(oscoring.affinity(Eo, oecapa.l2_normalise(batch.matrix)), axis=1)
+    clear = (full[:, -1] - full[:, -2]) > 1e-3
+    assert np.array_equal(gidx[clear, 0], oidx[clear, 0]) and np.abs(gsc[:, 0] - osc[:, 0])[clear].max() < 5e-4
+    # the other family must not compare against these vectors: same backend name, other model_version
+    monkeypatch.setenv("SDK_MODEL", "ecapa")
+    with pytest.raises(ValueError, match="enrolled under other weights"):
+        sub("backend").Backend().identify_speaker(tpath, profiles)
