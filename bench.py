@@ -187,6 +187,44 @@ def precision_modes(eng, pcm, pcm_host, P_host, Pn, Pb, rpm, default_value, defa
                             "give 2.3e-5, 22 bits (fp16 pairs) 1.5e-7"}
 
 
+def xvector_object(eng, pcm, pcm_host, P_host, Pn, Pb, rpm, n_par=16):
+    """The second model family north_star names (plain-TDNN x-vector, xvector.py / sdk_xvector_forward) on the same 1000 resident segments and
+    100 profiles, outside the timed region: throughput, its kernels, and cos / score deviation from its oracle's bf16 model on `n_par` segments."""
+    from oracle import ecapa as oecapa, fbank as ofbank, xvector as oxv
+    XV = importlib.import_module(f"{PKG}.xvector")
+    w = XV.synthetic_weights(0)
+    xv = XV.XVector(eng, w)
+    B = pcm.shape[0]
+
+    def step():
+        E, Eb, re = xv.embed_pcm(pcm)
+        return E, eng.affinity_topk(E, Eb, re, Pn, Pb, rpm, k=1)
+    for _ in range(2):
+        step()
+    torch.cuda.synchronize()
+    reps = 10
+    t0 = time.perf_counter()
+    for _ in range(reps):
+        E, (gi, gs) = step()
+    torch.cuda.synchronize()
+    ms = (time.perf_counter() - t0) / reps * 1e3
+    eng.profile_begin()
+    step()
+    prof = eng.profile_end()
+    m = min(n_par, B)
+    Eo = oecapa.l2_normalise(oxv.xvector_embed(w, torch.from_numpy(ofbank.fbank(pcm_host[:m])), mode="bf16").numpy())
+    par = parity_object(E[:m].cpu().numpy(), gi[:m, 0].cpu().numpy(), gs[:m, 0].cpu().numpy(), Eo, P_host)
+    mac = XV.DEFAULT_XVECTOR.macs_per_frame()
+    T = importlib.import_module(f"{PKG}.ops").num_frames(pcm.shape[1])
+    gemm_ms = sum(prof[k]["ms"] for k in ("conv_gemm256", "conv_gemm") if k in prof)
+    return {"model": "x-vector 512-512-512-512-1500, statistics pooling, 192-d (SDK_MODEL=xvector)", "value": round(B / ms * 1e3, 1), "unit": "segment-embeddings/sec",
+            "ms_per_step": round(ms, 3), "steps_timed": reps, "gflop_per_segment": round(2.0 * mac * T / 1e9, 3),
+            "frame_layers_ms": round(gemm_ms, 3), "frame_layers_tflops": round(2.0 * mac * T * B / (gemm_ms * 1e-3) / 1e12, 1) if gemm_ms else None,
+            "kernels_ms": {k: round(v["ms"], 3) for k, v in prof.items()},
+            "parity_vs_bf16_oracle": {"segments": m, "min_cos_embedding": par["min_cos_embedding"], "max_abs_dscore_all_pairs": par["max_abs_dscore_all_pairs"],
+                                      "id_mismatches": par["id_mismatches"]}}
+
+
 def cold_start_object(timeout_s=120):
     """Time to the first identify row in a fresh process (tools/cold_start.py), once with an empty packed-blob cache and once with the
     entry the first run wrote.  Child processes: they initialise the GPU themselves; this process never re-execs."""
@@ -210,8 +248,9 @@ def cold_start_object(timeout_s=120):
 def main() -> int:
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=10)
-    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=5)
+    ap.add_argument("--prewarm", type=int, default=30, help="minimum number of untimed steps BEFORE the W warm-up steps (they also run until the process is 2.5 s old: start-up stall, see the comment in main); 0 = none")
     ap.add_argument("--segments", type=int, default=1000, help="segments per GPU (config #2: 1000)")
     ap.add_argument("--profiles", type=int, default=100)
     ap.add_argument("--no-cpu-baseline", action="store_true")
@@ -245,6 +284,7 @@ def main() -> int:
     ops = importlib.import_module(f"{PKG}.ops")
     sdist = importlib.import_module(f"{PKG}.dist")
     _lib = importlib.import_module(f"{PKG}._lib")
+    t_ctx = time.perf_counter()
     eng = ops.get_engine(local)
     info = _lib.device_info(local)
     dev = eng.device
@@ -265,6 +305,21 @@ def main() -> int:
             sdist._gather_into(gathered, E)                   # k5: the embedding exchange (RCCL over xGMI): ONE all_gather_into_tensor
         return idx, sc
 
+    # A fresh process stalls ONCE, for 60-85 ms, about 1.4 s after it created its GPU context - whatever it is doing then (tools/step_jitter.py,
+    # profiles/r03_step_jitter.json: the 2nd or 3rd synchronised step of a process takes 69-87 ms instead of 8.7; a process that sleeps through that
+    # moment never sees it; weight-cache hit / miss / off make no difference; no later step is affected over 6000 launches).  With a 0.1-0.2 s timed
+    # region the stall lands inside it at random (one headline in eight read 63 k instead of 112 k).  So before the contract's W warm-up steps the
+    # process runs the same step untimed until it is PREWARM_AGE_S old and has done `--prewarm` steps (no collective in these: the ranks' counts may
+    # differ); the count is reported as `prewarm_steps`.
+    PREWARM_AGE_S = 2.5
+    prewarm_steps = 0
+    if args.prewarm > 0 and not os.environ.get("SDK_BENCH_PMC"):      # counter passes want exactly warmup + steps passes
+        while prewarm_steps < args.prewarm or time.perf_counter() - t_ctx < PREWARM_AGE_S:
+            step(exchange=False)
+            prewarm_steps += 1
+            if prewarm_steps % 8 == 0:
+                torch.cuda.synchronize()
+        torch.cuda.synchronize()
     for _ in range(args.warmup):
         step()
 
@@ -458,7 +513,7 @@ def main() -> int:
 
         out = {
             "metric": "segment-embeddings/sec", "value": round(value, 2), "unit": "segment-embeddings/sec",
-            "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(ms_step, 3),
+            "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "prewarm_steps": prewarm_steps, "ms_per_step": round(ms_step, 3),
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "bf16", "data": "synthetic",
             "config": {"workload": "config #2: 1k synthetic 2-s segments/GPU -> fbank -> ECAPA-TDNN C=1024 -> L2 -> cosine argmax vs 100 profiles",
                        "segments_per_gpu": B, "profiles": args.profiles, "embed_dim": 192, "frames_per_segment": T_FRAMES,
@@ -507,6 +562,10 @@ def main() -> int:
                 out["precision_modes"] = precision_modes(eng, pcm, pcm_host, P_host, Pn, Pb, rpm, value, ms_step, out.get("parity"))
             except Exception as exc:  # noqa: BLE001
                 out["precision_modes"] = {"error": repr(exc)[:300]}
+            try:
+                out["xvector"] = xvector_object(eng, pcm, pcm_host, P_host, Pn, Pb, rpm)
+            except Exception as exc:  # noqa: BLE001
+                out["xvector"] = {"error": repr(exc)[:300]}
             out["cold_start"] = cold_start_object()
         print(json.dumps(out), flush=True)
 
