@@ -37,4 +37,10 @@ for rep in range(8):
     torch.cuda.synchronize(); t0 = time.perf_counter()
     for _ in range(10): step()
     torch.cuda.synchronize(); pattern.append(round((time.perf_counter() - t0) * 100, 3))
+long_run = []
+t_l = time.perf_counter()
+while time.perf_counter() - t_l < 8.0:             # any later stall?  (age of the process, step time) of every step > 2x the usual
+    t0 = time.perf_counter(); step(); torch.cuda.synchronize(); dt = (time.perf_counter() - t0) * 1e3
+    if dt > 18.0: long_run.append((round(t0 - t_start, 3), round(dt, 2)))
+print(json.dumps({"long_run_8s_slow_steps": long_run}))
 print(json.dumps({"setup_s": round(t_ready - t_start, 2), "single_step_ms": single, "w3_k10_ms_per_step": pattern}))
