@@ -7,7 +7,6 @@ as the GPU sweep computes it from the stored tensor), embedding layer in fp32.
 """
 from __future__ import annotations
 
-import numpy as np
 import torch
 
 from .ecapa import BN_EPS, _bf16, reflect_index

@@ -22,7 +22,7 @@ ranks with an oracle-backed provider.
 from __future__ import annotations
 
 from dataclasses import dataclass
-from typing import Optional, Tuple
+from typing import Optional
 
 import numpy as np
 import torch

@@ -9,7 +9,6 @@ import sys
 from pathlib import Path
 from typing import Any, Dict, List, Optional
 
-from . import BACKEND_NAME
 from .assign import rows_with_trust
 
 

@@ -16,7 +16,6 @@ import numpy as np
 import torch
 
 from . import cluster as scluster
-from . import dist as sdist
 
 
 @dataclass

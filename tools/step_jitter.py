@@ -3,7 +3,6 @@
 (b) then bench.py's own pattern (W un-synchronised warm-up steps, fence, K steps, fence) repeated."""
 import importlib, json, sys, time
 from pathlib import Path
-import numpy as np
 import torch
 sys.path.insert(0, str(Path(__file__).resolve().parent.parent))
 bench = importlib.import_module("bench")
