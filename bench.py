@@ -233,15 +233,16 @@ def cold_start_object(timeout_s=120):
     with tempfile.TemporaryDirectory(prefix="sdk_cache_") as cache:
         env = dict(os.environ, SDK_CACHE_DIR=cache, HSA_ENABLE_IPC_MODE_LEGACY="0")
         env.pop("SDK_ECAPA_WEIGHTS", None)
-        for label in ("first_process_empty_cache", "second_process_cache_hit"):
+        for label, extra in (("first_process_empty_cache", []), ("second_process_cache_hit", []), ("third_process_cache_hit_no_torch", ["--lite"])):
             try:
-                r = subprocess.run([sys.executable, str(ROOT / "tools" / "cold_start.py")], env=env, capture_output=True, text=True, timeout=timeout_s)
+                r = subprocess.run([sys.executable, str(ROOT / "tools" / "cold_start.py")] + extra, env=env, capture_output=True, text=True, timeout=timeout_s)
                 line = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
                 out[label] = json.loads(line[-1]) if line else {"error": (r.stderr or "no output")[-300:]}
             except Exception as exc:  # noqa: BLE001
                 out[label] = {"error": repr(exc)[:300]}
     out["note"] = ("fresh Python process through plugin_api.get_backend('mi355x'): import, weights (generate / cache), digest, pack, upload, first enroll + identify of a "
-                   "12-s WAV (code-object load), second identify; the reference builds its backend once per CLI process (base.py:272-293)")
+                   "12-s WAV (code-object load), second identify; the reference builds its backend once per CLI process (base.py:272-293); the third process takes the "
+                   "torch-free host path (SDK_NO_TORCH=1, lite.py): same library calls, no `import torch`")
     return out
 
 

@@ -21,6 +21,7 @@
  *
  * STABLE SURFACE - what a backend binds (INTEGRATION.md shows the stub); SDK_ABI_VERSION changes when any of these does:
  *     sdk_abi_version  sdk_init  sdk_shutdown  sdk_last_error  sdk_get_device_info
+ *     sdk_device_malloc  sdk_device_free  sdk_memcpy  sdk_stream_synchronize          device memory for hosts without an allocator of their own
  *     sdk_resample_out_len  sdk_resample_s16                                   audio -> AudioProfile format
  *     sdk_fbank_tables_bytes  sdk_fbank_tables_fill  sdk_fbank_workspace_bytes  sdk_fbank              k1
  *     sdk_ecapa_workspace_bytes  sdk_ecapa_forward  sdk_ecapa_calib_floats  sdk_ecapa_forward_calib            k2
@@ -66,6 +67,14 @@ int sdk_init(int device, sdk_ctx** out);
 int sdk_shutdown(sdk_ctx* ctx);
 const char* sdk_last_error(void);
 int sdk_get_device_info(sdk_ctx* ctx, sdk_device_info* out);
+/* Device memory for hosts that bring no allocator (a C / C++ binding; the torch-free Python path lite.py that serves a one-recording CLI
+ * call without the 0.8-s `import torch` - the reference constructs its backend fresh in every process, base.py:291-293).  sdk_memcpy: kind 1 =
+ * host -> device, 2 = device -> host, 3 = device -> device; ordered on `stream` and COMPLETE when the call returns (the one entry point that
+ * synchronises, next to sdk_stream_synchronize).  Pointers from any other allocator of the same HIP runtime (torch tensors) work equally. */
+int sdk_device_malloc(sdk_ctx* ctx, size_t bytes, void** out);
+int sdk_device_free(sdk_ctx* ctx, void* p);
+int sdk_memcpy(sdk_ctx* ctx, void* dst, const void* src, size_t bytes, int kind, void* stream);
+int sdk_stream_synchronize(sdk_ctx* ctx, void* stream);
 /* A/B and test knobs: "res2net_chain_fusion" (1 default / 0 = seven conv_gemm launches), "res2net_packed_weights" (1 default /
  * 0 = the chain ignores the blob's optional fragment-ordered weight copies, ecapa_layout.h EL_CHAINPACK), "res2net_two_per_cu" (1 default /
  * 0 = 8-wave workgroups, one segment per CU), "asp_packed_weights"

@@ -4,6 +4,8 @@ There is no CPU fallback: if the shared library has not been built, or no gfx950
 present, every entry point raises.  torch is imported first on purpose - it brings the HIP
 runtime (libamdhip64.so.7) into the process, and libsdk_hip.so binds to that same runtime, so
 torch tensors' device pointers and torch's streams are valid inside the library.
+Exception: SDK_NO_TORCH=1 (the torch-free path, lite.py): torch is NOT imported - the library then binds to the system HIP
+runtime and device memory comes from sdk_device_malloc; such a process must never import torch afterwards.
 """
 from __future__ import annotations
 
@@ -11,7 +13,8 @@ import ctypes as C
 import os
 from pathlib import Path
 
-import torch  # noqa: F401  (must precede loading libsdk_hip.so, see module docstring)
+if os.environ.get("SDK_NO_TORCH") != "1":
+    import torch  # noqa: F401  (must precede loading libsdk_hip.so, see module docstring)
 
 _HERE = Path(__file__).resolve().parent
 LIB_PATH = Path(os.environ.get("SDK_HIP_LIB", _HERE / "libsdk_hip.so"))
@@ -125,6 +128,10 @@ SIGNATURES = {
     "sdk_kmeans_mindist": (_i, [_vp, _vp, _i, _i, _vp, _vp, _i, _vp]),
     "sdk_kmeans_assign": (_i, [_vp, _vp, _i, _i, _vp, _i, _vp, _vp, _vp, _vp, _vp]),
     "sdk_affinity_topk": (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _vp, _vp, _vp, _vp, _sz, _vp]),
+    "sdk_device_malloc": (_i, [_vp, _sz, C.POINTER(C.c_void_p)]),
+    "sdk_device_free": (_i, [_vp, _vp]),
+    "sdk_memcpy": (_i, [_vp, _vp, _vp, _sz, _i, _vp]),
+    "sdk_stream_synchronize": (_i, [_vp, _vp]),
 }
 
 _lib = None

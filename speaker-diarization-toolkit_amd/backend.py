@@ -17,6 +17,9 @@ Environment:
   SDK_ECAPA_LAYOUT    "public": SDK_ECAPA_WEIGHTS is a checkpoint in the public ECAPA-TDNN state-dict naming (.ckpt / .pt via
                       torch.load(weights_only=True), .safetensors, .npz); SDK_ECAPA_PREFIX strips a key prefix
   SDK_WINDOW_S / SDK_HOP_S   analysis window / hop in seconds (default 2.0 / 1.0)
+  SDK_NO_TORCH        1: the torch-free host path (lite.py) for enroll / identify / verify: same library calls, numpy on the host, device memory
+                      from sdk_device_malloc - a warm-cache CLI process reaches its first row without the 0.8-s `import torch`.  The packed
+                      weights come from the on-disk cache; a missing entry is built once in a child process (through the torch engine)
   SDK_BIAS_CORRECTION 1 (default) / 0: fold the constant part of the bf16 weight-rounding error into the layer biases (one calibration pass at the
                       first load of a weight set, cached): scores within ~8e-4 of the fp32 model instead of ~4e-3, no run-time cost
   SDK_PRECISION       0 (default: bf16 operands) / 1 (precise mode: fp16 hi+lo planes, within 1e-5,
@@ -130,7 +133,39 @@ class Backend(EmbeddingBackend):
                 self._digest = weights_digest(self._host_weights())
         return self._digest
 
+    @property
+    def lite(self) -> bool:
+        return os.environ.get("SDK_NO_TORCH") == "1"
+
+    def _lite_engine(self):
+        """lite.LiteEngine on the cached packed weights; a cache miss is filled ONCE by a child process that runs the torch engine (pack, bias-correction
+        calibration pass, store) - this process must not import torch itself (one HIP runtime per process)."""
+        from .lite import LiteEngine
+        dev = int(os.environ.get("SDK_DEVICE", os.environ.get("LOCAL_RANK", "0")))
+        if int(os.environ.get("SDK_PRECISION", "0")):
+            raise ValueError("SDK_NO_TORCH=1 serves the default numerical contract only (SDK_PRECISION=1 needs the torch engine)")
+        if self.model == "xvector":
+            eng = LiteEngine(dev)
+            eng.load_xvector(self._host_weights())
+            return eng
+        eng = LiteEngine(dev, cache_key=self._cache_key())
+        if not eng.has_cached_weights():
+            import subprocess
+            root = str(Path(__file__).resolve().parent.parent)
+            env = {k: v for k, v in os.environ.items() if k != "SDK_NO_TORCH"}
+            env["PYTHONPATH"] = root + os.pathsep + env.get("PYTHONPATH", "")
+            code = f"import importlib; b = importlib.import_module('{__package__}.backend').Backend(); b.engine().desc"
+            r = subprocess.run([sys.executable, "-c", code], env=env, capture_output=True, text=True)
+            if r.returncode != 0 or not eng.has_cached_weights():
+                raise RuntimeError("SDK_NO_TORCH=1: building the packed-weight cache entry in a child process failed "
+                                   f"(is the cache writable? SDK_CACHE_DIR / SDK_WEIGHTS_CACHE): {r.stderr.strip()[-400:]}")
+        eng.load_weights()
+        self._cache_hit = eng.cache_hit
+        return eng
+
     def engine(self):
+        if self._engine is None and self.lite:
+            self._engine = self._lite_engine()
         if self._engine is None:
             from .ops import Engine   # imports torch + dlopens libsdk_hip.so; raises SdkError if absent
             dev = int(os.environ.get("SDK_DEVICE", os.environ.get("LOCAL_RANK", "0")))
@@ -157,14 +192,30 @@ class Backend(EmbeddingBackend):
         """pcm [B, S] int16 (host) -> torch device tensors (E fp32, Eb bf16, resid).
         Recordings of any length: the forward's scratch is ~6.7 MB per 2-s window, so the windows go through in batches
         of SDK_MAX_BATCH (default 2048 = 13.7 GB of scratch; a 1-h file at a 1-s hop is two batches)."""
-        import torch
         eng = self.engine()
         step = max(1, int(os.environ.get("SDK_MAX_BATCH", "2048")))
+        if self.lite:
+            raise RuntimeError("embed_windows returns device tensors: not available with SDK_NO_TORCH=1 (use embed_windows_host)")
+        import torch
         if pcm.shape[0] <= step:
             return self._embed_pcm(torch.from_numpy(np.ascontiguousarray(pcm)).to(eng.device))
         parts = [self._embed_pcm(torch.from_numpy(np.ascontiguousarray(pcm[a:a + step])).to(eng.device))
                  for a in range(0, pcm.shape[0], step)]
         return tuple(torch.cat([p[i] for p in parts], dim=0) for i in range(3))
+
+    def embed_windows_host(self, pcm: np.ndarray, profiles: Optional[np.ndarray] = None, k: int = 1):
+        """pcm [B, S] int16 -> unit-norm embeddings [B, d] fp32 on the HOST and, when `profiles` [P, d] is given, the cosine top-k of every window
+        (idx [B, k] int32, score [B, k] fp32) - the torch-free form of embed_windows + score_windows (SDK_NO_TORCH=1), same bounded batches."""
+        eng = self.engine()
+        step = max(1, int(os.environ.get("SDK_MAX_BATCH", "2048")))
+        Es, idxs, scs = [], [], []
+        for a in range(0, pcm.shape[0], step):
+            Es.append(eng.embed_pcm(pcm[a:a + step]))
+            if profiles is not None:
+                i, s_ = eng.score_last(profiles, k)
+                idxs.append(i); scs.append(s_)
+        E = np.concatenate(Es) if Es else np.zeros((0, self.embedding_dim), np.float32)
+        return (E, np.concatenate(idxs), np.concatenate(scs)) if profiles is not None else (E, None, None)
 
     def _windows(self, audio_path: Path, segments):
         samples = decode_to_profile(Path(audio_path), self.engine(), self.get_audio_profile())   # other rates / layouts: GPU resampler
@@ -202,14 +253,24 @@ class Backend(EmbeddingBackend):
     def enroll_speaker(self, audio_path: Path, segments: Optional[List[Tuple[float, float]]] = None) -> Dict[str, Any]:
         if segments:           # the caller vouches that each range is this speaker: true-length windows, never widened
             samples = decode_to_profile(Path(audio_path), self.engine(), self.get_audio_profile())
-            E, _, _, spans, _ = self.embed_ranges(samples, list(segments))
+            if self.lite:
+                pcm_by_len, wins, _ = cut_ranges(samples, list(segments), hop_s=self.hop_s)
+                parts = {S: self.embed_windows_host(pcm)[0] for S, pcm in pcm_by_len.items()}
+                spans = [(ri, a, b) for ri, _, _, a, b in wins]
+                E = np.stack([parts[S][row] for _, S, row, _, _ in wins]) if wins else None
+            else:
+                E, _, _, spans, _ = self.embed_ranges(samples, list(segments))
             if not spans:
                 raise ValueError(f"{audio_path}: no analysable audio (every segment shorter than 0.5 s)")
         else:
             pcm, spans = self._windows(audio_path, None)
-            E, _, _ = self.embed_windows(pcm)
-        mean = E.double().mean(dim=0)
-        vec = (mean / mean.norm().clamp_min(1e-12)).float().cpu().numpy()
+            E = self.embed_windows_host(pcm)[0] if self.lite else self.embed_windows(pcm)[0]
+        if self.lite:
+            mean = E.astype(np.float64).mean(axis=0)
+            vec = (mean / max(float(np.linalg.norm(mean)), 1e-12)).astype(np.float32)
+        else:
+            mean = E.double().mean(dim=0)
+            vec = (mean / mean.norm().clamp_min(1e-12)).float().cpu().numpy()
         ext = save_vector(vec)
         return {
             "external_id": ext,                      # the only backend field cmd_enroll persists (speaker_detection:890-904)
@@ -242,8 +303,11 @@ class Backend(EmbeddingBackend):
         if len(batch) == 0:
             return []
         pcm, spans = self._windows(audio_path, None)
-        E, Eb, re = self.embed_windows(pcm)
-        idx, sc = self.score_windows(E, Eb, re, batch)
+        if self.lite:
+            _, idx, sc = self.embed_windows_host(pcm, batch.matrix)
+        else:
+            E, Eb, re = self.embed_windows(pcm)
+            idx, sc = self.score_windows(E, Eb, re, batch)
         return aggregate_matches(idx[:, 0], sc[:, 0], spans, batch, threshold)
 
     # ---- a3: verify - the CLI reads result['confidence'] (speaker_detection:1173-1174) ---------

@@ -59,6 +59,35 @@ int sdk_lds_optin(sdk_ctx* ctx, const void* func, int bytes) {
   return 0;
 }
 
+// ---- device memory for hosts that bring no allocator of their own (a C / C++ host, or the torch-free Python path lite.py) -----------
+extern "C" int sdk_device_malloc(sdk_ctx* ctx, size_t bytes, void** out) {
+  SDK_REQUIRE(ctx && out, "sdk_device_malloc: null argument");
+  *out = nullptr;
+  SDK_HIP_OK(hipSetDevice(ctx->device));
+  SDK_HIP_OK(hipMalloc(out, bytes ? bytes : 1));
+  return 0;
+}
+extern "C" int sdk_device_free(sdk_ctx* ctx, void* p) {
+  SDK_REQUIRE(ctx, "sdk_device_free: null context");
+  if (p) SDK_HIP_OK(hipFree(p));
+  return 0;
+}
+// kind 1 = host -> device, 2 = device -> host, 3 = device -> device; ordered on `stream`, and the call returns when the copy is complete
+extern "C" int sdk_memcpy(sdk_ctx* ctx, void* dst, const void* src, size_t bytes, int kind, void* stream) {
+  SDK_REQUIRE(ctx && (bytes == 0 || (dst && src)), "sdk_memcpy: null argument");
+  SDK_REQUIRE(kind >= 1 && kind <= 3, "sdk_memcpy: kind=%d (1 = host to device, 2 = device to host, 3 = device to device)", kind);
+  if (!bytes) return 0;
+  const hipMemcpyKind k = kind == 1 ? hipMemcpyHostToDevice : kind == 2 ? hipMemcpyDeviceToHost : hipMemcpyDeviceToDevice;
+  SDK_HIP_OK(hipMemcpyAsync(dst, src, bytes, k, (hipStream_t)stream));
+  SDK_HIP_OK(hipStreamSynchronize((hipStream_t)stream));
+  return 0;
+}
+extern "C" int sdk_stream_synchronize(sdk_ctx* ctx, void* stream) {
+  SDK_REQUIRE(ctx, "sdk_stream_synchronize: null context");
+  SDK_HIP_OK(hipStreamSynchronize((hipStream_t)stream));
+  return 0;
+}
+
 extern "C" int sdk_shutdown(sdk_ctx* ctx) {
   delete ctx;
   return 0;

@@ -1,0 +1,208 @@
+"""Torch-free host path for the toolkit's process model (SDK_NO_TORCH=1).
+
+The reference constructs its backend fresh in every CLI process (speaker_detection_backends/base.py:291-293) and runs up to four of
+them at once (speaker-process:627-629); of the 1.1 s a warm-cache process needs to its first identify row, 0.8 s is `import torch`.
+This module drives the SAME library calls as ops.Engine (fbank -> ECAPA-TDNN / x-vector forward -> L2 -> cosine top-k, and the audio
+resampler) with numpy on the host side and device memory from the library itself (sdk_device_malloc / sdk_memcpy): no torch, no second
+allocator.  Everything runs on the null stream; sdk_memcpy completes before it returns, so results are ready when they reach numpy.
+
+Scope: what Backend.enroll_speaker / identify_speaker / verify_speaker need.  It takes the packed (bias-corrected) weight blob from the
+on-disk cache (weights_cache.py); when the entry is missing the caller (backend.py) builds it once in a child process through the torch
+engine.  Clustering (k6), multi-GPU and the tuning tools stay on ops.Engine.  A process that uses this module must never import torch
+(two HIP runtimes in one process).
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+from typing import Dict, Optional, Tuple
+
+import numpy as np
+
+os.environ.setdefault("SDK_NO_TORCH", "1")      # before ._lib is imported: it must not pull torch in
+from . import _lib                              # noqa: E402
+from ._lib import EcapaDesc, SdkError, check    # noqa: E402
+from .weights import DEFAULT_CONFIG, EcapaConfig  # noqa: E402
+from .weights_pack import N_MELS_PADDED         # noqa: E402
+
+HOP = 160
+H2D, D2H = 1, 2
+
+
+def num_frames(n_samples: int) -> int:
+    return 1 + n_samples // HOP
+
+
+class DevBuf:
+    """A device allocation owned by this object (sdk_device_malloc / sdk_device_free)."""
+
+    def __init__(self, eng: "LiteEngine", nbytes: int):
+        self.eng, self.nbytes = eng, int(nbytes)
+        p = C.c_void_p()
+        check(eng.lib.sdk_device_malloc(eng.ctx, self.nbytes, C.byref(p)), "sdk_device_malloc")
+        self.ptr = p.value
+
+    def upload(self, host: np.ndarray) -> "DevBuf":
+        host = np.ascontiguousarray(host)
+        if host.nbytes > self.nbytes:
+            raise SdkError(f"upload of {host.nbytes} bytes into a {self.nbytes}-byte device buffer")
+        check(self.eng.lib.sdk_memcpy(self.eng.ctx, self.ptr, host.ctypes.data, host.nbytes, H2D, None), "sdk_memcpy")
+        return self
+
+    def download(self, dtype, shape) -> np.ndarray:
+        out = np.empty(shape, dtype=dtype)
+        if out.nbytes > self.nbytes:
+            raise SdkError(f"download of {out.nbytes} bytes from a {self.nbytes}-byte device buffer")
+        check(self.eng.lib.sdk_memcpy(self.eng.ctx, out.ctypes.data, self.ptr, out.nbytes, D2H, None), "sdk_memcpy")
+        return out
+
+    def free(self) -> None:
+        if self.ptr:
+            self.eng.lib.sdk_device_free(self.eng.ctx, self.ptr)
+            self.ptr = None
+
+    def __del__(self):  # noqa: D105
+        try:
+            self.free()
+        except Exception:  # noqa: BLE001  (interpreter shutdown)
+            pass
+
+
+class LiteEngine:
+    """Resident state of one process on one GPU: context, fbank tables, weight blob, growing scratch buffers."""
+
+    def __init__(self, device: int = 0, cache_key: Optional[str] = None, cfg: EcapaConfig = DEFAULT_CONFIG,
+                 bias_correction: Optional[bool] = None):
+        self.lib = _lib.load_library()
+        self.ctx = _lib.get_ctx(device)
+        self.cfg = cfg
+        self._cache_key = cache_key
+        self.bias_correction = (os.environ.get("SDK_BIAS_CORRECTION", "1") != "0") if bias_correction is None else bool(bias_correction)
+        self._scratch: Dict[str, DevBuf] = {}
+        self._tabs: Optional[DevBuf] = None
+        self._blob: Optional[DevBuf] = None
+        self._desc: Optional[EcapaDesc] = None
+        self._xv = None                     # (DevBuf blob, XVectorDesc) when the x-vector family is loaded
+        self._taps: Dict[Tuple[int, int], DevBuf] = {}
+        self.cache_hit = False
+
+    # ---------------------------------------------------------------- resident state
+    def _buf(self, key: str, nbytes: int) -> DevBuf:
+        b = self._scratch.get(key)
+        if b is None or b.nbytes < nbytes:
+            if b is not None:
+                b.free()
+            self._scratch[key] = b = DevBuf(self, max(int(nbytes), 256))
+        return b
+
+    def _tables(self) -> DevBuf:
+        if self._tabs is None:
+            n = self.lib.sdk_fbank_tables_bytes()
+            host = np.zeros(n, dtype=np.uint8)
+            check(self.lib.sdk_fbank_tables_fill(host.ctypes.data, n), "sdk_fbank_tables_fill")
+            self._tabs = DevBuf(self, n).upload(host)
+        return self._tabs
+
+    def cache_entry_name(self):
+        return "0c" if self.bias_correction else 0
+
+    def has_cached_weights(self) -> bool:
+        from . import weights_cache
+        return bool(self._cache_key) and weights_cache.load_meta(self._cache_key) is not None and \
+            str(self.cache_entry_name()) in weights_cache.load_meta(self._cache_key).get("fields", {})
+
+    def load_weights(self) -> None:
+        """ECAPA-TDNN blob from the cache entry ops.Engine wrote (memory-mapped, validated, one upload)."""
+        if self._blob is not None:
+            return
+        from . import weights_cache
+        hit = weights_cache.load_blob(self._cache_key, self.cache_entry_name()) if self._cache_key else None
+        if hit is None:
+            raise SdkError("lite path: no cached packed weights for this model (backend.py builds the entry in a child process first)")
+        blob, f = hit
+        d = EcapaDesc()
+        for k, v in f.items():
+            if k == "dilation":
+                d.dilation = (C.c_int32 * 4)(*v)
+            elif k == "off":
+                d.off = (C.c_int64 * 256)(*v)
+            else:
+                setattr(d, k, v)
+        self._blob = DevBuf(self, blob.size).upload(np.asarray(blob))
+        self._desc = d
+        self.cache_hit = True
+
+    def load_xvector(self, weights: Dict[str, np.ndarray]) -> None:
+        from . import xvector
+        blob, desc = xvector.pack_weights(weights)
+        self._xv = (DevBuf(self, blob.size).upload(blob), desc)
+
+    # ---------------------------------------------------------------- the path (device buffers in, device buffers out)
+    def fbank(self, pcm_dev: DevBuf, B: int, S: int) -> DevBuf:
+        check(self.lib.sdk_set_option(self.ctx, b"precision", 0), "sdk_set_option")
+        T = num_frames(S)
+        feats = self._buf("feats", B * T * N_MELS_PADDED * 2)
+        ws = self._buf("fbank_ws", self.lib.sdk_fbank_workspace_bytes(B, S))
+        check(self.lib.sdk_fbank(self.ctx, pcm_dev.ptr, B, S, self._tables().ptr, feats.ptr, N_MELS_PADDED, ws.ptr, ws.nbytes, None), "sdk_fbank")
+        return feats
+
+    def forward(self, feats: DevBuf, B: int, T: int) -> DevBuf:
+        emb = self._buf("emb", B * self.cfg.embed_dim * 4)
+        if self._xv is not None:
+            blob, d = self._xv
+            ws = self._buf("fwd_ws", self.lib.sdk_xvector_workspace_bytes(C.byref(d), B, T))
+            check(self.lib.sdk_xvector_forward(self.ctx, blob.ptr, C.byref(d), feats.ptr, N_MELS_PADDED, B, T, ws.ptr, ws.nbytes, emb.ptr, None),
+                  "sdk_xvector_forward")
+        else:
+            self.load_weights()
+            ws = self._buf("fwd_ws", self.lib.sdk_ecapa_workspace_bytes(C.byref(self._desc), B, T))
+            check(self.lib.sdk_ecapa_forward(self.ctx, self._blob.ptr, C.byref(self._desc), feats.ptr, N_MELS_PADDED, B, T, ws.ptr, ws.nbytes,
+                                             emb.ptr, None), "sdk_ecapa_forward")
+        return emb
+
+    def l2norm(self, x: DevBuf, N: int, d: int, tag: str) -> Tuple[DevBuf, DevBuf, DevBuf]:
+        E, Eb, r = self._buf(tag + "_E", N * d * 4), self._buf(tag + "_Eb", N * d * 2), self._buf(tag + "_r", N * 4)
+        check(self.lib.sdk_l2norm(self.ctx, x.ptr, N, d, E.ptr, Eb.ptr, r.ptr, None), "sdk_l2norm")
+        return E, Eb, r
+
+    # ---------------------------------------------------------------- host-level entry points (numpy in, numpy out)
+    def embed_pcm(self, pcm: np.ndarray) -> np.ndarray:
+        """pcm [B, S] int16 -> unit-norm embeddings [B, d] fp32 (host); the device copies (E, Eb, resid) stay resident for score_last()."""
+        pcm = np.ascontiguousarray(pcm, dtype=np.int16)
+        B, S = pcm.shape
+        dev = self._buf("pcm", pcm.nbytes).upload(pcm)
+        emb = self.forward(self.fbank(dev, B, S), B, num_frames(S))
+        self._last = (self.l2norm(emb, B, self.cfg.embed_dim, "seg"), B)
+        return self._last[0][0].download(np.float32, (B, self.cfg.embed_dim))
+
+    def score_last(self, profiles: np.ndarray, k: int = 1) -> Tuple[np.ndarray, np.ndarray]:
+        """Cosine top-k of the segments of the last embed_pcm() call against `profiles` [P, d] fp32 -> (idx [B, k] int32, score [B, k] fp32)."""
+        (E, Eb, re), B = self._last
+        P = np.ascontiguousarray(profiles, dtype=np.float32)
+        Pn, d = P.shape
+        k = min(k, Pn)
+        Pd = self._buf("prof", P.nbytes).upload(P)
+        Pe, Pb, rp = self.l2norm(Pd, Pn, d, "prof")
+        rmax = self._buf("rpmax", 4).upload(np.array([rp.download(np.float32, (Pn,)).max()], dtype=np.float32))
+        idx, sc = self._buf("idx", B * k * 4), self._buf("sc", B * k * 4)
+        ws = self._buf("aff_ws", self.lib.sdk_affinity_workspace_bytes(B, Pn))
+        check(self.lib.sdk_affinity_topk(self.ctx, E.ptr, Eb.ptr, re.ptr, Pe.ptr, Pb.ptr, rmax.ptr, B, Pn, d, k, idx.ptr, sc.ptr, None,
+                                         ws.ptr, ws.nbytes, None), "sdk_affinity_topk")
+        return idx.download(np.int32, (B, k)), sc.download(np.float32, (B, k))
+
+    def resample_s16_host(self, x: np.ndarray, rate_in: int, rate_out: int = 16000) -> np.ndarray:
+        """x int16 [n] or [n, C] interleaved at rate_in -> mono int16 at rate_out (GPU integer polyphase FIR, bit-exact vs oracle/resample.py)."""
+        from . import resample
+        x = np.ascontiguousarray(x, dtype=np.int16)
+        n_in = x.shape[0]
+        ch = 1 if x.ndim == 1 else x.shape[1]
+        taps, L, M, K = resample.design_taps(int(rate_in), int(rate_out))
+        key = (int(rate_in), int(rate_out))
+        if key not in self._taps:
+            t = np.array(taps)
+            self._taps[key] = DevBuf(self, t.nbytes).upload(t)
+        n_out = resample.out_len(n_in, L, M)
+        xd = self._buf("rs_in", x.nbytes).upload(x)
+        yd = self._buf("rs_out", n_out * 2)
+        check(self.lib.sdk_resample_s16(self.ctx, xd.ptr, n_in, ch, self._taps[key].ptr, L, M, K, yd.ptr, n_out, None), "sdk_resample_s16")
+        return yd.download(np.int16, (n_out,))

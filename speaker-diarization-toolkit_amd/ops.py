@@ -259,6 +259,10 @@ class Engine:
               "sdk_resample_s16")
         return y
 
+    def resample_s16_host(self, x: np.ndarray, rate_in: int, rate_out: int = 16000) -> np.ndarray:
+        """Host arrays in and out (wav.decode_to_profile; lite.LiteEngine has the same method)."""
+        return self.resample_s16(torch.from_numpy(np.ascontiguousarray(x)).to(self.device), rate_in, rate_out).cpu().numpy()
+
     # ------------------------------------------------------------------ k1
     def _sync_precision(self) -> None:
         """The library context is shared by every Engine of a device (one per process and GPU): make it agree with THIS engine's numerical

@@ -110,15 +110,13 @@ def read_wav(path: Path, profile: Optional[AudioProfile] = None) -> Tuple[np.nda
 def decode_to_profile(path: Path, engine, profile: Optional[AudioProfile] = None) -> np.ndarray:
     """WAVE file -> mono int16 samples at the profile's rate.  Files already in the contract format are returned as
     read; anything else is down-mixed and resampled on the GPU (`sdk_resample_s16`, integer polyphase FIR)."""
-    import torch
     profile = profile or AudioProfile()
     x, rate = read_wav(path, profile)
     if rate == profile.sample_rate and x.shape[1] == profile.channels == 1:
         return np.ascontiguousarray(x[:, 0])
     if x.shape[0] == 0:
         return np.zeros((0,), dtype=np.int16)
-    y = engine.resample_s16(torch.from_numpy(np.ascontiguousarray(x)).to(engine.device), rate, profile.sample_rate)
-    return y.cpu().numpy()
+    return engine.resample_s16_host(np.ascontiguousarray(x), rate, profile.sample_rate)      # ops.Engine and lite.LiteEngine both have it
 
 
 def write_wav_s16(path: Path, samples: np.ndarray, rate: int = 16000) -> None:

@@ -5,7 +5,9 @@
 steady-state step.  Prints one JSON object with the phases in seconds.  Run it twice: the second process finds the packed blob in
 the on-disk cache (weights_cache.py) and skips generate / digest / pack.
 
-    python tools/cold_start.py [--seconds 12] [--no-cache]
+    python tools/cold_start.py [--seconds 12] [--no-cache] [--lite]
+
+--lite: the torch-free host path (SDK_NO_TORCH=1, lite.py): the same library calls without `import torch`.
 """
 import argparse, json, os, sys, tempfile, time
 t_proc = time.perf_counter()
@@ -15,9 +17,12 @@ sys.path.insert(0, str(ROOT))
 ap = argparse.ArgumentParser()
 ap.add_argument("--seconds", type=float, default=12.0)
 ap.add_argument("--no-cache", action="store_true")
+ap.add_argument("--lite", action="store_true")
 a = ap.parse_args()
 if a.no_cache:
     os.environ["SDK_WEIGHTS_CACHE"] = "0"
+if a.lite:
+    os.environ["SDK_NO_TORCH"] = "1"
 ph = {}
 def mark(name, t0):
     ph[name] = round(time.perf_counter() - t0, 4)
@@ -25,8 +30,10 @@ def mark(name, t0):
 
 t = time.perf_counter()
 import numpy as np
-import torch                                                    # noqa: F401
-t = mark("import_numpy_torch", t)
+if not a.lite:
+    import torch                                                # noqa: F401
+sync = (lambda: torch.cuda.synchronize()) if not a.lite else (lambda: None)      # the lite path's calls return host arrays: already complete
+t = mark("import_numpy_torch" if not a.lite else "import_numpy", t)
 import importlib
 api = importlib.import_module("speaker-diarization-toolkit_amd.plugin_api")
 wav = importlib.import_module("speaker-diarization-toolkit_amd.wav")
@@ -45,21 +52,22 @@ mv = be.model_version                                           # host weights (
 t = mark("weights_and_digest", t)
 eng = be.engine()
 t = mark("engine_ctx (dlopen, hipInit)", t)
-eng.desc                                                        # pack (or cache hit) + upload
-torch.cuda.synchronize()
+if not a.lite:
+    eng.desc                                                    # pack (or cache hit) + upload (lite: be.engine() did it - cache hit, or a child process built the entry)
+sync()
 t = mark("pack_and_upload", t)
 rec = be.enroll_speaker(tmp / "a.wav")                          # first GPU pass: code-object load, fbank tables, scratch allocation
-torch.cuda.synchronize()
+sync()
 t = mark("first_enroll (code objects, tables, scratch)", t)
 cand = [{"id": "a", "embeddings": {"mi355x": [{"id": "emb-a", "external_id": rec["external_id"], "model_version": rec["model_version"]}]}}]
 rows = be.identify_speaker(tmp / "a.wav", cand)
-torch.cuda.synchronize()
+sync()
 t = mark("first_identify", t)
 rows = be.identify_speaker(tmp / "a.wav", cand)
-torch.cuda.synchronize()
+sync()
 t = mark("second_identify", t)
 wc = importlib.import_module("speaker-diarization-toolkit_amd.weights_cache")
 out = {"phases_s": ph, "time_to_first_row_s": round(sum(v for k, v in ph.items() if k != "second_identify"), 3),
        "process_wall_s": round(time.perf_counter() - t_proc, 3), "audio_seconds": a.seconds, "windows": rows[0]["n_segments"] if rows else 0,
-       "cache": {"enabled": wc.enabled(), "dir": str(wc.cache_dir()), "hit": bool(getattr(be, "_cache_hit", False))}, "model_version": mv}
+       "cache": {"enabled": wc.enabled(), "dir": str(wc.cache_dir()), "hit": bool(getattr(be, "_cache_hit", False))}, "model_version": mv, "lite": bool(a.lite), "torch_imported": "torch" in sys.modules}
 print(json.dumps(out))
