@@ -11,9 +11,9 @@ n = int(sys.argv[1]) if len(sys.argv) > 1 else 4
 out = {}
 with tempfile.TemporaryDirectory(prefix="sdk_cache_") as cache:
     env = dict(os.environ, SDK_CACHE_DIR=cache, HSA_ENABLE_IPC_MODE_LEGACY="0")
-    def run(k):
+    def run(k, extra=()):
         t0 = time.perf_counter()
-        ps = [subprocess.Popen([sys.executable, str(ROOT / "tools" / "cold_start.py")], env=env, stdout=subprocess.PIPE, stderr=subprocess.DEVNULL, text=True) for _ in range(k)]
+        ps = [subprocess.Popen([sys.executable, str(ROOT / "tools" / "cold_start.py"), *extra], env=env, stdout=subprocess.PIPE, stderr=subprocess.DEVNULL, text=True) for _ in range(k)]
         res = []
         for p in ps:
             o, _ = p.communicate(timeout=300)
@@ -29,4 +29,10 @@ with tempfile.TemporaryDirectory(prefix="sdk_cache_") as cache:
                                      "first_enroll_s": [r.get("phases_s", {}).get("first_enroll (code objects, tables, scratch)") for r in rn],
                                      "second_identify_s": [r.get("phases_s", {}).get("second_identify") for r in rn],
                                      "same_model_version": len({r.get("model_version") for r in rn}) == 1}
+    wl, rl = run(1, ("--lite",))                       # the torch-free host path (SDK_NO_TORCH=1), same cache
+    wln, rln = run(n, ("--lite",))
+    out["alone_cache_hit_no_torch"] = {"wall_s": round(wl, 3), "time_to_first_row_s": rl[0].get("time_to_first_row_s")}
+    out[f"{n}_at_once_cache_hit_no_torch"] = {"wall_s": round(wln, 3), "time_to_first_row_s": [r.get("time_to_first_row_s") for r in rln],
+                                              "torch_imported": [r.get("torch_imported") for r in rln],
+                                              "same_model_version": len({r.get("model_version") for r in rln} | {r.get("model_version") for r in rn}) == 1}
 print(json.dumps(out))
