@@ -86,3 +86,30 @@ def test_plugin_errors(tmp_path, monkeypatch):
     ok = {"id": "a", "embeddings": {"mi355x": [{"id": "emb-a", "external_id": rec["external_id"], "model_version": rec["model_version"]}]}}
     rows = be.identify_speaker(good, [ghost, ok], threshold=0.354)
     assert [r["speaker_id"] for r in rows] == ["a"] and rows[0]["similarity"] > 0.99
+
+
+def test_cabi_device_memory_entry_points(engine):
+    """sdk_device_malloc / sdk_memcpy / sdk_device_free (the allocator of a host that brings none, lite.py): a round trip through library-owned
+    memory, interoperability with torch's pointers (same HIP runtime in this process), and the argument checks."""
+    import ctypes as C
+    lib, ctx = engine.lib, engine.ctx
+    host = np.arange(1000, dtype=np.float32)
+    p = C.c_void_p()
+    LIB.check(lib.sdk_device_malloc(ctx, host.nbytes, C.byref(p)), "sdk_device_malloc")
+    assert p.value
+    LIB.check(lib.sdk_memcpy(ctx, p, host.ctypes.data, host.nbytes, 1, None), "sdk_memcpy")
+    t = torch.empty(1000, dtype=torch.float32, device="cuda")
+    LIB.check(lib.sdk_memcpy(ctx, t.data_ptr(), p, host.nbytes, 3, None), "sdk_memcpy")        # device -> device into a torch tensor
+    back = np.empty_like(host)
+    LIB.check(lib.sdk_memcpy(ctx, back.ctypes.data, t.data_ptr(), host.nbytes, 2, None), "sdk_memcpy")
+    assert np.array_equal(back, host) and torch.equal(t.cpu(), torch.from_numpy(host))
+    with pytest.raises(LIB.SdkError, match=r"sdk_memcpy: kind=7"):
+        LIB.check(lib.sdk_memcpy(ctx, p, host.ctypes.data, 4, 7, None), "sdk_memcpy")
+    with pytest.raises(LIB.SdkError, match=r"sdk_memcpy: null argument"):
+        LIB.check(lib.sdk_memcpy(ctx, None, host.ctypes.data, 4, 1, None), "sdk_memcpy")
+    LIB.check(lib.sdk_memcpy(ctx, None, None, 0, 1, None), "sdk_memcpy")                          # empty copies are fine
+    LIB.check(lib.sdk_stream_synchronize(ctx, None), "sdk_stream_synchronize")
+    LIB.check(lib.sdk_device_free(ctx, p), "sdk_device_free")
+    LIB.check(lib.sdk_device_free(ctx, None), "sdk_device_free")
+    with pytest.raises(LIB.SdkError, match=r"sdk_device_malloc: null argument"):
+        LIB.check(lib.sdk_device_malloc(ctx, 16, None), "sdk_device_malloc")
