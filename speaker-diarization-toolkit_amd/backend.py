@@ -249,6 +249,23 @@ class Backend(EmbeddingBackend):
             out.append(full)
         return out[0], out[1], out[2], [(ri, a, b) for ri, _, _, a, b in wins], dropped
 
+    def score_ranges(self, samples: np.ndarray, ranges: List[Tuple[float, float]], batch, k: int = 1):
+        """Single-speaker ranges -> per window (best profile rows [W, k], scores [W, k]) on the host + windows [(range index, start s, end s)]:
+        embed_ranges + score_windows in one call, on either host path (torch engine or SDK_NO_TORCH=1)."""
+        if not self.lite:
+            E, Eb, re, wins, _ = self.embed_ranges(samples, ranges)
+            if not wins:
+                return np.zeros((0, k), np.int32), np.zeros((0, k), np.float32), []
+            idx, sc = self.score_windows(E, Eb, re, batch, k)
+            return idx, sc, wins
+        pcm_by_len, wins, _ = cut_ranges(samples, ranges, hop_s=self.hop_s)
+        if not wins:
+            return np.zeros((0, k), np.int32), np.zeros((0, k), np.float32), []
+        parts = {S: self.embed_windows_host(pcm, batch.matrix, k)[1:] for S, pcm in pcm_by_len.items()}      # one bucket = one forward + one top-k
+        idx = np.stack([parts[S][0][row] for _, S, row, _, _ in wins])
+        sc = np.stack([parts[S][1][row] for _, S, row, _, _ in wins])
+        return idx, sc, [(ri, a, b) for ri, _, _, a, b in wins]
+
     # ---- a2: enroll (base.py:107-128) ---------------------------------------------------------
     def enroll_speaker(self, audio_path: Path, segments: Optional[List[Tuple[float, float]]] = None) -> Dict[str, Any]:
         if segments:           # the caller vouches that each range is this speaker: true-length windows, never widened

@@ -84,10 +84,9 @@ def make_rows_fn(audio_path: Path, tags: Optional[List[str]] = None, per_label: 
 
     def score(ranges):
         """ranges -> (best profile row, score, range index, span) per window"""
-        E, Eb, re, wins, _ = be.embed_ranges(samples, ranges)
+        idx, sc, wins = be.score_ranges(samples, ranges, batch)             # either host path (torch engine / SDK_NO_TORCH=1)
         if not wins:
             return [], [], []
-        idx, sc = be.score_windows(E, Eb, re, batch)
         return idx[:, 0], sc[:, 0], wins
 
     if transcript is not None:

@@ -29,12 +29,26 @@ for sid in ("alice", "bob"):
 rows = be.identify_speaker(tmp / "meeting.wav", profiles, threshold=-1.0)
 ver = be.verify_speaker(tmp / "meeting48k.wav", profiles[0], threshold=-1.0)          # 48 kHz stereo: the GPU resampler on the way in
 vecs = {p["id"]: __import__("numpy").load(str(B.vector_path(p["embeddings"]["mi355x"][0]["external_id"]))).tolist() for p in profiles}
-print(json.dumps({"rows": rows, "verify": ver, "vecs": vecs, "torch": "torch" in sys.modules, "model_version": be.model_version, "cache_hit": bool(be._cache_hit)}))
+# the speaker-assign compatible driver on top (per-label identify through Backend.score_ranges): speaker-assign:262-328, 418-492
+db = Path(os.environ["SPEAKERS_EMBEDDINGS_DIR"]) / "db"
+db.mkdir(parents=True, exist_ok=True)
+for p in profiles:
+    p["names"] = {"default": p["id"]}
+    p["embeddings"]["mi355x"][0]["trust_level"] = "high"
+    (db / (p["id"] + ".json")).write_text(json.dumps(p))
+transcript = tmp / ("t_" + os.environ["TAG"] + ".json")
+transcript.write_text(json.dumps({"results": [
+    {"type": "word", "start_time": 0.2, "end_time": 3.8, "alternatives": [{"content": "hello", "speaker": "S1"}]},
+    {"type": "word", "start_time": 4.2, "end_time": 7.8, "alternatives": [{"content": "there", "speaker": "S2"}]}]}))
+asg, ident = importlib.import_module(sys.argv[2] + ".assign"), importlib.import_module(sys.argv[2] + ".identify")
+out = asg.assign_recording(tmp / "meeting.wav", transcript, rows_fn=ident.make_rows_fn(tmp / "meeting.wav", per_label=True, backend=be), use_embeddings=True, threshold=0.1)
+maps = {k: {f: v[f] for f in ("speaker_id", "confidence", "score", "signals")} for k, v in out["mappings"].items()}
+print(json.dumps({"rows": rows, "verify": ver, "vecs": vecs, "mappings": maps, "torch": "torch" in sys.modules, "model_version": be.model_version, "cache_hit": bool(be._cache_hit)}))
 """
 
 
 def _run_child(tmp_path, env_extra):
-    env = dict(os.environ, SPEAKERS_EMBEDDINGS_DIR=str(tmp_path / ("store_" + env_extra.get("TAG", "x"))), HSA_ENABLE_IPC_MODE_LEGACY="0", **env_extra)
+    env = dict(os.environ, SPEAKERS_EMBEDDINGS_DIR=str(tmp_path / ("store_" + env_extra["TAG"])), HSA_ENABLE_IPC_MODE_LEGACY="0", **env_extra)
     r = subprocess.run([sys.executable, "-c", CHILD, str(ROOT), PKG, str(tmp_path)], env=env, capture_output=True, text=True, timeout=300)
     assert r.returncode == 0, r.stderr[-2000:]
     return json.loads([ln for ln in r.stdout.splitlines() if ln.startswith("{")][-1])
@@ -81,5 +95,6 @@ def test_lite_rows_equal_the_torch_engine(tmp_path, model):
     for got in (lite_cold, lite_warm):
         # same kernels on the same inputs: stored vectors, scores and rows are the torch engine's, bit for bit
         assert got["vecs"] == ref["vecs"]
-        assert got["rows"] == ref["rows"] and got["verify"] == ref["verify"]
+        assert got["rows"] == ref["rows"] and got["verify"] == ref["verify"] and got["mappings"] == ref["mappings"]
     assert {r["speaker_id"] for r in ref["rows"]} == {"alice", "bob"} and ref["verify"]["match"] is True
+    assert ref["mappings"]["S1"]["speaker_id"] == "bob" and ref["mappings"]["S2"]["speaker_id"] == "alice"
