@@ -214,6 +214,8 @@ def xvector_object(eng, pcm, pcm_host, P_host, Pn, Pb, rpm, n_par=16):
     m = min(n_par, B)
     Eo = oecapa.l2_normalise(oxv.xvector_embed(w, torch.from_numpy(ofbank.fbank(pcm_host[:m])), mode="bf16").numpy())
     par = parity_object(E[:m].cpu().numpy(), gi[:m, 0].cpu().numpy(), gs[:m, 0].cpu().numpy(), Eo, P_host)
+    Eo32 = oecapa.l2_normalise(oxv.xvector_embed(w, torch.from_numpy(ofbank.fbank(pcm_host[:m])), mode="fp32").numpy())
+    par32 = parity_object(E[:m].cpu().numpy(), gi[:m, 0].cpu().numpy(), gs[:m, 0].cpu().numpy(), Eo32, P_host)
     mac = XV.DEFAULT_XVECTOR.macs_per_frame()
     T = importlib.import_module(f"{PKG}.ops").num_frames(pcm.shape[1])
     gemm_ms = sum(prof[k]["ms"] for k in ("conv_gemm256", "conv_gemm") if k in prof)
@@ -222,7 +224,9 @@ def xvector_object(eng, pcm, pcm_host, P_host, Pn, Pb, rpm, n_par=16):
             "frame_layers_ms": round(gemm_ms, 3), "frame_layers_tflops": round(2.0 * mac * T * B / (gemm_ms * 1e-3) / 1e12, 1) if gemm_ms else None,
             "kernels_ms": {k: round(v["ms"], 3) for k, v in prof.items()},
             "parity_vs_bf16_oracle": {"segments": m, "min_cos_embedding": par["min_cos_embedding"], "max_abs_dscore_all_pairs": par["max_abs_dscore_all_pairs"],
-                                      "id_mismatches": par["id_mismatches"]}}
+                                      "id_mismatches": par["id_mismatches"]},
+            "parity_vs_fp32_oracle": {"segments": m, "min_cos_embedding": par32["min_cos_embedding"], "max_abs_dscore_all_pairs": par32["max_abs_dscore_all_pairs"],
+                                      "id_mismatches": par32["id_mismatches"], "note": "bf16 operands, no bias correction for this family"}}
 
 
 def cold_start_object(timeout_s=120):
