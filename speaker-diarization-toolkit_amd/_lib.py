@@ -13,8 +13,7 @@ import ctypes as C
 import os
 from pathlib import Path
 
-if os.environ.get("SDK_NO_TORCH") != "1":
-    import torch  # noqa: F401  (must precede loading libsdk_hip.so, see module docstring)
+NO_TORCH = os.environ.get("SDK_NO_TORCH") == "1"      # lite.py sets this attribute (not the environment) when it is what loads the library
 
 _HERE = Path(__file__).resolve().parent
 LIB_PATH = Path(os.environ.get("SDK_HIP_LIB", _HERE / "libsdk_hip.so"))
@@ -148,6 +147,8 @@ def load_library() -> C.CDLL:
             f"{LIB_PATH} not found: the HIP extension has not been built. Run "
             f"`python -c 'import __graft_entry__ as g; g.build()'` (or `make -C {_HERE / 'csrc'}`). "
             "This package has no CPU fallback.")
+    if not NO_TORCH:
+        import torch  # noqa: F401  (must precede loading libsdk_hip.so, see module docstring)
     lib = C.CDLL(str(LIB_PATH))
     for name, (res, args) in SIGNATURES.items():
         fn = getattr(lib, name)  # AttributeError here = header/library mismatch

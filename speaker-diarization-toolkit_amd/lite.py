@@ -19,11 +19,13 @@ from typing import Dict, Optional, Tuple
 
 import numpy as np
 
-os.environ.setdefault("SDK_NO_TORCH", "1")      # before ._lib is imported: it must not pull torch in
-from . import _lib                              # noqa: E402
-from ._lib import EcapaDesc, SdkError, check    # noqa: E402
-from .weights import DEFAULT_CONFIG, EcapaConfig  # noqa: E402
-from .weights_pack import N_MELS_PADDED         # noqa: E402
+from . import _lib
+from ._lib import EcapaDesc, SdkError, check
+from .weights import DEFAULT_CONFIG, EcapaConfig
+from .weights_pack import N_MELS_PADDED
+
+_lib.NO_TORCH = True        # if THIS module is what loads libsdk_hip.so, torch stays out (process-local: the environment is not touched; a library
+                            # that ops.Engine already loaded - with torch - is simply reused)
 
 HOP = 160
 H2D, D2H = 1, 2
