@@ -250,6 +250,22 @@ def cold_start_object(timeout_s=120):
     return out
 
 
+def spawn_ranks(n: int) -> int:
+    """`python bench.py --gpus N` without a rank environment: start the N ranks as CHILD processes (torch.distributed.run, one per GPU,
+    rendezvous on 127.0.0.1) BEFORE this process makes any GPU call, let rank 0's JSON line through on stdout and return the children's exit
+    code.  Nothing is re-exec'ed: a process that has initialised the GPU must never be replaced, and this one never initialises it."""
+    import socket
+    import subprocess
+    with socket.socket() as sk:                      # a free rendezvous port
+        sk.bind(("127.0.0.1", 0))
+        port = sk.getsockname()[1]
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")  # dmabuf IPC: what RCCL needs on these hosts
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={n}", "--master-addr", "127.0.0.1",
+           "--master-port", str(port), str(Path(__file__).resolve())] + sys.argv[1:]
+    return subprocess.run(cmd, env=env).returncode
+
+
 def main() -> int:
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -263,12 +279,14 @@ def main() -> int:
     ap.add_argument("--no-extras", action="store_true", help="skip the precise-mode, sustained and cold-start legs (they run outside the timed region)")
     args = ap.parse_args()
 
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        return spawn_ranks(args.gpus)          # plain `python bench.py --gpus N`: this process becomes the launcher (it has made no GPU call)
     rank = int(os.environ.get("RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
     if world != args.gpus:
         if rank == 0:
-            print(f"bench.py: --gpus {args.gpus} but WORLD_SIZE={world}; launch with torch.distributed.run", file=sys.stderr)
+            print(f"bench.py: --gpus {args.gpus} but WORLD_SIZE={world}: the rank environment and the flag disagree", file=sys.stderr)
         return 2
     # one process per GPU.  SDK_BENCH_BACKEND=gloo rehearses the N > 1 path on a box with fewer GPUs than ranks (ranks then
     # share devices and the collectives are staged through the host): a plumbing check, never a measurement

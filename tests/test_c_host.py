@@ -26,9 +26,12 @@ def test_c_host_compiles_against_the_header(tmp_path):
 
 
 @pytest.mark.gpu
-def test_c_host_equals_the_python_engine(tmp_path, engine):
+@pytest.mark.parametrize("bias_correction", [False, True])
+def test_c_host_equals_the_python_engine(tmp_path, engine, bias_correction):
     import sys
     import torch
+    if bias_correction:                      # the shipped default: the blob the C host maps is the bias-corrected one
+        engine = sub("ops").Engine(0, bias_correction=True)
     sys.path.insert(0, str(ROOT))
     import bench
     B, S, P = 7, 32000, 33

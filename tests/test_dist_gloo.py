@@ -131,3 +131,38 @@ def test_spectral_cluster_raises_on_a_flagged_gram_matrix():
             CL.spectral_cluster(prov, torch.from_numpy(E), Eb, 150, 6, n_iter=4, n_kmeans=3)
     res = CL.spectral_cluster(Flagging(), torch.from_numpy(E), Eb, 150, 3, n_iter=6, n_kmeans=3)
     assert np.array_equal(res.labels, np.repeat(np.arange(3), 50))
+
+
+def test_bench_gpus_n_spawns_its_own_ranks_before_any_gpu_call(monkeypatch):
+    """VERDICT r3 next #2b: the driver runs `python bench.py --gpus N ...` directly.  Without a rank environment bench.py becomes the launcher:
+    N children through torch.distributed.run on 127.0.0.1, the original flags passed on, the children's exit code returned, and no GPU call
+    in the parent (a process that has initialised the GPU must never be replaced or re-exec'ed)."""
+    import subprocess
+    import sys as _sys
+    import torch
+    _sys.path.insert(0, str(ROOT))
+    import bench
+    seen = {}
+
+    class R:
+        returncode = 7
+
+    def fake_run(cmd, env=None, **kw):
+        seen["cmd"], seen["env"] = cmd, env
+        return R()
+
+    monkeypatch.setattr(subprocess, "run", fake_run)
+    for k in ("WORLD_SIZE", "RANK", "LOCAL_RANK"):
+        monkeypatch.delenv(k, raising=False)
+    monkeypatch.setattr(_sys, "argv", ["bench.py", "--gpus", "8", "--steps", "3", "--warmup", "1"])
+    assert bench.main() == 7
+    cmd = seen["cmd"]
+    assert cmd[:3] == [_sys.executable, "-m", "torch.distributed.run"] and "--nproc-per-node=8" in cmd and "--nnodes=1" in cmd
+    assert cmd[cmd.index("--master-addr") + 1] == "127.0.0.1" and int(cmd[cmd.index("--master-port") + 1]) > 0
+    assert cmd[-6:] == ["--gpus", "8", "--steps", "3", "--warmup", "1"] and cmd[-7].endswith("bench.py")
+    assert seen["env"]["HSA_ENABLE_IPC_MODE_LEGACY"] == "0"
+    assert not torch.cuda.is_initialized()
+    # with a rank environment that disagrees with the flag it is still a usage error, not a second launcher
+    monkeypatch.setenv("WORLD_SIZE", "2")
+    seen.clear()
+    assert bench.main() == 2 and not seen

@@ -28,14 +28,24 @@ def _voice(seed, seconds, f0):
     return np.clip(np.round(x / np.abs(x).max() * 0.5 * 32767), -32768, 32767).astype(np.int16)
 
 
-def _oracle_embed(pcm_windows):
+def _oracle_embed(pcm_windows, weights=None):
     feats = torch.from_numpy(ofbank.fbank(pcm_windows))
-    return oecapa.l2_normalise(oecapa.EcapaOracle(W.synthetic_weights(0), "bf16", torch.float64).embed(feats).numpy())
+    return oecapa.l2_normalise(oecapa.EcapaOracle(weights if weights is not None else W.synthetic_weights(0), "bf16", torch.float64).embed(feats).numpy())
 
 
-def test_enroll_identify_verify_roundtrip(tmp_path, monkeypatch):
+@pytest.mark.parametrize("bias_correction", ["0", "1"])
+def test_enroll_identify_verify_roundtrip(tmp_path, monkeypatch, bias_correction):
+    """Both settings of the bf16 weight-rounding bias correction through the plug-in class: "1" is what ships (calibration pass -> 29 patched bias
+    slots -> cache entry "0c"), "0" the plain model.  The oracle is the bf16 layer-boundary model of the engine's EFFECTIVE weights either way."""
     monkeypatch.setenv("SPEAKERS_EMBEDDINGS_DIR", str(tmp_path / "store"))
+    monkeypatch.setenv("SDK_BIAS_CORRECTION", bias_correction)
+    monkeypatch.setenv("SDK_CACHE_DIR", str(tmp_path / "cache"))
     be = sub("backend").Backend()
+    assert be.engine().bias_correction is (bias_correction == "1")
+    eff = be.engine().effective_weights()
+    plain = W.synthetic_weights(0)
+    assert any(not np.array_equal(eff[k], plain[k]) for k in plain) is (bias_correction == "1")
+    assert any((tmp_path / "cache").glob("*.p0c.npy" if bias_correction == "1" else "*.p0.npy"))        # the entry this setting builds
     voices = {"alice": 140.0, "bob": 95.0, "carol": 210.0}
     profiles, oracle_vecs = [], {}
     for i, (sid, f0) in enumerate(voices.items()):
@@ -48,7 +58,7 @@ def test_enroll_identify_verify_roundtrip(tmp_path, monkeypatch):
             {"id": f"emb-{sid}", "external_id": rec["external_id"], "model_version": rec["model_version"], "trust_level": "high"}]}})
         # oracle enrollment on the same windows
         pcm, _ = wav.cut_windows(wav.read_wav_s16(path), [(0.5, 5.5)])
-        e = _oracle_embed(pcm).astype(np.float64).mean(0)
+        e = _oracle_embed(pcm, eff).astype(np.float64).mean(0)
         oracle_vecs[sid] = (e / np.linalg.norm(e)).astype(np.float32)
         stored = np.load(rec["file"])
         assert float(stored @ oracle_vecs[sid]) > 1 - 1e-4, "stored enrollment vector vs oracle"
@@ -63,7 +73,7 @@ def test_enroll_identify_verify_roundtrip(tmp_path, monkeypatch):
 
     # oracle: same windows, same profiles, same aggregation
     pcm, spans = wav.cut_windows(wav.read_wav_s16(tpath), None)
-    Eo = _oracle_embed(pcm)
+    Eo = _oracle_embed(pcm, eff)
     Pm = oecapa.l2_normalise(np.stack([np.load(str(tmp_path / "store/embeddings/by-hash" / (p["embeddings"]["mi355x"][0]["external_id"][4:] + ".npy")))
                                        for p in profiles]))
     oidx, osc = oscoring.affinity_topk(Eo, Pm, 1)

@@ -72,3 +72,96 @@ def test_bias_correction_brings_the_default_mode_closer_to_the_fp32_model(engine
     assert rep["corrected"]["max_abs_dscore_all_pairs"] < CORRECTED_BUDGET
     assert rep["corrected"]["max_abs_dscore_all_pairs"] < 0.4 * rep["plain"]["max_abs_dscore_all_pairs"]
     assert rep["plain"]["max_abs_dscore_all_pairs"] > 2.5e-3                   # (the fixture engine really is the uncorrected one)
+
+
+LITE_CHILD = r"""
+import importlib, sys
+import numpy as np
+sys.path.insert(0, sys.argv[1])
+lite = importlib.import_module(sys.argv[2] + ".lite")
+eng = lite.LiteEngine(0, cache_key=sys.argv[3], bias_correction=True)
+assert eng.cache_entry_name() == "0c" and eng.has_cached_weights()
+E = eng.embed_pcm(np.load(sys.argv[4]))
+assert eng.cache_hit and "torch" not in sys.modules
+np.save(sys.argv[5], E)
+"""
+
+
+def test_cache_entry_0c_is_bit_identical_across_fresh_hit_and_lite(tmp_path, monkeypatch):
+    """ADVICE r3 (medium) / VERDICT r3 next #2a: the shipped default through the packed-blob cache.  The process that calibrates and stores entry
+    "0c", a second engine that maps it, and the torch-free host path reading the same entry give bit-identical embeddings and identical
+    effective biases."""
+    import subprocess
+    sys.path.insert(0, str(ROOT))
+    bench = importlib.import_module("bench")
+    WC = sub("weights_cache")
+    monkeypatch.setenv("SDK_CACHE_DIR", str(tmp_path / "cache"))
+    monkeypatch.delenv("SDK_WEIGHTS_CACHE", raising=False)
+    w = W.synthetic_weights(0)
+    key = WC.key_for_seed(0, W.DEFAULT_CONFIG)
+    digest = W.weights_digest(w)
+    mk = lambda: OPS.Engine(0, cache_key=key, weights_fn=lambda: w, digest_fn=lambda: digest, bias_correction=True)  # noqa: E731
+    pcm = bench.synth_pcm(5, seed=9)
+    cold = mk()
+    E_cold = cold.embed_pcm(torch.from_numpy(pcm).cuda())[0].cpu()
+    assert cold.cache_hit is False
+    assert WC.load_blob(key, "0c") is not None and WC.load_blob(key, 0) is None          # the corrected blob is its own entry; the plain one was not stored
+    assert WC.load_meta(key)["digest"] == digest
+    warm = mk()
+    E_warm = warm.embed_pcm(torch.from_numpy(pcm).cuda())[0].cpu()
+    assert warm.cache_hit is True and torch.equal(E_cold, E_warm)
+    eff_c, eff_w = cold.effective_weights(), warm.effective_weights()                    # warm: read back from the device blob
+    assert set(eff_c) == set(eff_w) and all(np.array_equal(eff_c[k], eff_w[k]) for k in eff_c)
+    assert any(not np.array_equal(eff_c[k], w[k]) for k in w)
+    np.save(tmp_path / "pcm.npy", pcm)
+    r = subprocess.run([sys.executable, "-c", LITE_CHILD, str(ROOT), OPS.__package__, key, str(tmp_path / "pcm.npy"), str(tmp_path / "E_lite.npy")],
+                       capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0, r.stderr[-2000:]
+    assert np.array_equal(np.load(tmp_path / "E_lite.npy"), E_cold.numpy())
+
+
+def _input_kinds(n):
+    """The six input kinds of tools/bias_corr_generalise.py (same generators, n segments each)."""
+    bench = importlib.import_module("bench")
+    rng = np.random.default_rng(77)
+
+    def voices(m, S):
+        t = np.arange(S) / 16000.0
+        out = []
+        for _ in range(m):
+            f0 = rng.uniform(80, 260)
+            x = sum((0.5 / h ** rng.uniform(1.0, 1.6)) * np.sin(2 * np.pi * f0 * h * t + rng.uniform(0, 6.28)) for h in range(1, 12))
+            x = x * (0.6 + 0.4 * np.sin(2 * np.pi * rng.uniform(2, 5) * t)) + rng.normal(0, 0.02, t.shape)
+            out.append(np.clip(np.round(x / np.abs(x).max() * 0.5 * 32767), -32768, 32767).astype(np.int16))
+        return np.stack(out)
+
+    return {
+        "config2_other_seed": bench.synth_pcm(n, seed=9),
+        "harmonic_voices": voices(n, 32000),
+        "quiet_white_noise": np.clip(np.round(rng.normal(0, 0.01, (n, 32000)) * 32768), -32768, 32767).astype(np.int16),
+        "loud_clipped_noise": np.clip(np.round(rng.normal(0, 0.6, (n, 32000)) * 32768), -32768, 32767).astype(np.int16),
+        "half_second_windows": bench.synth_pcm(n, seed=10)[:, :8000].copy(),
+        "five_second_windows": np.concatenate([bench.synth_pcm(n, seed=11), bench.synth_pcm(n, seed=12), bench.synth_pcm(n, seed=13)[:, :16000]], axis=1),
+    }
+
+
+def test_corrected_budget_holds_on_other_input_kinds(corrected, engine):
+    """the correction is calibrated once on 24 built-in synthetic segments; assert that it still helps on inputs unlike
+    the calibration set - each kind with its own bound of 2 x the deviation measured on MI355X over 64 segments
+    (profiles/r03_bias_correction_generalisation.json: 7.3e-4, 1.5e-3, 8.3e-4, 1.0e-3, 1.2e-3, 2.3e-3)."""
+    sys.path.insert(0, str(ROOT))
+    P = importlib.import_module("bench").unit_rows(100, 192, seed=1).astype(np.float64)
+    model = oecapa.EcapaOracle(W.synthetic_weights(0), "fp32", torch.float32)
+    bounds = {"config2_other_seed": 1.5e-3, "harmonic_voices": 3.0e-3, "quiet_white_noise": 1.7e-3, "loud_clipped_noise": 2.1e-3,
+              "half_second_windows": 2.4e-3, "five_second_windows": 4.7e-3}
+    rep = {}
+    for kind, pcm in _input_kinds(16).items():
+        Eo = oecapa.l2_normalise(model.embed(torch.from_numpy(ofbank.fbank(pcm))).numpy()).astype(np.float64)
+        dev = {}
+        for name, eng in (("plain", engine), ("corrected", corrected)):
+            E = eng.embed_pcm(torch.from_numpy(pcm).cuda())[0].cpu().numpy().astype(np.float64)
+            dev[name] = float(np.abs(E @ P.T - Eo @ P.T).max())
+        rep[kind] = dev
+        assert dev["corrected"] < bounds[kind], (kind, dev)
+        assert dev["corrected"] < dev["plain"], (kind, dev)
+    print("\nbias correction on other input kinds (max |dscore| vs the fp32 model):", json.dumps(rep))

@@ -27,8 +27,11 @@ def _voice(seed, seconds, f0):
     return np.clip(np.round(x / np.abs(x).max() * 0.5 * 32767), -32768, 32767).astype(np.int16)
 
 
-def test_fixture_sentences_one_pass_per_recording(tmp_path, monkeypatch):
+@pytest.mark.parametrize("bias_correction", ["0", "1"])
+def test_fixture_sentences_one_pass_per_recording(tmp_path, monkeypatch, bias_correction):
     monkeypatch.setenv("SPEAKERS_EMBEDDINGS_DIR", str(tmp_path / "store"))
+    monkeypatch.setenv("SDK_BIAS_CORRECTION", bias_correction)             # "1" = the shipped default; the oracle below runs on the engine's effective weights
+    monkeypatch.setenv("SDK_CACHE_DIR", str(tmp_path / "cache"))
     be = sub("backend").Backend()
     seg, ident, asg, store = sub("segments"), sub("identify"), sub("assign"), sub("store")
     data = json.loads(FIXTURE.read_text())
@@ -72,7 +75,8 @@ def test_fixture_sentences_one_pass_per_recording(tmp_path, monkeypatch):
     assert dropped == [6]
     E, Eb, re, gw, _ = be.embed_ranges(samples, [(s["start"], s["end"]) for s in sents])
     assert [(ri, a, b) for ri, _, _, a, b in wins] == gw
-    orc = oecapa.EcapaOracle(W.synthetic_weights(0), "bf16", torch.float64)
+    assert be.engine().bias_correction is (bias_correction == "1")
+    orc = oecapa.EcapaOracle(be.engine().effective_weights(), "bf16", torch.float64)
     Eo = np.zeros((len(wins), 192), np.float32)
     for S, pcm in pcm_by_len.items():
         e = oecapa.l2_normalise(orc.embed(torch.from_numpy(ofbank.fbank(pcm))).numpy())

@@ -70,8 +70,8 @@ def test_lite_needs_the_default_contract(monkeypatch):
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("model", ["ecapa", "xvector"])
-def test_lite_rows_equal_the_torch_engine(tmp_path, model):
+@pytest.mark.parametrize("model,bias_correction", [("ecapa", "1"), ("ecapa", "0"), ("xvector", "1")])
+def test_lite_rows_equal_the_torch_engine(tmp_path, model, bias_correction):
     from test_gpu_backend_e2e import _voice
     wav = sub("wav")
     wav.write_wav_s16(tmp_path / "enroll_alice.wav", _voice(10, 6.0, 140.0))
@@ -84,14 +84,15 @@ def test_lite_rows_equal_the_torch_engine(tmp_path, model):
     (tmp_path / "meeting48k.wav").write_bytes(b"RIFF" + struct.pack("<I", 36 + len(pcm)) + b"WAVEfmt " + struct.pack("<IHHIIHH", 16, 1, 2, 48000, 48000 * 4, 4, 16)
                                               + b"data" + struct.pack("<I", len(pcm)) + pcm)
     cache = tmp_path / "cache"
-    base = {"SDK_MODEL": model, "SDK_CACHE_DIR": str(cache)}
+    base = {"SDK_MODEL": model, "SDK_CACHE_DIR": str(cache), "SDK_BIAS_CORRECTION": bias_correction}     # "1" = the shipped default (cache entry "p0c")
     lite_cold = _run_child(tmp_path, dict(base, SDK_NO_TORCH="1", TAG="lite_cold"))       # empty cache: a grandchild builds the entry (ecapa)
     ref = _run_child(tmp_path, dict(base, TAG="torch"))
     lite_warm = _run_child(tmp_path, dict(base, SDK_NO_TORCH="1", TAG="lite_warm"))
     assert lite_cold["torch"] is False and lite_warm["torch"] is False and ref["torch"] is True
     assert lite_cold["model_version"] == ref["model_version"] == lite_warm["model_version"]
     if model == "ecapa":
-        assert lite_warm["cache_hit"] is True and any(cache.glob("*.npy"))      # (the test environment switches the bias correction off: entry "p0", not "p0c")
+        assert lite_warm["cache_hit"] is True and any(cache.glob("*.p0c.npy" if bias_correction == "1" else "*.p0.npy"))
+        assert not any(cache.glob("*.p0.npy" if bias_correction == "1" else "*.p0c.npy"))
     for got in (lite_cold, lite_warm):
         # same kernels on the same inputs: stored vectors, scores and rows are the torch engine's, bit for bit
         assert got["vecs"] == ref["vecs"]
