@@ -244,6 +244,25 @@ def cold_start_object(timeout_s=120):
                 out[label] = json.loads(line[-1]) if line else {"error": (r.stderr or "no output")[-300:]}
             except Exception as exc:  # noqa: BLE001
                 out[label] = {"error": repr(exc)[:300]}
+        # k7 at BASELINE's profile counts: P enrolled embeddings in the store; the first process over the candidate set loads
+        # them file by file (one np.load + one link probe each) and publishes the set's pack, later processes map ONE file.  Warm weight cache.
+        by_p = {}
+        for P in (100, 1000, 10000):
+            with tempfile.TemporaryDirectory(prefix=f"sdk_store_{P}_") as store_dir:
+                row = {}
+                for label, extra in (("pack_miss_builds", []), ("pack_hit", []), ("pack_hit_no_torch", ["--lite"])):
+                    try:
+                        r = subprocess.run([sys.executable, str(ROOT / "tools" / "cold_start.py"), "--profiles", str(P), "--store", store_dir] + extra,
+                                           env=env, capture_output=True, text=True, timeout=timeout_s)
+                        line = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
+                        j = json.loads(line[-1]) if line else {"error": (r.stderr or "no output")[-300:]}
+                        row[label] = ({"time_to_first_row_s": j["time_to_first_row_s"], "first_identify_s": j["phases_s"].get("first_identify"),
+                                       "second_identify_s": j["phases_s"].get("second_identify"), "profile_pack_hit": j.get("profile_pack_hit")}
+                                      if "phases_s" in j else j)
+                    except Exception as exc:  # noqa: BLE001
+                        row[label] = {"error": repr(exc)[:300]}
+                by_p[str(P)] = row
+        out["by_enrolled_profiles"] = by_p
     out["note"] = ("fresh Python process through plugin_api.get_backend('mi355x'): import, weights (generate / cache), digest, pack, upload, first enroll + identify of a "
                    "12-s WAV (code-object load), second identify; the reference builds its backend once per CLI process (base.py:272-293); the third process takes the "
                    "torch-free host path (SDK_NO_TORCH=1, lite.py): same library calls, no `import torch`")

@@ -37,7 +37,7 @@ import numpy as np
 
 from . import BACKEND_NAME
 from .plugin_api import EmbeddingBackend
-from .store import load_profile_batch, save_vector, vector_path
+from .store import load_profile_batch, publish_pack, save_vector, vector_path
 from .wav import cut_ranges, cut_windows, decode_to_profile
 from .weights import DEFAULT_CONFIG, load_weights, synthetic_weights, weights_digest
 
@@ -203,15 +203,22 @@ class Backend(EmbeddingBackend):
                  for a in range(0, pcm.shape[0], step)]
         return tuple(torch.cat([p[i] for p in parts], dim=0) for i in range(3))
 
-    def embed_windows_host(self, pcm: np.ndarray, profiles: Optional[np.ndarray] = None, k: int = 1):
-        """pcm [B, S] int16 -> unit-norm embeddings [B, d] fp32 on the HOST and, when `profiles` [P, d] is given, the cosine top-k of every window
-        (idx [B, k] int32, score [B, k] fp32) - the torch-free form of embed_windows + score_windows (SDK_NO_TORCH=1), same bounded batches."""
+    def embed_windows_host(self, pcm: np.ndarray, profiles=None, k: int = 1):
+        """pcm [B, S] int16 -> unit-norm embeddings [B, d] fp32 on the HOST and, when `profiles` (a store.ProfileBatch, or a [P, d] matrix) is
+        given, the cosine top-k of every window (idx [B, k] int32, score [B, k] fp32) - the torch-free form of embed_windows + score_windows
+        (SDK_NO_TORCH=1), same bounded batches.  A ProfileBatch served from its pack is uploaded as packed (no normalisation pass); one loaded
+        file by file is normalised on the device once and its pack is published."""
         eng = self.engine()
         step = max(1, int(os.environ.get("SDK_MAX_BATCH", "2048")))
         Es, idxs, scs = [], [], []
+        batch = profiles if hasattr(profiles, "matrix") else None
         for a in range(0, pcm.shape[0], step):
             Es.append(eng.embed_pcm(pcm[a:a + step]))
-            if profiles is not None:
+            if batch is not None:
+                i, s_ = eng.score_last(batch.matrix, k, norm=batch.norm, tag=batch.uid,
+                                       on_norm=(lambda E, Eb, r: publish_pack(batch, E, Eb, r)) if batch.pack_ref else None)
+                idxs.append(i); scs.append(s_)
+            elif profiles is not None:
                 i, s_ = eng.score_last(profiles, k)
                 idxs.append(i); scs.append(s_)
         E = np.concatenate(Es) if Es else np.zeros((0, self.embedding_dim), np.float32)
@@ -261,7 +268,7 @@ class Backend(EmbeddingBackend):
         pcm_by_len, wins, _ = cut_ranges(samples, ranges, hop_s=self.hop_s)
         if not wins:
             return np.zeros((0, k), np.int32), np.zeros((0, k), np.float32), []
-        parts = {S: self.embed_windows_host(pcm, batch.matrix, k)[1:] for S, pcm in pcm_by_len.items()}      # one bucket = one forward + one top-k
+        parts = {S: self.embed_windows_host(pcm, batch, k)[1:] for S, pcm in pcm_by_len.items()}      # one bucket = one forward + one top-k
         idx = np.stack([parts[S][0][row] for _, S, row, _, _ in wins])
         sc = np.stack([parts[S][1][row] for _, S, row, _, _ in wins])
         return idx, sc, [(ri, a, b) for ri, _, _, a, b in wins]
@@ -300,17 +307,37 @@ class Backend(EmbeddingBackend):
         }
 
     # ---- a1: identify (base.py:130-151) --------------------------------------------------------
-    def score_windows(self, E, Eb, re, batch, k: int = 1):
-        """Device scoring of embedded windows against a ProfileBatch -> (idx, score) on host."""
+    def profile_tensors(self, batch):
+        """Device copies (unit rows fp32, bf16, max rounding residual) of a ProfileBatch, made once per batch object.  Pack hit: the three arrays
+        are uploaded as sdk_l2norm wrote them when the pack was built (no per-embedding file I/O happened, no normalisation pass runs).  Pack
+        miss: one sdk_l2norm pass, whose outputs are then published as the set's pack (store.publish_pack) - so hit and miss score bit-identically."""
         import torch
         eng = self.engine()
-        P = torch.from_numpy(np.ascontiguousarray(batch.matrix)).to(eng.device)
-        Pn, Pb, rp = eng.l2norm(P)
-        idx, sc = eng.affinity_topk(E, Eb, re, Pn, Pb, rp.max().reshape(1), k=min(k, len(batch)))
+        dev = getattr(batch, "_dev", None)
+        if dev is not None and dev[0] is eng:
+            return dev[1]
+        if batch.norm is not None:
+            E, Eb, r = batch.norm
+            Pn = torch.from_numpy(np.array(E, dtype=np.float32)).to(eng.device)
+            Pb = torch.from_numpy(np.array(Eb, dtype=np.uint16).view(np.int16)).to(eng.device).view(torch.bfloat16)
+            rp = torch.from_numpy(np.array(r, dtype=np.float32)).to(eng.device)
+        else:
+            Pn, Pb, rp = eng.l2norm(torch.from_numpy(np.ascontiguousarray(batch.matrix, dtype=np.float32)).to(eng.device))
+            if batch.pack_ref:
+                publish_pack(batch, Pn.cpu().numpy(), Pb.view(torch.int16).cpu().numpy().view(np.uint16), rp.cpu().numpy())
+        out = (Pn, Pb, rp.max().reshape(1))
+        batch._dev = (eng, out)
+        return out
+
+    def score_windows(self, E, Eb, re, batch, k: int = 1):
+        """Device scoring of embedded windows against a ProfileBatch -> (idx, score) on host."""
+        eng = self.engine()
+        Pn, Pb, rpm = self.profile_tensors(batch)
+        idx, sc = eng.affinity_topk(E, Eb, re, Pn, Pb, rpm, k=min(k, len(batch)))
         return idx.cpu().numpy(), sc.cpu().numpy()
 
     def identify_speaker(self, audio_path: Path, candidates: List[Dict[str, Any]], threshold: float = 0.354) -> List[Dict[str, Any]]:
-        batch = load_profile_batch(candidates, self.name, model_prefix=f"{self.name}-", model_version=self.model_version)
+        batch = self.last_batch = load_profile_batch(candidates, self.name, model_prefix=f"{self.name}-", model_version=self.model_version)
         for why in batch.skipped:
             print(f"mi355x backend: skipped embedding {why}", file=sys.stderr)
         if batch.all_skipped_message():
@@ -321,7 +348,7 @@ class Backend(EmbeddingBackend):
             return []
         pcm, spans = self._windows(audio_path, None)
         if self.lite:
-            _, idx, sc = self.embed_windows_host(pcm, batch.matrix)
+            _, idx, sc = self.embed_windows_host(pcm, batch)
         else:
             E, Eb, re = self.embed_windows(pcm)
             idx, sc = self.score_windows(E, Eb, re, batch)

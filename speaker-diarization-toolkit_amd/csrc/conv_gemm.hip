@@ -360,18 +360,24 @@ __global__ __launch_bounds__(NT2, 2) void conv_gemm256_kernel(Params p) {
       const int mm = min(tm0 + row, p.M - 1);
       aseg0 = (mm / p.T) * p.T;
       atl0 = mm - aseg0;                             // rows past M fetch some valid row; their results are dropped
+    } else if (p.tune & 512) {
+      // TIMING PROBE ONLY (gemm_variant 8194, tools/gemm_kblock_probe.py; results are wrong): source addresses as if A were stored K-blocked
+      // [K/64][M][64] - a wave's piece of 8 rows x 128 B is then ONE contiguous KiB and a tile's K-step 32 contiguous KiB
+#pragma unroll
+      for (int i = 0; i < 4; ++i) aoff[i] = ((uint32_t)min(tm0 + row + 8 * i, p.M - 1) * 64u + (uint32_t)gch) * 2u;
     } else {
 #pragma unroll
       for (int i = 0; i < 4; ++i) aoff[i] = ((uint32_t)min(tm0 + row + 8 * i, p.M - 1) * (uint32_t)p.lda + (uint32_t)gch) * 2u;
     }
-    woff = ((uint32_t)(tn0 + row) * (uint32_t)Ktot + (uint32_t)gch) * 2u;
+    woff = (p.tune & 1024) ? ((uint32_t)(tn0 + row) * 64u + (uint32_t)gch) * 2u       // probe: W as [K/64][N][64] too (gemm_variant 24578)
+                           : ((uint32_t)(tn0 + row) * (uint32_t)Ktot + (uint32_t)gch) * 2u;
   };
   auto issue = [&](int t, int stage) {
     const int j = t / ksteps_per_tap;
     const int kc = (t - j * ksteps_per_tap) * BK;
     char* sA = smem + stage * STAGE2 + (32 * wu) * 128;
     char* sB = sA + BM2 * BK * 2;
-    const char* abase = reinterpret_cast<const char*>(p.A + kc);
+    const char* abase = reinterpret_cast<const char*>(p.A + ((p.tune & 512) ? (size_t)(kc >> 6) * (size_t)p.M * 64 : (size_t)kc));
     if constexpr (TAPS) {
       int off = (j - half) * p.dil;
       uint32_t acol = (uint32_t)gch;
@@ -404,10 +410,12 @@ __global__ __launch_bounds__(NT2, 2) void conv_gemm256_kernel(Params p) {
       for (int i = 0; i < 4; ++i)
         __builtin_amdgcn_global_load_lds((gptr_t)(abase + (size_t)aoff[i]), (lptr_t)(sA + i * 1024), 16, 0, 0);
     }
-    const char* wbase = reinterpret_cast<const char*>(p.W + (j * cin_w + kc));
+    const bool wkb = (p.tune & 1024) != 0;
+    const char* wbase = reinterpret_cast<const char*>(p.W + (wkb ? (size_t)((j * cin_w + kc) >> 6) * (size_t)p.N * 64 : (size_t)(j * cin_w + kc)));
+    const size_t wstep = wkb ? (size_t)16 * 64 : (size_t)16 * Ktot;
 #pragma unroll
     for (int i = 0; i < 4; ++i)
-      __builtin_amdgcn_global_load_lds((gptr_t)(wbase + (size_t)i * 16 * Ktot + (size_t)woff), (lptr_t)(sB + i * 1024), 16, 0, 0);
+      __builtin_amdgcn_global_load_lds((gptr_t)(wbase + (size_t)i * wstep + (size_t)woff), (lptr_t)(sB + i * 1024), 16, 0, 0);
   };
 
   const int fr = lane & 15, fq = lane >> 4, sw = lane & 7;

@@ -177,15 +177,31 @@ class LiteEngine:
         self._last = (self.l2norm(emb, B, self.cfg.embed_dim, "seg"), B)
         return self._last[0][0].download(np.float32, (B, self.cfg.embed_dim))
 
-    def score_last(self, profiles: np.ndarray, k: int = 1) -> Tuple[np.ndarray, np.ndarray]:
-        """Cosine top-k of the segments of the last embed_pcm() call against `profiles` [P, d] fp32 -> (idx [B, k] int32, score [B, k] fp32)."""
+    def score_last(self, profiles: np.ndarray, k: int = 1, norm=None, on_norm=None, tag=None) -> Tuple[np.ndarray, np.ndarray]:
+        """Cosine top-k of the segments of the last embed_pcm() call against `profiles` [P, d] fp32 -> (idx [B, k] int32, score [B, k] fp32).
+        norm = (E fp32, Eb bf16 bits, resid) of a packed profile store (store.load_pack): uploaded as they are, no normalisation pass;
+        on_norm(E, Eb bits, resid): called once with the device's normalisation of `profiles` (store.publish_pack); tag: identity of the
+        profile set - the device copies of the previous call are reused when it repeats (per-bucket / per-label scoring of one batch)."""
         (E, Eb, re), B = self._last
-        P = np.ascontiguousarray(profiles, dtype=np.float32)
-        Pn, d = P.shape
+        Pn, d = profiles.shape
         k = min(k, Pn)
-        Pd = self._buf("prof", P.nbytes).upload(P)
-        Pe, Pb, rp = self.l2norm(Pd, Pn, d, "prof")
-        rmax = self._buf("rpmax", 4).upload(np.array([rp.download(np.float32, (Pn,)).max()], dtype=np.float32))
+        if tag is not None and getattr(self, "_prof_tag", None) == (tag, Pn):
+            Pe, Pb, rmax = self._prof_dev
+        else:
+            if norm is not None:
+                nE, nEb, nr = (np.ascontiguousarray(x) for x in norm)
+                Pe = self._buf("prof_E", nE.nbytes).upload(nE)
+                Pb = self._buf("prof_Eb", nEb.nbytes).upload(nEb)
+                r_host = np.asarray(nr, dtype=np.float32)
+            else:
+                P = np.ascontiguousarray(profiles, dtype=np.float32)
+                Pd = self._buf("prof", P.nbytes).upload(P)
+                Pe, Pb, rp = self.l2norm(Pd, Pn, d, "prof")
+                r_host = rp.download(np.float32, (Pn,))
+                if on_norm is not None:
+                    on_norm(Pe.download(np.float32, (Pn, d)), Pb.download(np.uint16, (Pn, d)), r_host)
+            rmax = self._buf("rpmax", 4).upload(np.array([r_host.max()], dtype=np.float32))
+            self._prof_tag, self._prof_dev = ((tag, Pn) if tag is not None else None), (Pe, Pb, rmax)
         idx, sc = self._buf("idx", B * k * 4), self._buf("sc", B * k * 4)
         ws = self._buf("aff_ws", self.lib.sdk_affinity_workspace_bytes(B, Pn))
         check(self.lib.sdk_affinity_topk(self.ctx, E.ptr, Eb.ptr, re.ptr, Pe.ptr, Pb.ptr, rmax.ptr, B, Pn, d, k, idx.ptr, sc.ptr, None,

@@ -10,6 +10,13 @@ a vector.  This module gives the directory its content:
     embeddings/<speaker_id>/<emb-id>.npy  hard link made at identify time, once both ids are known
                                           (keeps speaker-report's per-speaker count meaningful)
 
+    embeddings/packs/pack-<model>-<set>.npy  PACKED profile matrix of one candidate set (+ .json side table): the fp32 rows, their
+                                          L2-normalised bf16 copy and the rounding residuals as sdk_l2norm wrote them, so a
+                                          later process maps ONE file, uploads and scores - no per-embedding file I/O
+                                          (the reference loads every db/*.json per call, speaker_detection:206-220,1054;
+                                          at BASELINE's 1k / 10k profiles one np.load + one link probe per embedding is
+                                          10^4 small-file opens per CLI process)
+
 and the batch loader turns a list of candidate profile dicts (the `db/<id>.json` objects
 cmd_identify passes down, speaker_detection:1054-1071) into ONE [P, 192] matrix + side tables.
 """
@@ -80,9 +87,19 @@ def adopt(external_id: str, speaker_id: str, emb_id: str, root: Optional[Path] =
     dst_dir.mkdir(parents=True, exist_ok=True)
     try:
         os.link(src, dst)
+    except FileExistsError:
+        return                                   # another CLI process linked it between the probe and here (speaker-process runs four at once)
     except OSError:
         import shutil
-        shutil.copyfile(src, dst)
+        tmp = dst_dir / f".{emb_id}.{os.getpid()}.tmp"
+        try:                                     # no hard links on this file system: copy, published atomically
+            shutil.copyfile(src, tmp)
+            os.replace(tmp, dst)
+        except OSError:
+            pass
+
+
+_BATCH_UID = __import__("itertools").count(1)
 
 
 @dataclass
@@ -93,6 +110,13 @@ class ProfileBatch:
     embedding_ids: List[Optional[str]] = field(default_factory=list)
     trust_levels: List[str] = field(default_factory=list)
     skipped: List[str] = field(default_factory=list)   # human-readable reasons
+    # packed store (see pack_*): `norm` = (E fp32 [P,192], Eb bf16 bits uint16 [P,192], resid fp32 [P]) exactly as sdk_l2norm produced them when
+    # the pack was built (pack hit: memory-mapped, upload and score; None: normalise on the device); `pack_ref` = where to publish them after
+    # the first normalisation of a batch that was loaded file by file (pack miss); `from_pack` says which of the two happened
+    norm: Optional[tuple] = None
+    pack_ref: Optional[tuple] = None
+    from_pack: bool = False
+    uid: int = field(default_factory=lambda: next(_BATCH_UID))      # process-unique identity (device-copy reuse across scoring calls of one batch)
 
     def __len__(self) -> int:
         return len(self.speaker_ids)
@@ -108,14 +132,125 @@ class ProfileBatch:
                 + f"; first: {self.skipped[0]}")
 
 
+# ---------------------------------------------------------------------------------------------------------------- packed profile matrix (k7)
+PACK_FORMAT = 1
+PACK_KEEP = 8          # packs kept per store (one per candidate set x model; the oldest are pruned at publish time)
+
+
+def pack_enabled() -> bool:
+    return os.environ.get("SDK_PROFILE_PACK", "1") != "0"
+
+
+def pack_min_rows() -> int:
+    """Below this many embeddings the per-file loader is as fast as the pack (default 16)."""
+    return max(1, int(os.environ.get("SDK_PROFILE_PACK_MIN", "16")))
+
+
+def candidate_digest(candidates: List[Dict[str, Any]], backend_name: str, model_prefix: Optional[str], model_version: Optional[str]) -> str:
+    """Identity of a candidate set as the loader sees it: every (speaker id, embedding id, external_id, model_version, trust level) of the
+    backend's records, in order, plus the filter arguments.  The by-hash files are content-addressed (external_id = hash of the vector), so
+    the keys alone pin the matrix: no stat() per embedding is needed to notice a change - a re-enrolment changes a key, a deletion removes one."""
+    h = hashlib.sha256(f"pack{PACK_FORMAT}|{backend_name}|{model_prefix}|{model_version}|{EMBED_DIM}\n".encode())
+    for prof in candidates:
+        sid = prof.get("id")
+        for rec in prof.get("embeddings", {}).get(backend_name, []) or []:
+            h.update(f"{sid}|{rec.get('id')}|{rec.get('external_id')}|{rec.get('model_version', 'unknown')}|{rec.get('trust_level', 'unknown')}\n".encode())
+    return h.hexdigest()[:20]
+
+
+def _pack_paths(root: Optional[Path], model_version: Optional[str], digest: str):
+    tag = hashlib.sha256(str(model_version).encode()).hexdigest()[:10]
+    d = (root or embeddings_root()) / "packs"
+    return d / f"pack-{tag}-{digest}.npy", d / f"pack-{tag}-{digest}.json"
+
+
+def load_pack(candidates: List[Dict[str, Any]], backend_name: str, model_prefix: Optional[str] = None, root: Optional[Path] = None,
+              model_version: Optional[str] = None) -> Optional[ProfileBatch]:
+    """The packed matrix of exactly this candidate set, memory-mapped, or None (no pack, stale format, truncated file).  One JSON read +
+    one mmap whatever P is."""
+    import json
+    digest = candidate_digest(candidates, backend_name, model_prefix, model_version)
+    npy, side = _pack_paths(root, model_version, digest)
+    try:
+        t = json.loads(side.read_text())
+        if t.get("format") != PACK_FORMAT or t.get("digest") != digest or t.get("dim") != EMBED_DIM:
+            return None
+        P = int(t["rows"])
+        blob = np.load(npy, mmap_mode="r", allow_pickle=False)
+    except (OSError, ValueError, KeyError, TypeError):
+        return None
+    per_row = 2 * EMBED_DIM * 4 + EMBED_DIM * 2 + 4          # layout: [matrix fp32 P x 192][E fp32 P x 192][Eb bf16 bits P x 192][resid fp32 P]
+    if blob.dtype != np.uint8 or blob.ndim != 1 or blob.size != P * per_row or any(len(t.get(k, ())) != P for k in ("speaker_ids", "embedding_ids", "trust_levels")):
+        return None
+    return _pack_batch(blob, P, t)
+
+
+def _pack_batch(blob: np.ndarray, P: int, t: dict) -> ProfileBatch:
+    a = P * EMBED_DIM * 4
+    mat = blob[:a].view(np.float32).reshape(P, EMBED_DIM)
+    E = blob[a:2 * a].view(np.float32).reshape(P, EMBED_DIM)
+    Eb = blob[2 * a:2 * a + P * EMBED_DIM * 2].view(np.uint16).reshape(P, EMBED_DIM)
+    r = blob[2 * a + P * EMBED_DIM * 2:].view(np.float32)
+    return ProfileBatch(mat, list(t["speaker_ids"]), list(t["embedding_ids"]), list(t["trust_levels"]), list(t.get("skipped", [])),
+                        norm=(E, Eb, r), from_pack=True)
+
+
+def publish_pack(batch: ProfileBatch, E: np.ndarray, Eb_bits: np.ndarray, resid: np.ndarray) -> Optional[Path]:
+    """Write the pack of a batch that was loaded file by file (batch.pack_ref), with the normalised copies the device produced for it.
+    Atomic (tmp + rename, the side table LAST so a reader never sees a table without its matrix); concurrent builders of the same set write
+    identical bytes and the last rename wins (speaker-process:627-629 runs up to 4 CLI processes at once).  Best effort: a read-only store
+    must not break identify."""
+    import json
+    if not batch.pack_ref:
+        return None
+    npy, side, digest = batch.pack_ref
+    P = len(batch)
+    E = np.ascontiguousarray(E, dtype=np.float32)
+    Eb_bits = np.ascontiguousarray(Eb_bits, dtype=np.uint16)
+    resid = np.ascontiguousarray(resid, dtype=np.float32)
+    if E.shape != (P, EMBED_DIM) or Eb_bits.shape != (P, EMBED_DIM) or resid.shape != (P,):
+        raise ValueError(f"publish_pack: normalised arrays {E.shape} {Eb_bits.shape} {resid.shape} do not match {P} profiles")
+    try:
+        npy.parent.mkdir(parents=True, exist_ok=True)
+        blob = np.concatenate([np.ascontiguousarray(batch.matrix, dtype=np.float32).view(np.uint8).reshape(-1), E.view(np.uint8).reshape(-1),
+                               Eb_bits.view(np.uint8).reshape(-1), resid.view(np.uint8).reshape(-1)])
+        tmp = npy.parent / f".{npy.stem}.{os.getpid()}.tmp.npy"
+        np.save(tmp, blob)
+        os.replace(tmp, npy)
+        tmpj = npy.parent / f".{side.stem}.{os.getpid()}.tmp.json"
+        tmpj.write_text(json.dumps({"format": PACK_FORMAT, "digest": digest, "dim": EMBED_DIM, "rows": P, "speaker_ids": batch.speaker_ids,
+                                    "embedding_ids": batch.embedding_ids, "trust_levels": batch.trust_levels, "skipped": batch.skipped}))
+        os.replace(tmpj, side)
+        packs = sorted(npy.parent.glob("pack-*.json"), key=lambda q: q.stat().st_mtime, reverse=True)
+        for old in packs[PACK_KEEP:]:                                      # bounded: one pack per (candidate set, model)
+            for q in (old, old.with_suffix(".npy")):
+                try:
+                    q.unlink()
+                except OSError:
+                    pass
+    except OSError:
+        return None
+    batch.pack_ref = None
+    return npy
+
+
 def load_profile_batch(candidates: List[Dict[str, Any]], backend_name: str, model_prefix: Optional[str] = None,
-                       root: Optional[Path] = None, link: bool = True, model_version: Optional[str] = None) -> ProfileBatch:
+                       root: Optional[Path] = None, link: bool = True, model_version: Optional[str] = None,
+                       use_pack: Optional[bool] = None) -> ProfileBatch:
     """Gather every usable embedding of every candidate into one matrix.
+    use_pack (default: $SDK_PROFILE_PACK != 0): serve the set from its packed matrix when one exists (`from_pack`, `norm` set: ONE file mapped,
+    no per-embedding I/O); otherwise load file by file and leave `pack_ref` set so the caller publishes the pack after the first device
+    normalisation (publish_pack).
     Records with a foreign model_version prefix, a foreign external_id or a missing file are
     skipped with a reason (the caller logs them to stderr - never silently).
     `model_version` (exact) is stricter than the toolkit's prefix rule (base.py:92-93), which was written for a versioned
     remote API: a LOCAL model's version carries its weights digest, and a vector enrolled under other weights lives in a
     different embedding space - its cosines against the current model's embeddings are noise, so it is skipped too."""
+    use_pack = pack_enabled() if use_pack is None else use_pack
+    if use_pack:
+        hit = load_pack(candidates, backend_name, model_prefix, root, model_version)
+        if hit is not None:
+            return hit
     rows, sids, eids, trusts, skipped = [], [], [], [], []
     for prof in candidates:
         sid = prof.get("id")
@@ -140,19 +275,8 @@ def load_profile_batch(candidates: List[Dict[str, Any]], backend_name: str, mode
             eids.append(rec.get("id"))
             trusts.append(rec.get("trust_level", "unknown"))
     mat = np.stack(rows).astype(np.float32) if rows else np.zeros((0, EMBED_DIM), np.float32)
-    return ProfileBatch(mat, sids, eids, trusts, skipped)
-
-
-def save_matrix_pack(path: Path, batch: ProfileBatch) -> None:
-    """Optional packed form for large enrolments (10k+ profiles): one .npy + a JSON side table."""
-    import json
-    np.save(path, batch.matrix)
-    Path(str(path) + ".json").write_text(json.dumps({"speaker_ids": batch.speaker_ids, "embedding_ids": batch.embedding_ids,
-                                                     "trust_levels": batch.trust_levels}))
-
-
-def load_matrix_pack(path: Path, mmap: bool = True) -> ProfileBatch:
-    import json
-    mat = np.load(path, mmap_mode="r" if mmap else None, allow_pickle=False)
-    side = json.loads(Path(str(path) + ".json").read_text())
-    return ProfileBatch(mat, side["speaker_ids"], side["embedding_ids"], side["trust_levels"])
+    batch = ProfileBatch(mat, sids, eids, trusts, skipped)
+    if use_pack and len(batch) >= pack_min_rows():
+        digest = candidate_digest(candidates, backend_name, model_prefix, model_version)
+        batch.pack_ref = _pack_paths(root, model_version, digest) + (digest,)
+    return batch

@@ -164,3 +164,60 @@ def test_embed_windows_in_bounded_batches(monkeypatch):
     monkeypatch.setenv("SDK_MAX_BATCH", "1")
     E3 = be.embed_windows(pcm)[0]
     assert float((E1 - E3).abs().max()) < 1e-3
+
+
+PACK_CHILD = r"""
+import importlib, json, sys
+sys.path.insert(0, sys.argv[1])
+B = importlib.import_module(sys.argv[2] + ".backend")
+be = B.Backend()
+cands = json.load(open(sys.argv[3]))
+rows = be.identify_speaker(sys.argv[4], cands, threshold=-1.0)
+print(json.dumps({"rows": rows, "from_pack": bool(be.last_batch.from_pack), "torch": "torch" in sys.modules}))
+"""
+
+
+def test_profile_pack_hit_scores_bit_identically_to_the_miss_that_built_it(tmp_path, monkeypatch):
+    """k7: the first identify over a candidate set loads every embedding file, normalises on the device and publishes the set's
+    pack; a later Backend - and the torch-free host path in another process - maps that ONE file, uploads the normalised copies as packed and must
+    return the same rows bit for bit."""
+    import subprocess
+    import sys
+    monkeypatch.setenv("SPEAKERS_EMBEDDINGS_DIR", str(tmp_path / "store"))
+    monkeypatch.setenv("SDK_CACHE_DIR", str(tmp_path / "cache"))
+    store = sub("store")
+    be = sub("backend").Backend()
+    path = tmp_path / "meeting.wav"
+    wav.write_wav_s16(path, np.concatenate([_voice(40, 4.0, 95.0), _voice(41, 4.0, 140.0)]))
+    enr = tmp_path / "enr.wav"
+    wav.write_wav_s16(enr, _voice(10, 6.0, 140.0))
+    rec = be.enroll_speaker(enr)
+    mv = rec["model_version"]
+    cands = [{"id": "alice", "embeddings": {"mi355x": [{"id": "emb-alice", "external_id": rec["external_id"], "model_version": mv, "trust_level": "high"}]}}]
+    rng = np.random.default_rng(3)
+    for i in range(70):
+        v = rng.standard_normal(192).astype(np.float32) * np.float32(1.0 + 0.01 * i)         # not unit length: the device normalisation matters
+        cands.append({"id": f"spk{i}", "embeddings": {"mi355x": [{"id": f"emb-{i}", "external_id": store.save_vector(v), "model_version": mv}]}})
+    rows_miss = be.identify_speaker(path, cands, threshold=-1.0)
+    assert be.last_batch.from_pack is False and be.last_batch.pack_ref is None                 # published
+    assert len(list((tmp_path / "store" / "embeddings" / "packs").glob("pack-*.npy"))) == 1
+    be2 = sub("backend").Backend()
+    rows_hit = be2.identify_speaker(path, cands, threshold=-1.0)
+    assert be2.last_batch.from_pack is True
+    assert rows_hit == rows_miss and rows_miss[0]["speaker_id"] == "alice"
+    monkeypatch.setenv("SDK_PROFILE_PACK", "0")                                                # and both equal the plain per-file path
+    be3 = sub("backend").Backend()
+    assert be3.identify_speaker(path, cands, threshold=-1.0) == rows_miss and be3.last_batch.from_pack is False
+    monkeypatch.delenv("SDK_PROFILE_PACK")
+    (tmp_path / "cands.json").write_text(json.dumps(cands))
+    for lite in ("1", "0"):
+        env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0")
+        env.pop("SDK_NO_TORCH", None)
+        if lite == "1":
+            env["SDK_NO_TORCH"] = "1"
+        r = subprocess.run([sys.executable, "-c", PACK_CHILD, str(sub("backend").__file__.rsplit("/", 2)[0]), sub("backend").__package__,
+                            str(tmp_path / "cands.json"), str(path)], env=env, capture_output=True, text=True, timeout=300)
+        assert r.returncode == 0, r.stderr[-2000:]
+        got = json.loads([ln for ln in r.stdout.splitlines() if ln.startswith("{")][-1])
+        assert got["from_pack"] is True and got["torch"] is (lite == "0")
+        assert json.loads(json.dumps(rows_miss)) == got["rows"]

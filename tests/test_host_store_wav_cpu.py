@@ -131,9 +131,7 @@ def test_store_and_batch_loader(tmp_path, monkeypatch):
     assert np.array_equal(batch.matrix, vecs)
     # per-speaker links: what speaker-report counts (speaker-report:292-294)
     assert sorted(p.name for p in (tmp_path / "embeddings" / "alice").glob("*.npy")) == ["emb-a1.npy", "emb-a2.npy"]
-    store.save_matrix_pack(tmp_path / "pack.npy", batch)
-    again = store.load_matrix_pack(tmp_path / "pack.npy")
-    assert np.array_equal(np.asarray(again.matrix), vecs) and again.speaker_ids == batch.speaker_ids
+    assert batch.pack_ref is None and not batch.from_pack                                   # 3 rows: below SDK_PROFILE_PACK_MIN, no pack is offered
     with pytest.raises(ValueError):
         store.save_vector(np.zeros(10, np.float32))
     with pytest.raises(ValueError):
@@ -329,3 +327,118 @@ def test_packed_blob_cache_roundtrip_and_backend_digest(tmp_path, monkeypatch):
     # ... and from the weights themselves when the cache is switched off
     monkeypatch.setenv("SDK_WEIGHTS_CACHE", "0")
     assert wc.load_meta(be_key) is None
+
+
+# ---------------------------------------------------------------------------------------------------------------- packed profile matrix (k7)
+def _fake_norm(mat):
+    """Stand-in for sdk_l2norm on a CPU box: unit rows, their bf16 bits (round to nearest even) and the rounding residual norms."""
+    E = (mat / np.linalg.norm(mat, axis=1, keepdims=True)).astype(np.float32)
+    u = E.view(np.uint32)
+    bits = ((u + 0x7FFF + ((u >> 16) & 1)) >> 16).astype(np.uint16)
+    back = (bits.astype(np.uint32) << 16).view(np.float32)
+    return E, bits, np.linalg.norm(E - back, axis=1).astype(np.float32)
+
+
+def _enrol(n, seed=0, mv="mi355x-ecapa1024-x"):
+    rng = np.random.default_rng(seed)
+    vecs = rng.standard_normal((n, 192)).astype(np.float32)
+    vecs /= np.linalg.norm(vecs, axis=1, keepdims=True)
+    cands = [_profile(f"spk{i:05d}", [{"id": f"emb-{i}", "external_id": store.save_vector(v), "model_version": mv, "trust_level": "high" if i % 2 else "low"}])
+             for i, v in enumerate(vecs)]
+    return vecs, cands
+
+
+def test_profile_pack_miss_publish_hit(tmp_path, monkeypatch):
+    """the first identify over a candidate set loads file by file and publishes the set's pack; the next process maps
+    ONE file - same matrix, same side tables, the normalised copies exactly as published - and touches no per-embedding file."""
+    monkeypatch.setenv("SPEAKERS_EMBEDDINGS_DIR", str(tmp_path))
+    vecs, cands = _enrol(40)
+    cands[3]["embeddings"]["mi355x"].append({"id": "emb-foreign", "external_id": "AD1NQVAB", "model_version": "speechmatics-v2"})
+    kw = dict(model_prefix="mi355x-", model_version="mi355x-ecapa1024-x")
+    miss = store.load_profile_batch(cands, "mi355x", **kw)
+    assert not miss.from_pack and miss.norm is None and miss.pack_ref is not None and len(miss.skipped) == 1
+    E, bits, r = _fake_norm(miss.matrix)
+    path = store.publish_pack(miss, E, bits, r)
+    assert path is not None and path.exists() and miss.pack_ref is None
+    # the hit must not need the per-embedding files at all
+    for f in (tmp_path / "embeddings" / "by-hash").glob("*.npy"):
+        f.unlink()
+    hit = store.load_profile_batch(cands, "mi355x", **kw)
+    assert hit.from_pack and hit.pack_ref is None
+    assert np.array_equal(np.asarray(hit.matrix), vecs) and hit.speaker_ids == miss.speaker_ids and hit.embedding_ids == miss.embedding_ids
+    assert hit.trust_levels == miss.trust_levels and hit.skipped == miss.skipped
+    assert all(np.array_equal(np.asarray(a), b) for a, b in zip(hit.norm, (E, bits, r)))
+    assert hit.uid != miss.uid
+    # SDK_PROFILE_PACK=0: the per-file loader, which now finds nothing
+    monkeypatch.setenv("SDK_PROFILE_PACK", "0")
+    off = store.load_profile_batch(cands, "mi355x", **kw)
+    assert len(off) == 0 and not off.from_pack and off.pack_ref is None and len(off.skipped) == 41
+
+
+def test_profile_pack_goes_stale_with_the_candidate_set(tmp_path, monkeypatch):
+    monkeypatch.setenv("SPEAKERS_EMBEDDINGS_DIR", str(tmp_path))
+    vecs, cands = _enrol(20)
+    kw = dict(model_prefix="mi355x-", model_version="mi355x-ecapa1024-x")
+    b = store.load_profile_batch(cands, "mi355x", **kw)
+    store.publish_pack(b, *_fake_norm(b.matrix))
+    assert store.load_profile_batch(cands, "mi355x", **kw).from_pack
+    import copy
+    # (a) a trust level edited in db/*.json, (b) one speaker fewer, (c) a re-enrolment (new content hash), (d) other weights, (e) another order
+    c1 = copy.deepcopy(cands); c1[5]["embeddings"]["mi355x"][0]["trust_level"] = "medium"
+    c2 = cands[:-1]
+    c3 = copy.deepcopy(cands); c3[0]["embeddings"]["mi355x"][0]["external_id"] = store.save_vector(-vecs[0])
+    c5 = list(reversed(cands))
+    for variant in (c1, c2, c3, c5):
+        got = store.load_profile_batch(variant, "mi355x", **kw)
+        assert not got.from_pack and got.pack_ref is not None
+    assert not store.load_profile_batch(cands, "mi355x", model_prefix="mi355x-", model_version="mi355x-ecapa1024-y").from_pack
+    assert np.array_equal(store.load_profile_batch(c3, "mi355x", **kw).matrix[0], -vecs[0])
+    assert store.load_profile_batch(cands, "mi355x", **kw).from_pack                        # the original set's pack is still there
+    # a truncated / foreign pack file is ignored, never trusted
+    npy = next((tmp_path / "embeddings" / "packs").glob("pack-*.npy"))
+    raw = npy.read_bytes()
+    npy.write_bytes(raw[:len(raw) // 2])
+    assert not store.load_profile_batch(cands, "mi355x", **kw).from_pack
+    np.save(npy, np.zeros(7, np.float32))
+    assert not store.load_profile_batch(cands, "mi355x", **kw).from_pack
+
+
+def test_profile_pack_is_bounded(tmp_path, monkeypatch):
+    monkeypatch.setenv("SPEAKERS_EMBEDDINGS_DIR", str(tmp_path))
+    _, cands = _enrol(60)
+    kw = dict(model_prefix="mi355x-", model_version="mi355x-ecapa1024-x")
+    for n in range(20, 20 + store.PACK_KEEP + 4):
+        b = store.load_profile_batch(cands[:n], "mi355x", **kw)
+        store.publish_pack(b, *_fake_norm(b.matrix))
+        os.utime(next(iter(sorted((tmp_path / "embeddings" / "packs").glob("pack-*.json"), key=lambda q: q.stat().st_mtime, reverse=True))), (n, n))
+    assert len(list((tmp_path / "embeddings" / "packs").glob("pack-*.json"))) == store.PACK_KEEP
+    assert len(list((tmp_path / "embeddings" / "packs").glob("pack-*.npy"))) == store.PACK_KEEP
+
+
+def _pack_builder(root, n, barrier, q):
+    os.environ["SPEAKERS_EMBEDDINGS_DIR"] = root
+    _, cands = _enrol(n)                                    # content-addressed: every process writes / finds the same by-hash files
+    barrier.wait()
+    b = store.load_profile_batch(cands, "mi355x", model_prefix="mi355x-", model_version="mi355x-ecapa1024-x")
+    if not b.from_pack:
+        store.publish_pack(b, *_fake_norm(b.matrix))
+    again = store.load_profile_batch(cands, "mi355x", model_prefix="mi355x-", model_version="mi355x-ecapa1024-x")
+    q.put((b.from_pack, again.from_pack, bool(np.array_equal(np.asarray(again.matrix), b.matrix)), len(again)))
+
+
+def test_profile_pack_four_concurrent_builders(tmp_path):
+    """speaker-process runs up to four CLI processes at once (speaker-process:627-629): four builders of the same set race; every one of them ends
+    with a valid pack and the survivor is complete (atomic publish: matrix first, side table last)."""
+    import multiprocessing as mp
+    ctx = mp.get_context("spawn")
+    barrier, q = ctx.Barrier(4), ctx.Queue()
+    procs = [ctx.Process(target=_pack_builder, args=(str(tmp_path), 300, barrier, q)) for _ in range(4)]
+    for pr in procs:
+        pr.start()
+    res = [q.get(timeout=120) for _ in procs]
+    for pr in procs:
+        pr.join(timeout=60)
+        assert pr.exitcode == 0
+    assert all(r[1] and r[2] and r[3] == 300 for r in res), res
+    packs = list((tmp_path / "embeddings" / "packs").glob("pack-*"))
+    assert sorted(q_.suffix for q_ in packs) == [".json", ".npy"], packs                      # one pack, no temporary files left behind

@@ -5,9 +5,12 @@
 steady-state step.  Prints one JSON object with the phases in seconds.  Run it twice: the second process finds the packed blob in
 the on-disk cache (weights_cache.py) and skips generate / digest / pack.
 
-    python tools/cold_start.py [--seconds 12] [--no-cache] [--lite]
+    python tools/cold_start.py [--seconds 12] [--no-cache] [--lite] [--profiles P --store DIR]
 
 --lite: the torch-free host path (SDK_NO_TORCH=1, lite.py): the same library calls without `import torch`.
+--profiles P: identify against P enrolled embeddings (BASELINE configs #3 / #4: 1 000 / 10 000) kept in --store DIR (populated, untimed, on first
+  use; reused by later processes): the first process over a candidate set loads them file by file and publishes the set's PACK
+  (store.publish_pack), later processes map that one file (`profile_pack_hit`).
 """
 import argparse, json, os, sys, tempfile, time
 t_proc = time.perf_counter()
@@ -18,6 +21,8 @@ ap = argparse.ArgumentParser()
 ap.add_argument("--seconds", type=float, default=12.0)
 ap.add_argument("--no-cache", action="store_true")
 ap.add_argument("--lite", action="store_true")
+ap.add_argument("--profiles", type=int, default=1)
+ap.add_argument("--store", default=None)
 a = ap.parse_args()
 if a.no_cache:
     os.environ["SDK_WEIGHTS_CACHE"] = "0"
@@ -40,7 +45,8 @@ wav = importlib.import_module("speaker-diarization-toolkit_amd.wav")
 t = mark("import_package", t)
 be = api.get_backend("mi355x")
 t = mark("get_backend", t)
-tmp = Path(tempfile.mkdtemp(prefix="cold_"))
+tmp = Path(a.store) if a.store else Path(tempfile.mkdtemp(prefix="cold_"))
+tmp.mkdir(parents=True, exist_ok=True)
 os.environ["SPEAKERS_EMBEDDINGS_DIR"] = str(tmp)
 rng = np.random.default_rng(0)
 n = int(16000 * a.seconds)
@@ -60,6 +66,16 @@ rec = be.enroll_speaker(tmp / "a.wav")                          # first GPU pass
 sync()
 t = mark("first_enroll (code objects, tables, scratch)", t)
 cand = [{"id": "a", "embeddings": {"mi355x": [{"id": "emb-a", "external_id": rec["external_id"], "model_version": rec["model_version"]}]}}]
+if a.profiles > 1:      # P - 1 further enrolled speakers (random unit vectors, content-addressed: a later process finds the same files); untimed set-up
+    st = importlib.import_module("speaker-diarization-toolkit_amd.store")
+    extra = np.random.default_rng(1).standard_normal((a.profiles - 1, 192)).astype(np.float32)
+    extra /= np.linalg.norm(extra, axis=1, keepdims=True)
+    have = (tmp / f".populated_{a.profiles}").exists()
+    for i, v in enumerate(extra):
+        ext = (st.EXTERNAL_PREFIX + st.vector_key(v)) if have else st.save_vector(v)
+        cand.append({"id": f"spk{i:05d}", "embeddings": {"mi355x": [{"id": f"emb-{i}", "external_id": ext, "model_version": rec["model_version"]}]}})
+    (tmp / f".populated_{a.profiles}").write_text("1")
+    t = time.perf_counter()
 rows = be.identify_speaker(tmp / "a.wav", cand)
 sync()
 t = mark("first_identify", t)
@@ -69,5 +85,6 @@ t = mark("second_identify", t)
 wc = importlib.import_module("speaker-diarization-toolkit_amd.weights_cache")
 out = {"phases_s": ph, "time_to_first_row_s": round(sum(v for k, v in ph.items() if k != "second_identify"), 3),
        "process_wall_s": round(time.perf_counter() - t_proc, 3), "audio_seconds": a.seconds, "windows": rows[0]["n_segments"] if rows else 0,
+       "profiles": a.profiles, "profile_pack_hit": bool(getattr(getattr(be, "last_batch", None), "from_pack", False)),
        "cache": {"enabled": wc.enabled(), "dir": str(wc.cache_dir()), "hit": bool(getattr(be, "_cache_hit", False))}, "model_version": mv, "lite": bool(a.lite), "torch_imported": "torch" in sys.modules}
 print(json.dumps(out))
