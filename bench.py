@@ -229,6 +229,45 @@ def xvector_object(eng, pcm, pcm_host, P_host, Pn, Pb, rpm, n_par=16):
                                       "id_mismatches": par32["id_mismatches"], "note": "bf16 operands, no bias correction for this family"}}
 
 
+def ingest_object(eng, pcm_host, Pn, Pb, rpm, resident_value, n_steps=50):
+    """The same step with its 1000 segments starting in HOST memory (outside the timed region): the batch crosses PCIe once
+    per step through the pinned, double-buffered staging slots (csrc/ingest.hip: the upload of step i + 1 runs under the forward pass of step
+    i), the windows are cut on the device from a start table (sdk_fbank_windows).  `value_from_host` next to the resident headline."""
+    B, S = pcm_host.shape
+    rec = np.ascontiguousarray(pcm_host).reshape(-1)                 # the 1000 two-second segments as they lie in host memory (pageable)
+    tables = {S: (np.arange(B, dtype=np.int64) * S).astype(np.int32)}
+
+    def step():
+        E, Eb, re = eng.embed_from_host(rec, tables, step=B)[S]
+        return E, eng.affinity_topk(E, Eb, re, Pn, Pb, rpm, k=1)
+    for _ in range(3):
+        step()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(n_steps):
+        E, (gi, gs) = step()
+    torch.cuda.synchronize()
+    dt = time.perf_counter() - t0
+    ms, nbytes = eng.ingest().copy_ms(eng.last_ingest_ticket)
+    Er = eng.embed_pcm(torch.from_numpy(pcm_host).to(eng.device))[0]
+    t1 = time.perf_counter()
+    for _ in range(5):
+        tk, _, _ = eng.ingest().submit(rec, tables[S], S, torch.cuda.current_stream().cuda_stream)
+        eng.ingest().release(tk, torch.cuda.current_stream().cuda_stream)
+    torch.cuda.synchronize()
+    host_ms = (time.perf_counter() - t1) / 5 * 1e3
+    val = B * n_steps / dt
+    return {"workload": f"config #2 step with the {B} segments starting in pageable HOST memory ({rec.nbytes / 1e6:.0f} MB per step + a {B}-entry start table)",
+            "steps": n_steps, "value_from_host": round(val, 1), "unit": "segment-embeddings/sec", "ms_per_step": round(dt / n_steps * 1e3, 3),
+            "ratio_to_resident_headline": round(val / resident_value, 4),
+            "pcie": {"bytes_per_step": nbytes, "copy_ms": round(ms, 3), "achieved_GBps": round(nbytes / (ms * 1e-3) / 1e9, 1), "peak_GBps_spec": 63.0,
+                     "note": "one H2D DMA per step from pinned staging, HIP events on the copy stream"},
+            "host_staging_ms_per_step": round(host_ms, 3),
+            "embeddings_bit_identical_to_resident_path": bool(torch.equal(E, Er)),
+            "pipeline": "2 pinned slots + 2 device slots, copy stream of its own; submit = host memcpy into pinned memory (4 threads) + async DMA; the compute stream "
+                        "waits on the slot's `copied` event, the slot's next upload waits on its `consumed` event"}
+
+
 def cold_start_object(timeout_s=120):
     """Time to the first identify row in a fresh process (tools/cold_start.py), once with an empty packed-blob cache and once with the
     entry the first run wrote.  Child processes: they initialise the GPU themselves; this process never re-execs."""
@@ -608,7 +647,22 @@ def main() -> int:
                 out["xvector"] = xvector_object(eng, pcm, pcm_host, P_host, Pn, Pb, rpm)
             except Exception as exc:  # noqa: BLE001
                 out["xvector"] = {"error": repr(exc)[:300]}
+            try:
+                out["ingest"] = ingest_object(eng, pcm_host, Pn, Pb, rpm, value)
+            except Exception as exc:  # noqa: BLE001
+                out["ingest"] = {"error": repr(exc)[:300]}
             out["cold_start"] = cold_start_object()
+            # the headline is never quoted without the two figures that qualify it
+            pm = out.get("precision_modes", {})
+            out["value_at_north_star_tolerance"] = pm.get("precise", {}).get("value") if isinstance(pm, dict) else None
+            out["default_mode_dscore"] = out.get("parity", {}).get("max_abs_dscore_all_pairs")
+            out["value_from_host"] = out["ingest"].get("value_from_host")
+        # the contract's fields and the figures that qualify the headline first, the large objects after them (a record that keeps only the
+        # head of the line still carries: the mode that meets north_star's 1e-5 runs at value_at_north_star_tolerance; the default mode's
+        # PCM -> score deviation is default_mode_dscore; value_from_host = the same step with its inputs starting in host memory)
+        front = ["metric", "value", "unit", "value_at_north_star_tolerance", "default_mode_dscore", "value_from_host", "n_gpus", "steps", "warmup", "prewarm_steps",
+                 "ms_per_step", "higher_is_better", "scaling", "vs_baseline", "dtype", "data", "config", "roofline", "cpu_baseline"]
+        out = {**{k: out[k] for k in front if k in out}, **{k: v for k, v in out.items() if k not in front}}
         print(json.dumps(out), flush=True)
 
     if use_dist:

@@ -23,7 +23,8 @@
  *     sdk_abi_version  sdk_init  sdk_shutdown  sdk_last_error  sdk_get_device_info
  *     sdk_device_malloc  sdk_device_free  sdk_memcpy  sdk_stream_synchronize          device memory for hosts without an allocator of their own
  *     sdk_resample_out_len  sdk_resample_s16                                   audio -> AudioProfile format
- *     sdk_fbank_tables_bytes  sdk_fbank_tables_fill  sdk_fbank_workspace_bytes  sdk_fbank              k1
+ *     sdk_fbank_tables_bytes  sdk_fbank_tables_fill  sdk_fbank_workspace_bytes  sdk_fbank  sdk_fbank_windows          k1
+ *     sdk_ingest_create / _destroy / _acquire / _commit / _submit / _release / _copy_ms          host audio -> HBM, pinned + double-buffered
  *     sdk_ecapa_workspace_bytes  sdk_ecapa_forward  sdk_ecapa_calib_floats  sdk_ecapa_forward_calib            k2
  *     sdk_xvector_workspace_bytes  sdk_xvector_forward                                                  k2 (second model family)
  *     sdk_l2norm                                                                                        k3
@@ -47,7 +48,7 @@
 extern "C" {
 #endif
 
-#define SDK_ABI_VERSION 2   /* 2: sdk_ecapa_desc.precision (round 3) */
+#define SDK_ABI_VERSION 3   /* 2: sdk_ecapa_desc.precision (round 3); 3: sdk_fbank_windows + sdk_ingest_* (round 4) */
 
 typedef struct sdk_ctx sdk_ctx;
 
@@ -115,13 +116,43 @@ int sdk_profile_end(sdk_ctx* ctx, sdk_profile_report* out);   /* synchronises th
  * ws    caller scratch of sdk_fbank_workspace_bytes(B, S)
  * feats [B*T, ldf] bf16, channels 0..79 = mean-normalised log-mel, 80..ldf-1 = 0 (ldf >= 80)
  *       precise mode ("precision" 1): fp16 planes, hi in columns [0, ldf/2), lo in [ldf/2, ldf), channels >= 80 of each zero
- *       (ldf/2 >= 80, ldf % 16 == 0); the DFT then runs with a THREE-way bf16 split of the table (6 MFMAs per product)
+ *       (ldf/2 >= 80, ldf % 16 == 0); the DFT then runs on fp16 MFMAs with an fp16 hi+lo table (the folded int16 samples split exactly in
+ *       fp16 too: three MFMAs per product)
  */
 size_t sdk_fbank_tables_bytes(void);
 int sdk_fbank_tables_fill(void* host_dst, size_t bytes);          /* HOST buffer */
 size_t sdk_fbank_workspace_bytes(int B, int S);                    /* fp32 log-mel scratch */
 int sdk_fbank(sdk_ctx* ctx, const int16_t* pcm, int B, int S, const void* tabs,
               uint16_t* feats, int ldf, void* ws, size_t ws_bytes, void* stream);
+/* The same, with the windows cut ON THE DEVICE from ONE resident recording (the boundary hands a backend a path and segments,
+ * base.py:130-151; the reference cuts with ffmpeg per segment list, speechmatics_backend.py:231-281): samples [n_samples] int16 (device),
+ * starts [B] int32 (device) = first sample of every window, each inside the recording; window b = samples[starts[b] .. starts[b] + S), samples
+ * past the recording's end read as zero.  Bit-identical to sdk_fbank on the materialised [B, S] windows; the overlapping windows (2x the
+ * samples at hop 1 s / window 2 s) never exist on the host and never cross PCIe.  n_samples < 2^31. */
+int sdk_fbank_windows(sdk_ctx* ctx, const int16_t* samples, int64_t n_samples, const int32_t* starts, int B, int S, const void* tabs,
+                      uint16_t* feats, int ldf, void* ws, size_t ws_bytes, void* stream);
+
+/* ---- ingest: host audio -> HBM, staged through pinned memory on a copy stream of its own, `depth`-deep (2 = double-buffered) so that the
+ *      upload of recording i + 1 runs under the forward pass of recording i.  A slot = pinned host buffers for max_samples int16 and
+ *      max_windows int32 window starts + their device twins.
+ *   sdk_ingest_acquire : next slot (ring order); *pinned_samples / *pinned_starts are HOST pointers the caller fills (a file reader can
+ *                        read straight into them: no second host copy).  Fails if that slot was committed and never released.
+ *   sdk_ingest_commit  : validates the start table (every start inside [0, n_samples)), enqueues the uploads on the copy stream - behind the
+ *                        slot's previous consumer, without blocking the host - and makes `compute_stream` wait for them;
+ *                        *dev_samples / *dev_starts are DEVICE pointers for sdk_fbank_windows (any sub-range of the table may be launched)
+ *   sdk_ingest_submit  : acquire + memcpy from pageable host memory + commit
+ *   sdk_ingest_release : call after the LAST kernel reading the slot has been enqueued on compute_stream; the slot's next upload waits for it
+ *   sdk_ingest_copy_ms : duration / bytes of the slot's last upload (HIP events on the copy stream; synchronises with that upload) */
+typedef struct sdk_ingest sdk_ingest;
+int sdk_ingest_create(sdk_ctx* ctx, int64_t max_samples, int max_windows, int depth, sdk_ingest** out);
+int sdk_ingest_destroy(sdk_ingest* ing);
+int sdk_ingest_acquire(sdk_ingest* ing, int* ticket, int16_t** pinned_samples, int32_t** pinned_starts);
+int sdk_ingest_commit(sdk_ingest* ing, int ticket, int64_t n_samples, int n_windows, int window_len, void* compute_stream,
+                      const int16_t** dev_samples, const int32_t** dev_starts);
+int sdk_ingest_submit(sdk_ingest* ing, const int16_t* host_samples, int64_t n_samples, const int32_t* host_starts, int n_windows,
+                      int window_len, void* compute_stream, int* ticket, const int16_t** dev_samples, const int32_t** dev_starts);
+int sdk_ingest_release(sdk_ingest* ing, int ticket, void* compute_stream);
+int sdk_ingest_copy_ms(sdk_ingest* ing, int ticket, float* ms, double* bytes);
 
 /* ---- k2 building blocks (ECAPA-TDNN forward; behind EmbeddingBackend.enroll_speaker /
  *      identify_speaker, base.py:107-151) -------------------------------------------------- */

@@ -65,7 +65,7 @@ KERNEL_FAMILIES = ["conv_gemm", "se_gate", "asp_stats", "rows_fc", "asp_pool", "
                    "affinity_coarse", "affinity_rescore", "affinity_rescan", "copy", "affinity_matvec", "conv_gemm256", "asp_fused", "res2net_chain", "resample",
                    "conv_gemm_hp"]
 
-ABI_VERSION = 2
+ABI_VERSION = 3
 GEMM_RELU = 1
 GEMM_TANH = 2
 
@@ -86,6 +86,14 @@ SIGNATURES = {
     "sdk_fbank_tables_fill": (_i, [_vp, _sz]),
     "sdk_fbank_workspace_bytes": (_sz, [_i, _i]),
     "sdk_fbank": (_i, [_vp, _vp, _i, _i, _vp, _vp, _i, _vp, _sz, _vp]),
+    "sdk_fbank_windows": (_i, [_vp, _vp, _i64, _vp, _i, _i, _vp, _vp, _i, _vp, _sz, _vp]),
+    "sdk_ingest_create": (_i, [_vp, _i64, _i, _i, C.POINTER(_vp)]),
+    "sdk_ingest_destroy": (_i, [_vp]),
+    "sdk_ingest_acquire": (_i, [_vp, C.POINTER(_i), C.POINTER(_vp), C.POINTER(_vp)]),
+    "sdk_ingest_commit": (_i, [_vp, _i, _i64, _i, _i, _vp, C.POINTER(_vp), C.POINTER(_vp)]),
+    "sdk_ingest_submit": (_i, [_vp, _vp, _i64, _vp, _i, _i, _vp, C.POINTER(_i), C.POINTER(_vp), C.POINTER(_vp)]),
+    "sdk_ingest_release": (_i, [_vp, _i, _vp]),
+    "sdk_ingest_copy_ms": (_i, [_vp, _i, C.POINTER(C.c_float), C.POINTER(C.c_double)]),
     "sdk_conv_gemm": (_i, [_vp, C.POINTER(ConvGemmArgs), _vp]),
     "sdk_conv_gemm_hp": (_i, [_vp, C.POINTER(ConvGemmHpArgs), _vp]),
     "sdk_set_gemm_variant": (_i, [_i]),

@@ -38,7 +38,7 @@ import numpy as np
 from . import BACKEND_NAME
 from .plugin_api import EmbeddingBackend
 from .store import load_profile_batch, publish_pack, save_vector, vector_path
-from .wav import cut_ranges, cut_windows, decode_to_profile
+from .wav import cut_ranges, cut_windows, decode_to_profile, range_starts, window_starts
 from .weights import DEFAULT_CONFIG, load_weights, synthetic_weights, weights_digest
 
 
@@ -225,11 +225,31 @@ class Backend(EmbeddingBackend):
         return (E, np.concatenate(idxs), np.concatenate(scs)) if profiles is not None else (E, None, None)
 
     def _windows(self, audio_path: Path, segments):
+        """Decoded recording + the table of its analysis windows (first samples; nothing is cut on the host)."""
         samples = decode_to_profile(Path(audio_path), self.engine(), self.get_audio_profile())   # other rates / layouts: GPU resampler
-        pcm, spans = cut_windows(samples, segments, window_s=self.window_s, hop_s=self.hop_s)
+        starts, spans, W = window_starts(len(samples), segments, window_s=self.window_s, hop_s=self.hop_s)
         if len(spans) == 0:
             raise ValueError(f"{audio_path}: no analysable audio (every segment shorter than 0.5 s)")
-        return pcm, spans
+        return samples, starts, W, spans
+
+    def embed_tables(self, samples: np.ndarray, tables: Dict[int, np.ndarray]):
+        """The ingest path: one recording in host memory + window-start tables {window samples S: int32 [B_S]} ->
+        {S: (E, Eb, resid)} device tensors.  The recording crosses PCIe once, through pinned staging on a copy stream (the next call's upload
+        overlaps this call's forward); the overlapping windows are cut on the device (sdk_fbank_windows) in batches of SDK_MAX_BATCH."""
+        eng = self.engine()
+        if self.lite:
+            raise RuntimeError("embed_tables returns device tensors: not available with SDK_NO_TORCH=1 (use embed_tables_host)")
+        step = max(1, int(os.environ.get("SDK_MAX_BATCH", "2048")))
+        return eng.embed_from_host(samples, tables, step, forward=self._xvector.forward if self._xvector is not None else None)
+
+    def embed_tables_host(self, samples: np.ndarray, tables: Dict[int, np.ndarray], batch=None, k: int = 1):
+        """The same for the torch-free host path: {S: (E host, idx, score)}; with a ProfileBatch every batch of windows is scored while resident."""
+        eng = self.engine()
+        step = max(1, int(os.environ.get("SDK_MAX_BATCH", "2048")))
+        kw = None
+        if batch is not None:
+            kw = {"norm": batch.norm, "tag": batch.uid, "on_norm": (lambda E, Eb, r: publish_pack(batch, E, Eb, r)) if batch.pack_ref else None}
+        return eng.embed_from_host(samples, tables, step, profiles=batch.matrix if batch is not None else None, k=k, score_kw=kw)
 
     def embed_ranges(self, samples: np.ndarray, ranges: List[Tuple[float, float]]):
         """Single-speaker ranges (sentences, enrollment segments) -> embeddings of true-length windows.
@@ -237,10 +257,10 @@ class Backend(EmbeddingBackend):
         bucket is ONE forward launch sequence; no window contains audio from outside its range.
         Returns (E, Eb, resid) device tensors in window order, windows [(range index, start s, end s)], dropped ranges."""
         import torch
-        pcm_by_len, wins, dropped = cut_ranges(samples, ranges, hop_s=self.hop_s)
+        starts_by, wins, dropped = range_starts(len(samples), ranges, hop_s=self.hop_s)
         if not wins:
             return None, None, None, [], dropped
-        parts = {S: self.embed_windows(pcm) for S, pcm in pcm_by_len.items()}
+        parts = self.embed_tables(samples, starts_by)                      # the recording is uploaded once; one launch sequence per bucket
         order = {S: [] for S in parts}
         for w, (_, S, row, _, _) in enumerate(wins):
             order[S].append((row, w))
@@ -265,12 +285,12 @@ class Backend(EmbeddingBackend):
                 return np.zeros((0, k), np.int32), np.zeros((0, k), np.float32), []
             idx, sc = self.score_windows(E, Eb, re, batch, k)
             return idx, sc, wins
-        pcm_by_len, wins, _ = cut_ranges(samples, ranges, hop_s=self.hop_s)
+        starts_by, wins, _ = range_starts(len(samples), ranges, hop_s=self.hop_s)
         if not wins:
             return np.zeros((0, k), np.int32), np.zeros((0, k), np.float32), []
-        parts = {S: self.embed_windows_host(pcm, batch, k)[1:] for S, pcm in pcm_by_len.items()}      # one bucket = one forward + one top-k
-        idx = np.stack([parts[S][0][row] for _, S, row, _, _ in wins])
-        sc = np.stack([parts[S][1][row] for _, S, row, _, _ in wins])
+        parts = self.embed_tables_host(samples, starts_by, batch, k)                                   # one bucket = one forward + one top-k
+        idx = np.stack([parts[S][1][row] for _, S, row, _, _ in wins])
+        sc = np.stack([parts[S][2][row] for _, S, row, _, _ in wins])
         return idx, sc, [(ri, a, b) for ri, _, _, a, b in wins]
 
     # ---- a2: enroll (base.py:107-128) ---------------------------------------------------------
@@ -278,17 +298,17 @@ class Backend(EmbeddingBackend):
         if segments:           # the caller vouches that each range is this speaker: true-length windows, never widened
             samples = decode_to_profile(Path(audio_path), self.engine(), self.get_audio_profile())
             if self.lite:
-                pcm_by_len, wins, _ = cut_ranges(samples, list(segments), hop_s=self.hop_s)
-                parts = {S: self.embed_windows_host(pcm)[0] for S, pcm in pcm_by_len.items()}
+                starts_by, wins, _ = range_starts(len(samples), list(segments), hop_s=self.hop_s)
+                parts = self.embed_tables_host(samples, starts_by) if wins else {}
                 spans = [(ri, a, b) for ri, _, _, a, b in wins]
-                E = np.stack([parts[S][row] for _, S, row, _, _ in wins]) if wins else None
+                E = np.stack([parts[S][0][row] for _, S, row, _, _ in wins]) if wins else None
             else:
                 E, _, _, spans, _ = self.embed_ranges(samples, list(segments))
             if not spans:
                 raise ValueError(f"{audio_path}: no analysable audio (every segment shorter than 0.5 s)")
         else:
-            pcm, spans = self._windows(audio_path, None)
-            E = self.embed_windows_host(pcm)[0] if self.lite else self.embed_windows(pcm)[0]
+            samples, starts, W, spans = self._windows(audio_path, None)
+            E = self.embed_tables_host(samples, {W: starts})[W][0] if self.lite else self.embed_tables(samples, {W: starts})[W][0]
         if self.lite:
             mean = E.astype(np.float64).mean(axis=0)
             vec = (mean / max(float(np.linalg.norm(mean)), 1e-12)).astype(np.float32)
@@ -346,11 +366,11 @@ class Backend(EmbeddingBackend):
             raise ValueError(batch.all_skipped_message())
         if len(batch) == 0:
             return []
-        pcm, spans = self._windows(audio_path, None)
+        samples, starts, W, spans = self._windows(audio_path, None)
         if self.lite:
-            _, idx, sc = self.embed_windows_host(pcm, batch)
+            _, idx, sc = self.embed_tables_host(samples, {W: starts}, batch)[W]
         else:
-            E, Eb, re = self.embed_windows(pcm)
+            E, Eb, re = self.embed_tables(samples, {W: starts})[W]
             idx, sc = self.score_windows(E, Eb, re, batch)
         return aggregate_matches(idx[:, 0], sc[:, 0], spans, batch, threshold)
 

@@ -63,7 +63,8 @@ struct FbankTables {
 template <bool F16>
 __global__ __launch_bounds__(NW * 64) __attribute__((amdgpu_waves_per_eu(4, 4))) void fbank_tile_kernel(const int16_t* __restrict__ pcm, int S, int T,
                                                             int tiles_per_seg, const FbankTables* __restrict__ tab,
-                                                            float* __restrict__ L, unsigned long long* __restrict__ dbg) {
+                                                            float* __restrict__ L, unsigned long long* __restrict__ dbg,
+                                                            const int32_t* __restrict__ starts, int64_t n_total) {
   __shared__ __attribute__((aligned(16))) char lds[4 * FT * AROW * 2 + TILE_SAMPLES * 4];
   // diagnostics only (tools/fbank_timeline.py): 100 MHz stamps of thread 0 of workgroups 0..255
   int nstamp = 0;
@@ -81,7 +82,11 @@ __global__ __launch_bounds__(NW * 64) __attribute__((amdgpu_waves_per_eu(4, 4)))
   const int b = blockIdx.x / tiles_per_seg;
   const int t0 = (blockIdx.x - b * tiles_per_seg) * FT;
   const int64_t s0 = (int64_t)t0 * HOP - NFFT / 2;     // first sample of the tile (may be < 0)
-  const int16_t* seg = pcm + (int64_t)b * S;
+  // window b of the batch: row b of a [B, S] array, or (sdk_fbank_windows) the S samples from starts[b] of ONE resident recording of n_total
+  // samples - what lies past the recording's end reads as zero, exactly the zero padding a host-side cut would have written
+  const int64_t w0 = starts ? (int64_t)starts[b] : (int64_t)b * S;
+  const int16_t* seg = pcm + w0;
+  const int Sv = starts ? (int)(n_total - w0 < S ? (n_total - w0 < 0 ? 0 : n_total - w0) : S) : S;     // samples of the window that exist
 
   {
     // every request of the thread first, then the conversions: rolled, this loop was load - wait - store twelve times over,
@@ -91,13 +96,13 @@ __global__ __launch_bounds__(NW * 64) __attribute__((amdgpu_waves_per_eu(4, 4)))
 #pragma unroll
     for (int i = 0; i < NLD; ++i) {
       const int64_t g = s0 + tid + i * (NW * 64);
-      raw[i] = seg[g < 0 ? 0 : (g < S ? g : S - 1)];          // clamped address, value masked below
+      raw[i] = seg[g < 0 ? 0 : (g < Sv ? g : (Sv > 0 ? Sv - 1 : 0))];          // clamped address, value masked below
     }
 #pragma unroll
     for (int i = 0; i < NLD; ++i) {
       const int q = tid + i * (NW * 64);
       const int64_t g = s0 + q;
-      if (q < TILE_SAMPLES) xs[q] = (g >= 0 && g < S) ? (float)raw[i] * (1.0f / 32768.0f) : 0.f;
+      if (q < TILE_SAMPLES) xs[q] = (g >= 0 && g < Sv) ? (float)raw[i] * (1.0f / 32768.0f) : 0.f;
     }
   }
   __syncthreads();
@@ -422,22 +427,22 @@ extern "C" size_t sdk_fbank_workspace_bytes(int B, int S) {
   return (size_t)B * (size_t)(1 + S / HOP) * NMEL * sizeof(float);
 }
 
-extern "C" int sdk_fbank(sdk_ctx* ctx, const int16_t* pcm, int B, int S, const void* tabs, uint16_t* feats, int ldf,
-                         void* ws, size_t ws_bytes, void* stream) {
-  SDK_REQUIRE(ctx && pcm && tabs && feats && ws, "sdk_fbank: null argument");
-  SDK_REQUIRE(B > 0 && S > 0, "sdk_fbank: empty batch (B=%d S=%d)", B, S);
+static int fbank_launch(sdk_ctx* ctx, const int16_t* pcm, const int32_t* starts, int64_t n_total, int B, int S, const void* tabs, uint16_t* feats,
+                        int ldf, void* ws, size_t ws_bytes, void* stream, const char* who) {
+  SDK_REQUIRE(ctx && pcm && tabs && feats && ws, "%s: null argument", who);
+  SDK_REQUIRE(B > 0 && S > 0, "%s: empty batch (B=%d S=%d)", who, B, S);
   const bool hp = ctx->precision == 1;
-  if (hp) SDK_REQUIRE((ldf >> 1) >= NMEL && ldf % 16 == 0, "sdk_fbank: precise mode writes planes: ldf=%d must be >= 160 and a multiple of 16", ldf);
-  SDK_REQUIRE(ldf >= NMEL && ldf % 8 == 0, "sdk_fbank: ldf=%d must be >= 80 and a multiple of 8", ldf);
-  SDK_REQUIRE(ws_bytes >= sdk_fbank_workspace_bytes(B, S), "sdk_fbank: workspace too small");
-  SDK_REQUIRE(((uintptr_t)feats % 16) == 0 && ((uintptr_t)tabs % 16) == 0, "sdk_fbank: feats/tabs must be 16-byte aligned");
+  if (hp) SDK_REQUIRE((ldf >> 1) >= NMEL && ldf % 16 == 0, "%s: precise mode writes planes: ldf=%d must be >= 160 and a multiple of 16", who, ldf);
+  SDK_REQUIRE(ldf >= NMEL && ldf % 8 == 0, "%s: ldf=%d must be >= 80 and a multiple of 8", who, ldf);
+  SDK_REQUIRE(ws_bytes >= sdk_fbank_workspace_bytes(B, S), "%s: workspace too small", who);
+  SDK_REQUIRE(((uintptr_t)feats % 16) == 0 && ((uintptr_t)tabs % 16) == 0, "%s: feats/tabs must be 16-byte aligned", who);
   const int T = 1 + S / HOP;
   const int tps = ceil_div(T, FT);
-  SDK_REQUIRE((int64_t)B * tps < (1ll << 31), "sdk_fbank: batch too large for one launch");
+  SDK_REQUIRE((int64_t)B * tps < (1ll << 31), "%s: batch too large for one launch", who);
   {
   ProfScope ps(ctx, stream, SDK_K_FBANK_TILE, 3 * 2.0 * B * T * (double)NSYM * 2 * (NW * 32) + 2.0 * B * T * NBIN * NMEL, 2.0 * B * S + 4.0 * B * T * NMEL);
   hipLaunchKernelGGL(hp ? fbank_tile_kernel<true> : fbank_tile_kernel<false>, dim3(B * tps), dim3(NW * 64), 0, (hipStream_t)stream, pcm, S, T, tps,
-                     (const FbankTables*)tabs, (float*)ws, (unsigned long long*)ctx->dbg_ptr);
+                     (const FbankTables*)tabs, (float*)ws, (unsigned long long*)ctx->dbg_ptr, starts, n_total);
   }
   SDK_LAUNCH_CHECK();
   ProfScope ps2(ctx, stream, SDK_K_FBANK_NORM, 3.0 * B * T * NMEL, 4.0 * B * T * NMEL + 2.0 * B * T * ldf);
@@ -450,4 +455,19 @@ extern "C" int sdk_fbank(sdk_ctx* ctx, const int16_t* pcm, int B, int S, const v
   }
   SDK_LAUNCH_CHECK();
   return 0;
+}
+
+extern "C" int sdk_fbank(sdk_ctx* ctx, const int16_t* pcm, int B, int S, const void* tabs, uint16_t* feats, int ldf,
+                         void* ws, size_t ws_bytes, void* stream) {
+  return fbank_launch(ctx, pcm, nullptr, 0, B, S, tabs, feats, ldf, ws, ws_bytes, stream, "sdk_fbank");
+}
+
+// Windows cut ON THE DEVICE: the recording is resident once ([n_samples] s16) and window b is the S samples from starts[b] (device int32 table).
+// The host never materialises the overlapping [B, S] windows (2x the samples at hop 1 s / window 2 s) and they never cross PCIe.  The START of
+// every window must lie inside the recording (checked by the caller: starts is device memory); samples past its end read as zero.
+extern "C" int sdk_fbank_windows(sdk_ctx* ctx, const int16_t* samples, int64_t n_samples, const int32_t* starts, int B, int S, const void* tabs,
+                                 uint16_t* feats, int ldf, void* ws, size_t ws_bytes, void* stream) {
+  SDK_REQUIRE(starts, "sdk_fbank_windows: null start table");
+  SDK_REQUIRE(n_samples > 0 && n_samples < (1ll << 31), "sdk_fbank_windows: n_samples=%lld must be in [1, 2^31)", (long long)n_samples);
+  return fbank_launch(ctx, samples, starts, n_samples, B, S, tabs, feats, ldf, ws, ws_bytes, stream, "sdk_fbank_windows");
 }

@@ -86,6 +86,7 @@ class LiteEngine:
         self._desc: Optional[EcapaDesc] = None
         self._xv = None                     # (DevBuf blob, XVectorDesc) when the x-vector family is loaded
         self._taps: Dict[Tuple[int, int], DevBuf] = {}
+        self._ingest = None
         self.cache_hit = False
 
     # ---------------------------------------------------------------- resident state
@@ -147,6 +148,49 @@ class LiteEngine:
         ws = self._buf("fbank_ws", self.lib.sdk_fbank_workspace_bytes(B, S))
         check(self.lib.sdk_fbank(self.ctx, pcm_dev.ptr, B, S, self._tables().ptr, feats.ptr, N_MELS_PADDED, ws.ptr, ws.nbytes, None), "sdk_fbank")
         return feats
+
+    def fbank_windows(self, samples_ptr: int, n_samples: int, starts_ptr: int, B: int, S: int) -> DevBuf:
+        """fbank with the windows cut on the device from a resident recording (sdk_fbank_windows; pointers from the ingest slots)."""
+        check(self.lib.sdk_set_option(self.ctx, b"precision", 0), "sdk_set_option")
+        T = num_frames(S)
+        feats = self._buf("feats", B * T * N_MELS_PADDED * 2)
+        ws = self._buf("fbank_ws", self.lib.sdk_fbank_workspace_bytes(B, S))
+        check(self.lib.sdk_fbank_windows(self.ctx, samples_ptr, n_samples, starts_ptr, B, S, self._tables().ptr, feats.ptr, N_MELS_PADDED, ws.ptr, ws.nbytes, None),
+              "sdk_fbank_windows")
+        return feats
+
+    def ingest(self):
+        if self._ingest is None:
+            from .ingest import Ingest
+            self._ingest = Ingest(self.lib, self.ctx, depth=2)
+        return self._ingest
+
+    def embed_from_host(self, samples: np.ndarray, tables: Dict[int, np.ndarray], step: int = 2048, profiles=None, k: int = 1, score_kw=None):
+        """One recording (int16 [n], host) + window-start tables {S: int32 [B_S]} -> {S: (E [B_S, d] fp32 host, idx or None, score or None)}.
+        The recording is uploaded ONCE (pinned staging slot); the windows are cut on the device, batch by batch; with `profiles` every batch is
+        scored while its embeddings are resident (score_last).  Same results as embed_pcm on host-cut windows, bit for bit."""
+        order = sorted(tables)
+        flat = np.concatenate([np.ascontiguousarray(tables[S], dtype=np.int32) for S in order]) if order else np.zeros((0,), np.int32)
+        ing = self.ingest()
+        ticket, ds, dw = ing.submit(samples, flat, max(order) if order else 0, None)
+        out, off = {}, 0
+        try:
+            for S in order:
+                Bs = len(tables[S])
+                Es, idxs, scs = [], [], []
+                for a in range(0, Bs, step):
+                    b = min(step, Bs - a)
+                    emb = self.forward(self.fbank_windows(ds, len(samples), dw + 4 * (off + a), b, S), b, num_frames(S))
+                    self._last = (self.l2norm(emb, b, self.cfg.embed_dim, "seg"), b)
+                    Es.append(self._last[0][0].download(np.float32, (b, self.cfg.embed_dim)))
+                    if profiles is not None:
+                        i, s_ = self.score_last(profiles, k, **(score_kw or {}))
+                        idxs.append(i); scs.append(s_)
+                out[S] = (np.concatenate(Es), np.concatenate(idxs) if idxs else None, np.concatenate(scs) if scs else None)
+                off += Bs
+        finally:
+            ing.release(ticket, None)
+        return out
 
     def forward(self, feats: DevBuf, B: int, T: int) -> DevBuf:
         emb = self._buf("emb", B * self.cfg.embed_dim * 4)

@@ -75,6 +75,7 @@ class Engine:
         self._graphs: Dict[tuple, tuple] = {}
         self._streams = []
         self._taps: Dict[tuple, torch.Tensor] = {}
+        self._ingest = None
 
     # ------------------------------------------------------------------ resident state
     def _scratch_bytes(self, key: str, nbytes: int) -> torch.Tensor:
@@ -285,6 +286,54 @@ class Engine:
         check(self.lib.sdk_fbank(self.ctx, pcm.data_ptr(), B, S, self.fbank_tables().data_ptr(), feats.data_ptr(), ldf,
                                  ws.data_ptr(), ws.numel(), _stream()), "sdk_fbank")
         return feats
+
+    def fbank_windows(self, samples_ptr: int, n_samples: int, starts_ptr: int, B: int, S: int, ldf: Optional[int] = None) -> torch.Tensor:
+        """fbank with the windows cut on the device (sdk_fbank_windows): samples_ptr -> int16 [n_samples] resident recording, starts_ptr -> int32 [B]
+        first samples; same features as fbank() on the materialised [B, S] windows, bit for bit."""
+        self._sync_precision()
+        T = num_frames(S)
+        if ldf is None:
+            ldf = 2 * N_MELS_PADDED_HP if self.precision == 1 else N_MELS_PADDED
+        feats = torch.empty((B * T, ldf), dtype=torch.float16 if self.precision == 1 else torch.bfloat16, device=self.device)
+        ws = self._scratch_bytes("fbank", self.lib.sdk_fbank_workspace_bytes(B, S))
+        check(self.lib.sdk_fbank_windows(self.ctx, samples_ptr, n_samples, starts_ptr, B, S, self.fbank_tables().data_ptr(), feats.data_ptr(), ldf,
+                                         ws.data_ptr(), ws.numel(), _stream()), "sdk_fbank_windows")
+        return feats
+
+    def ingest(self):
+        """The staging runtime (ingest.py / csrc/ingest.hip): pinned, double-buffered, on a copy stream of its own."""
+        if self._ingest is None:
+            from .ingest import Ingest
+            self._ingest = Ingest(self.lib, self.ctx, depth=2)
+        return self._ingest
+
+    def embed_from_host(self, samples: np.ndarray, tables: Dict[int, np.ndarray], step: int = 2048, forward=None):
+        """One recording in HOST memory (int16 [n]) + window-start tables {window samples S: int32 [B_S]} -> {S: (E, Eb, resid)} device tensors.
+        The recording is uploaded once through the pinned staging slots (the next call's upload overlaps this call's forward); the overlapping
+        windows are never materialised.  Windows go through in batches of `step`; forward(feats, B, T) defaults to the ECAPA-TDNN forward
+        (Backend passes the x-vector's).  Bit-identical to embed_pcm on the host-cut windows."""
+        forward = forward or self.ecapa_forward
+        order = sorted(tables)
+        flat = np.concatenate([np.ascontiguousarray(tables[S], dtype=np.int32) for S in order]) if order else np.zeros((0,), np.int32)
+        self.desc if forward == self.ecapa_forward else None          # lazy weight load (its uploads run on the current stream) before the fan-out
+        st = _stream()
+        ing = self.ingest()
+        ticket, ds, dw = ing.submit(samples, flat, max(order) if order else 0, st)
+        out, off = {}, 0
+        try:
+            for S in order:
+                Bs = len(tables[S])
+                parts = []
+                for a in range(0, Bs, step):
+                    b = min(step, Bs - a)
+                    feats = self.fbank_windows(ds, len(samples), dw + 4 * (off + a), b, S)
+                    parts.append(self.l2norm(forward(feats, b, num_frames(S))))
+                out[S] = parts[0] if len(parts) == 1 else tuple(torch.cat([p[i] for p in parts], dim=0) for i in range(3))
+                off += Bs
+        finally:
+            ing.release(ticket, st)
+        self.last_ingest_ticket = ticket
+        return out
 
     # ------------------------------------------------------------------ k2
     def ecapa_forward(self, feats: torch.Tensor, B: int, T: int) -> torch.Tensor:

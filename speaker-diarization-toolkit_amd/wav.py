@@ -125,13 +125,10 @@ def write_wav_s16(path: Path, samples: np.ndarray, rate: int = 16000) -> None:
     Path(path).write_bytes(hdr + b"data" + struct.pack("<I", len(pcm)) + pcm)
 
 
-def cut_windows(samples: np.ndarray, segments: Optional[List[Tuple[float, float]]], rate: int = 16000,
-                window_s: float = 2.0, hop_s: float = 1.0, min_s: float = 0.5) -> Tuple[np.ndarray, List[Tuple[float, float]]]:
-    """Slice (start, end) second ranges into fixed `window_s` windows (the unit the forward pass
-    batches: 2 s = 32 000 samples = 201 frames).  Ranges shorter than the window are extended
-    symmetrically (clamped to the file, then zero padded); longer ones are covered with hop `hop_s`.
-    Returns (pcm [B, window] int16, [(start, end)] actually covered)."""
-    n = len(samples)
+def window_starts(n: int, segments: Optional[List[Tuple[float, float]]], rate: int = 16000,
+                  window_s: float = 2.0, hop_s: float = 1.0, min_s: float = 0.5) -> Tuple[np.ndarray, List[Tuple[float, float]], int]:
+    """The windows of cut_windows as a TABLE of first samples (int32 [B]) + the spans covered + the window length W: what crosses PCIe next
+    to the recording itself when the windows are cut on the device (sdk_fbank_windows); a window that runs past sample n is zero padded there."""
     W = int(round(window_s * rate))
     if segments is None:
         segments = [(0.0, n / rate)]
@@ -151,31 +148,35 @@ def cut_windows(samples: np.ndarray, segments: Optional[List[Tuple[float, float]
                 pos += H
             if pos - H + W < b:                      # this range's last window stops short of its end: add one flush with it
                 starts.append(b - W)
+    spans = [(a / rate, min(n, a + W) / rate) for a in starts]
+    return np.asarray(starts, dtype=np.int32), spans, W
+
+
+def materialise_windows(samples: np.ndarray, starts: np.ndarray, W: int) -> np.ndarray:
+    """[B, W] int16 host copy of the windows of a start table, zero padded past the end of `samples` (tests, and hosts that keep the old form)."""
     out = np.zeros((len(starts), W), dtype=np.int16)
-    spans = []
-    for i, a in enumerate(starts):
+    for i, a in enumerate(starts.tolist()):
         chunk = samples[a:a + W]
         out[i, :len(chunk)] = chunk
-        spans.append((a / rate, min(n, a + W) / rate))
-    return out, spans
+    return out
+
+
+def cut_windows(samples: np.ndarray, segments: Optional[List[Tuple[float, float]]], rate: int = 16000,
+                window_s: float = 2.0, hop_s: float = 1.0, min_s: float = 0.5) -> Tuple[np.ndarray, List[Tuple[float, float]]]:
+    """Slice (start, end) second ranges into fixed `window_s` windows (the unit the forward pass
+    batches: 2 s = 32 000 samples = 201 frames).  Ranges shorter than the window are extended
+    symmetrically (clamped to the file, then zero padded); longer ones are covered with hop `hop_s`.
+    Returns (pcm [B, window] int16, [(start, end)] actually covered)."""
+    starts, spans, W = window_starts(len(samples), segments, rate, window_s, hop_s, min_s)
+    return materialise_windows(samples, starts, W), spans
 
 
 BUCKETS_S = (0.5, 1.0, 1.5, 2.0)      # window lengths the forward is launched with: 51 / 101 / 151 / 201 frames
 
 
-def cut_ranges(samples: np.ndarray, ranges: List[Tuple[float, float]], rate: int = 16000, buckets_s: Tuple[float, ...] = BUCKETS_S,
-               hop_s: float = 1.0):
-    """True-length windows for (start, end) ranges that belong to ONE speaker each (sentences, enrollment segments).
-
-    A window never leaves its range - nothing is widened into the neighbouring speech and nothing is zero padded:
-      * a range at least as long as the largest bucket is covered by largest-bucket windows at `hop_s`, the last one flush
-        with the range's end (the whole-recording rule, applied inside the range);
-      * a shorter range takes the largest bucket that fits and is covered by one or two such windows (first flush with
-        its start, second flush with its end);
-      * a range shorter than the smallest bucket is dropped (returned in `dropped`).
-    Returns (pcm_by_len {window samples: int16 [B, S]}, windows [(range index, S, row in pcm_by_len[S], start s, end s)],
-    dropped [range index]).  The forward takes a uniform length per launch, so the caller runs one launch per bucket."""
-    n = len(samples)
+def range_starts(n: int, ranges: List[Tuple[float, float]], rate: int = 16000, buckets_s: Tuple[float, ...] = BUCKETS_S, hop_s: float = 1.0):
+    """cut_ranges as start tables: (starts_by_len {window samples S: int32 [B_S]}, windows [(range index, S, row in the S table, start s, end s)],
+    dropped [range index]).  Every window lies inside the recording (nothing is padded)."""
     sizes = sorted(int(round(b * rate)) for b in buckets_s)
     hop = int(round(hop_s * rate))
     starts_by = {S: [] for S in sizes}
@@ -196,5 +197,21 @@ def cut_ranges(samples: np.ndarray, ranges: List[Tuple[float, float]], rate: int
         for x in st:
             windows.append((ri, S, len(starts_by[S]), x / rate, (x + S) / rate))
             starts_by[S].append(x)
-    pcm_by_len = {S: np.stack([samples[x:x + S] for x in st]).astype(np.int16) for S, st in starts_by.items() if st}
+    return {S: np.asarray(st, dtype=np.int32) for S, st in starts_by.items() if st}, windows, dropped
+
+
+def cut_ranges(samples: np.ndarray, ranges: List[Tuple[float, float]], rate: int = 16000, buckets_s: Tuple[float, ...] = BUCKETS_S,
+               hop_s: float = 1.0):
+    """True-length windows for (start, end) ranges that belong to ONE speaker each (sentences, enrollment segments).
+
+    A window never leaves its range - nothing is widened into the neighbouring speech and nothing is zero padded:
+      * a range at least as long as the largest bucket is covered by largest-bucket windows at `hop_s`, the last one flush
+        with the range's end (the whole-recording rule, applied inside the range);
+      * a shorter range takes the largest bucket that fits and is covered by one or two such windows (first flush with
+        its start, second flush with its end);
+      * a range shorter than the smallest bucket is dropped (returned in `dropped`).
+    Returns (pcm_by_len {window samples: int16 [B, S]}, windows [(range index, S, row in pcm_by_len[S], start s, end s)],
+    dropped [range index]).  The forward takes a uniform length per launch, so the caller runs one launch per bucket."""
+    starts_by, windows, dropped = range_starts(len(samples), ranges, rate, buckets_s, hop_s)
+    pcm_by_len = {S: np.stack([samples[x:x + S] for x in st.tolist()]).astype(np.int16) for S, st in starts_by.items()}
     return pcm_by_len, windows, dropped

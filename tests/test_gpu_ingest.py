@@ -1,0 +1,129 @@
+"""Ingest from host audio: a recording crosses PCIe once, as it lies in the file, next to an int32 table of window starts;
+the windows are cut on the device (sdk_fbank_windows) and the upload is staged through pinned slots on a copy stream (csrc/ingest.hip).
+Every result must equal the host-windowed path bit for bit.  Boundary being served: speaker_detection_backends/base.py:130-151 (a path and
+segments); the reference cuts with ffmpeg per segment list (speechmatics_backend.py:231-281)."""
+import numpy as np
+import pytest
+import torch
+
+from conftest import sub
+
+pytestmark = pytest.mark.gpu
+
+wav = sub("wav")
+SdkError = sub("_lib").SdkError
+
+
+def _recording(seconds, seed):
+    rng = np.random.default_rng(seed)
+    t = np.arange(int(16000 * seconds)) / 16000.0
+    x = 0.2 * np.sin(2 * np.pi * (110 + 7 * seed) * t) + 0.1 * np.sin(2 * np.pi * (900 + 31 * seed) * t) + rng.normal(0, 0.08, t.shape)
+    return np.clip(np.round(x * 32768), -32768, 32767).astype(np.int16)
+
+
+@pytest.mark.parametrize("precision", [0, 1])
+def test_fbank_windows_equals_fbank_on_materialised_windows(engine, precision):
+    rec = _recording(7.3, 1)
+    n = len(rec)
+    # overlapping windows, one flush with the end, two running PAST the end (zero padded), one of a single valid sample
+    starts = np.array([0, 16000, 32000, 5, 12345, n - 32000, n - 20000, n - 3000, n - 1], dtype=np.int32)
+    for S in (32000, 8000):
+        pcm = wav.materialise_windows(rec, starts, S)
+        assert pcm[-1, 1:].max() == 0 and pcm[-1, 0] == rec[-1]
+        engine.set_precision(precision)
+        try:
+            want = engine.fbank(torch.from_numpy(pcm).cuda())
+            ing = engine.ingest()
+            t, ds, dw = ing.submit(rec, starts, S, torch.cuda.current_stream().cuda_stream)
+            got = engine.fbank_windows(ds, n, dw, len(starts), S)
+            sub_ = engine.fbank_windows(ds, n, dw + 4 * 3, 4, S)                  # any sub-range of the table
+            ing.release(t, torch.cuda.current_stream().cuda_stream)
+            torch.cuda.synchronize()
+        finally:
+            engine.set_precision(0)
+        T = 1 + S // 160
+        assert torch.equal(got.view(torch.int16), want.view(torch.int16))
+        assert torch.equal(sub_.view(torch.int16), want.view(torch.int16)[3 * T:7 * T])
+
+
+def test_embed_from_host_equals_the_host_windowed_path_and_pipelines(engine):
+    """Several recordings back to back through the two staging slots (the upload of recording i + 1 is issued while recording i computes), two
+    window lengths each, batches of 5 windows: embeddings bit-identical to embed_pcm on host-cut windows; slots reused three times over."""
+    recs = [_recording(5.0 + 1.7 * i, 10 + i) for i in range(6)]
+    outs, wants = [], []
+    for rec in recs:                                       # enqueue everything first: no synchronisation between recordings
+        s2, _, W = wav.window_starts(len(rec), None)
+        s1 = np.arange(0, len(rec) - 16000, 9000, dtype=np.int32)
+        outs.append((engine.embed_from_host(rec, {W: s2, 16000: s1}, step=5), s2, s1, W))
+    for rec, (_, s2, s1, W) in zip(recs, outs):
+        wants.append({W: engine.embed_pcm(torch.from_numpy(wav.materialise_windows(rec, s2, W)).cuda()),
+                      16000: engine.embed_pcm(torch.from_numpy(wav.materialise_windows(rec, s1, 16000)).cuda())})
+    torch.cuda.synchronize()
+    for (got, s2, s1, W), want in zip(outs, wants):
+        for S in (W, 16000):
+            # batches of 5 start on other tile rows than one batch of all windows: per-segment fp32 statistics are summed in another grouping
+            # (test_embed_windows_in_bounded_batches); the first batch is bit-identical, the rest within the batch-invariance tolerance
+            assert torch.equal(got[S][0][:5], want[S][0][:5]) and torch.equal(got[S][2][:5], want[S][2][:5])
+            assert float((got[S][0] - want[S][0]).abs().max()) < 1e-3
+    # with one batch per bucket everything is bit-identical
+    rec = recs[3]
+    s2, _, W = wav.window_starts(len(rec), None)
+    got = engine.embed_from_host(rec, {W: s2})[W]
+    want = engine.embed_pcm(torch.from_numpy(wav.materialise_windows(rec, s2, W)).cuda())
+    torch.cuda.synchronize()
+    assert all(torch.equal(a.view(torch.int16) if a.dtype == torch.bfloat16 else a, b.view(torch.int16) if b.dtype == torch.bfloat16 else b)
+               for a, b in zip(got, want))
+    ms, nbytes = engine.ingest().copy_ms(engine.last_ingest_ticket)
+    assert nbytes == len(rec) * 2 + len(s2) * 4 and ms > 0
+
+
+def test_ingest_refuses_bad_tables_and_unreleased_slots(engine):
+    ing = sub("ingest").Ingest(engine.lib, engine.ctx, max_samples=1 << 16, max_windows=64, depth=2)
+    rec = _recording(2.0, 3)
+    st = torch.cuda.current_stream().cuda_stream
+    with pytest.raises(SdkError, match="outside the recording"):
+        ing.submit(rec, np.array([0, len(rec)], np.int32), 8000, st)
+    with pytest.raises(SdkError, match="outside the recording"):
+        ing.submit(rec, np.array([-1], np.int32), 8000, st)
+    t0, _, _ = ing.submit(rec, np.array([0], np.int32), 8000, st)      # a refused table leaves its slot free
+    t1, _, _ = ing.submit(rec, np.array([5], np.int32), 8000, st)
+    with pytest.raises(SdkError, match="never released"):
+        ing.submit(rec, np.array([9], np.int32), 8000, st)
+    ing.release(t0, st)
+    with pytest.raises(SdkError, match="not a committed slot"):
+        ing.release(t0, st)
+    t2, _, _ = ing.submit(rec, np.array([9], np.int32), 8000, st)
+    assert t2 == t0
+    ing.release(t1, st); ing.release(t2, st)
+    # the zero-copy form: fill the pinned views, then commit
+    t, ps, pw = ing.pinned(len(rec), 2)
+    ps[:] = rec; pw[:] = (0, 100)
+    ds, dw = ing.commit(t, len(rec), 2, 8000, st)
+    back = torch.empty(len(rec), dtype=torch.int16, device="cuda")
+    engine.lib.sdk_memcpy(engine.ctx, back.data_ptr(), ds, len(rec) * 2, 3, st)
+    ing.release(t, st)
+    assert np.array_equal(back.cpu().numpy(), rec)
+    ing.close()
+
+
+def test_backend_ingest_path_equals_host_cut_windows(tmp_path, monkeypatch):
+    """Through the plug-in class: what identify / enroll now run (recording uploaded once, windows cut on the device) against the previous form
+    (windows materialised on the host, uploaded as [B, 32000])."""
+    monkeypatch.setenv("SPEAKERS_EMBEDDINGS_DIR", str(tmp_path / "store"))
+    be = sub("backend").Backend()
+    rec = _recording(9.4, 21)
+    samples, starts, W, spans = None, None, None, None
+    path = tmp_path / "r.wav"
+    wav.write_wav_s16(path, rec)
+    samples, starts, W, spans = be._windows(path, None)
+    pcm, spans2 = wav.cut_windows(rec, None)
+    assert spans == spans2 and np.array_equal(samples, rec) and len(starts) == len(pcm) == 9
+    a = be.embed_tables(samples, {W: starts})[W]
+    b = be.embed_windows(pcm)
+    torch.cuda.synchronize()
+    assert torch.equal(a[0], b[0]) and torch.equal(a[1].view(torch.int16), b[1].view(torch.int16)) and torch.equal(a[2], b[2])
+    ra = be.embed_ranges(rec, [(0.2, 3.1), (3.3, 4.0), (4.2, 9.0)])
+    pcm_by_len, wins, _ = wav.cut_ranges(rec, [(0.2, 3.1), (3.3, 4.0), (4.2, 9.0)])
+    for w, (_, S, row, _, _) in enumerate(wins):
+        want = be.embed_windows(pcm_by_len[S])[0][row]
+        assert torch.equal(ra[0][w], want)

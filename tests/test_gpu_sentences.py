@@ -58,11 +58,15 @@ def test_fixture_sentences_one_pass_per_recording(tmp_path, monkeypatch, bias_co
         (db / f"{sid}.json").write_text(json.dumps(prof))
         profiles.append(prof)
 
-    calls = []
-    real = be.engine().embed_pcm
-    monkeypatch.setattr(be.engine(), "embed_pcm", lambda pcm: (calls.append(tuple(pcm.shape)), real(pcm))[1])
+    calls, uploads = [], []
+    real = be.engine().fbank_windows
+    monkeypatch.setattr(be.engine(), "fbank_windows", lambda ds, n, dw, B, S, **kw: (calls.append((B, S)), real(ds, n, dw, B, S, **kw))[1])
+    ing = be.engine().ingest()
+    real_submit = ing.submit
+    monkeypatch.setattr(ing, "submit", lambda smp, st, W, stream: (uploads.append((len(smp), len(st))), real_submit(smp, st, W, stream))[1])
     rows_fn = ident.make_rows_fn(tpath, per_label=True, backend=be, transcript=data)
     assert sorted(calls) == [(4, 24000), (6, 8000), (7, 16000)]            # the whole recording: one launch sequence per bucket
+    assert uploads == [(len(rec), 17)]                                      # ... and ONE upload: the recording as it is + 17 window starts
     out = asg.assign_recording(tpath, FIXTURE, rows_fn=rows_fn, use_embeddings=True, threshold=0.1)
     assert len(calls) == 3                                                   # labels are served from that one pass
     assert out["mappings"]["Alice"]["speaker_id"] == "alice" and out["mappings"]["Bob"]["speaker_id"] == "bob", out["mappings"]

@@ -442,3 +442,24 @@ def test_profile_pack_four_concurrent_builders(tmp_path):
     assert all(r[1] and r[2] and r[3] == 300 for r in res), res
     packs = list((tmp_path / "embeddings" / "packs").glob("pack-*"))
     assert sorted(q_.suffix for q_ in packs) == [".json", ".npy"], packs                      # one pack, no temporary files left behind
+
+
+def test_window_start_tables_reproduce_the_host_cut_windows():
+    """The ingest path ships a recording + int32 start tables instead of materialised windows: the tables must describe exactly the windows
+    cut_windows / cut_ranges produce (zero padding past the end included)."""
+    rng = np.random.default_rng(5)
+    x = rng.integers(-3000, 3000, 16000 * 9 + 777).astype(np.int16)
+    for segs in (None, [(1.0, 1.2), (3.0, 4.0), (5.0, 9.5)], [(0.0, 0.7)]):
+        st, spans, W = wav.window_starts(len(x), segs)
+        pcm, spans2 = wav.cut_windows(x, segs)
+        assert st.dtype == np.int32 and spans == spans2 and np.array_equal(wav.materialise_windows(x, st, W), pcm)
+        assert ((st >= 0) & (st < len(x))).all()
+    short = x[:20000]                                            # shorter than a window: one zero-padded window starting at 0
+    st, spans, W = wav.window_starts(len(short), None)
+    assert st.tolist() == [0] and wav.materialise_windows(short, st, W)[0, 20000:].max() == 0
+    ranges = [(0.2, 3.1), (3.3, 4.0), (4.2, 9.0), (9.1, 9.3)]
+    tabs, wins, dropped = wav.range_starts(len(x), ranges)
+    pcm_by_len, wins2, dropped2 = wav.cut_ranges(x, ranges)
+    assert wins == wins2 and dropped == dropped2 == [3] and set(tabs) == set(pcm_by_len)
+    for S, st in tabs.items():
+        assert np.array_equal(wav.materialise_windows(x, st, S), pcm_by_len[S]) and (st + S <= len(x)).all()
