@@ -42,6 +42,7 @@ struct Geom {            // host-computed, identical on both sides
   int ngroups, nst, G, segs;   // segment groups, stages per group, workgroups, segments per group
   long long U;                 // units = ngroups * nst
   int pen;                     // cost of starting a portion in a NEW group, in stages (fragment reload + a first stage that waits for it)
+  int prio;                    // A/B: 1 = waves 4-7 at static priority 2, 2 = waves 0-3 (`affinity_variant` 5 / 6); not part of the work split
 };
 
 // Work ranges balanced by COST, not by units (round 3; timeline profiles/r03_aff_timeline_config3.txt: with equal unit counts a workgroup whose
@@ -220,6 +221,11 @@ __global__ __launch_bounds__(WAVES * 64, 2) void aff_rowcol_kernel(const bf16_t*
   };
 
   if (u0 >= u1) return;
+  // A/B knob `affinity_variant` 5: static priority for waves 4-7 (the younger wave of every SIMD).  The two waves of a SIMD run this loop in
+  // lockstep - both in their MFMA phase, then both in their reduction phase, during which the matrix pipe idles (65 % busy inside the stage
+  // loop, tools/aff_timeline.py).  With one of them always winning arbitration its vector phases fall under the other's MFMAs.
+  if (gm.prio == 1) { if (wid >= WAVES / 2) __builtin_amdgcn_s_setprio(2); }
+  else if (gm.prio == 2) { if (wid < WAVES / 2) __builtin_amdgcn_s_setprio(2); }
   constexpr int AHEAD = NSTAGE - 1;                // stages in flight
 #pragma unroll
   for (int a = 0; a < AHEAD; ++a)
@@ -741,6 +747,7 @@ Geom plan_geometry(int N, int P, int segs, int tps, long long max_wg, int whole_
   // the boundary penalty needs every virtual range to hold at least one real unit (no empty workgroup inside a group's slot sequence):
   // floor(V / G) >= pen + 1; with G <= 2 groups that is nst >= pen + 2 - otherwise (very short sweeps) the plain split
   gm.pen = 0;
+  gm.prio = 0;
   if (pen > 0 && gm.nst >= pen + 2 && ((long long)gm.ngroups * (gm.nst + pen)) / G >= pen + 1) gm.pen = pen;
   return gm;
 }
@@ -751,7 +758,8 @@ int launch_coarse(sdk_ctx* ctx, const bf16_t* Eb, const bf16_t* Pb, int N, int P
   constexpr int SEGS = WAVES * SEGB * 32;
   constexpr int LDS = NSTAGE * TPS * TILE_BYTES;
   *segs = SEGS;
-  const Geom gm = plan_geometry(N, P, SEGS, TPS, (long long)ctx->num_cu * wg_per_cu, ctx->aff_whole_groups, ctx->aff_boundary_pen);
+  Geom gm = plan_geometry(N, P, SEGS, TPS, (long long)ctx->num_cu * wg_per_cu, ctx->aff_whole_groups, ctx->aff_boundary_pen);
+  gm.prio = ctx->aff_variant == 5 ? 1 : ctx->aff_variant == 6 ? 2 : 0;
   auto kern = aff_rowcol_kernel<WAVES, SEGB, TPS, NSTAGE, PIPE>;
   if (sdk_lds_optin(ctx, (const void*)kern, LDS)) return 1;
   hipLaunchKernelGGL(kern, dim3(gm.G), dim3(WAVES * 64), LDS, s, Eb, Pb, N, P, gm, w.stats, w.part_base, w.part_cnt, w.flag_count,

@@ -422,6 +422,8 @@ __global__ __launch_bounds__(NT2, 2) void conv_gemm256_kernel(Params p) {
   const uint32_t a_base = (wm * 128 + fr) * 128;
   const uint32_t b_base = BM2 * BK * 2 + (wn * 64 + fr) * 128;
   const uint32_t c0 = ((0 * 4 + fq) ^ sw) << 4, c1 = ((1 * 4 + fq) ^ sw) << 4;
+  const int prio_mode = (p.tune >> 11) & 3;
+  if (prio_mode == 2 && wu >= 4) __builtin_amdgcn_s_setprio(1);
   const int pol = p.tune & 3;   // 0: waves 0-3 early / 4-7 late (default), 1: all early, 2: all late, 3: odd/even
   const bool dma_early = pol == 1 ? true : pol == 2 ? false : pol == 3 ? (wu & 1) == 0 : wu < 4;
   const bool relu = p.flags & SDK_GEMM_RELU;
@@ -464,14 +466,18 @@ __global__ __launch_bounds__(NT2, 2) void conv_gemm256_kernel(Params p) {
     // the halves, so they complete under the second half instead of being waited for right after issue.
     // The WEIGHT fragment is the MFMA's row operand: a lane then holds 4 CONSECUTIVE output columns
     // (fq*4 + r) of one output row (fr), which the epilogue packs into one 8-byte LDS write.
+    // Priority experiments (A/B knobs, MI355X_MICROARCH.md "Two waves per SIMD" items 2-4): default = every wave raises its priority around an MFMA
+    // cluster.  prio_mode 1 (gemm_variant 32770): waves 4-7 - the younger half, the arbitration loser - use level 2 there, waves 0-3 level 1.
+    // prio_mode 2 (gemm_variant 65538): no flips at all; waves 4-7 run at level 1 for the whole kernel (set once before the tile loop).
     auto mma_half = [&](const bf16x8* af, const bf16x8* bf, int mh, int part) {
-      __builtin_amdgcn_s_setprio(1);
+      if (prio_mode == 0) __builtin_amdgcn_s_setprio(1);
+      else if (prio_mode == 1) { if (wu >= 4) __builtin_amdgcn_s_setprio(2); else __builtin_amdgcn_s_setprio(1); }
 #pragma unroll
       for (int mi = 2 * part; mi < 2 * part + 2; ++mi)
 #pragma unroll
         for (int ni = 0; ni < 4; ++ni)
           acc[mh * 4 + mi][ni] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(bf[ni], af[mi], acc[mh * 4 + mi][ni], 0, 0, 0);
-      __builtin_amdgcn_s_setprio(0);
+      if (prio_mode != 2) __builtin_amdgcn_s_setprio(0);
     };
 
     // Software pipeline over the K-tiles, one barrier per K-tile placed BEFORE the last MFMA sub-phase:

@@ -79,12 +79,13 @@ if a.profiles > 1:      # P - 1 further enrolled speakers (random unit vectors, 
 rows = be.identify_speaker(tmp / "a.wav", cand)
 sync()
 t = mark("first_identify", t)
+first_from_pack = bool(getattr(getattr(be, "last_batch", None), "from_pack", False))
 rows = be.identify_speaker(tmp / "a.wav", cand)
 sync()
 t = mark("second_identify", t)
 wc = importlib.import_module("speaker-diarization-toolkit_amd.weights_cache")
 out = {"phases_s": ph, "time_to_first_row_s": round(sum(v for k, v in ph.items() if k != "second_identify"), 3),
        "process_wall_s": round(time.perf_counter() - t_proc, 3), "audio_seconds": a.seconds, "windows": rows[0]["n_segments"] if rows else 0,
-       "profiles": a.profiles, "profile_pack_hit": bool(getattr(getattr(be, "last_batch", None), "from_pack", False)),
+       "profiles": a.profiles, "profile_pack_hit": first_from_pack,
        "cache": {"enabled": wc.enabled(), "dir": str(wc.cache_dir()), "hit": bool(getattr(be, "_cache_hit", False))}, "model_version": mv, "lite": bool(a.lite), "torch_imported": "torch" in sys.modules}
 print(json.dumps(out))
