@@ -189,44 +189,64 @@ def precision_modes(eng, pcm, pcm_host, P_host, Pn, Pb, rpm, default_value, defa
 
 def xvector_object(eng, pcm, pcm_host, P_host, Pn, Pb, rpm, n_par=16):
     """The second model family north_star names (plain-TDNN x-vector, xvector.py / sdk_xvector_forward) on the same 1000 resident segments and
-    100 profiles, outside the timed region: throughput, its kernels, and cos / score deviation from its oracle's bf16 model on `n_par` segments."""
+    100 profiles, outside the timed region: throughput and kernels of the shipped default (bf16 operands, bias-corrected), its deviation from its
+    oracle's bf16 model (on the EFFECTIVE weights) and from the fp32 model next to the uncorrected extractor's, and the precise mode
+    (fp16 hi+lo planes: throughput + deviation from the un-rounded model)."""
     from oracle import ecapa as oecapa, fbank as ofbank, xvector as oxv
     XV = importlib.import_module(f"{PKG}.xvector")
     w = XV.synthetic_weights(0)
-    xv = XV.XVector(eng, w)
     B = pcm.shape[0]
-
-    def step():
-        E, Eb, re = xv.embed_pcm(pcm)
-        return E, eng.affinity_topk(E, Eb, re, Pn, Pb, rpm, k=1)
-    for _ in range(2):
-        step()
-    torch.cuda.synchronize()
-    reps = 10
-    t0 = time.perf_counter()
-    for _ in range(reps):
-        E, (gi, gs) = step()
-    torch.cuda.synchronize()
-    ms = (time.perf_counter() - t0) / reps * 1e3
-    eng.profile_begin()
-    step()
-    prof = eng.profile_end()
     m = min(n_par, B)
-    Eo = oecapa.l2_normalise(oxv.xvector_embed(w, torch.from_numpy(ofbank.fbank(pcm_host[:m])), mode="bf16").numpy())
-    par = parity_object(E[:m].cpu().numpy(), gi[:m, 0].cpu().numpy(), gs[:m, 0].cpu().numpy(), Eo, P_host)
-    Eo32 = oecapa.l2_normalise(oxv.xvector_embed(w, torch.from_numpy(ofbank.fbank(pcm_host[:m])), mode="fp32").numpy())
-    par32 = parity_object(E[:m].cpu().numpy(), gi[:m, 0].cpu().numpy(), gs[:m, 0].cpu().numpy(), Eo32, P_host)
+    feats_o = torch.from_numpy(ofbank.fbank(pcm_host[:m]))
+    Eo32 = oecapa.l2_normalise(oxv.xvector_embed(w, feats_o, mode="fp32").numpy())
+
+    def run(xv, reps):
+        def step():
+            E, Eb, re = xv.embed_pcm(pcm)
+            return E, eng.affinity_topk(E, Eb, re, Pn, Pb, rpm, k=1)
+        for _ in range(2):
+            step()
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(reps):
+            E, (gi, gs) = step()
+        torch.cuda.synchronize()
+        ms = (time.perf_counter() - t0) / reps * 1e3
+        eng.profile_begin()
+        step()
+        return ms, eng.profile_end(), E[:m].cpu().numpy(), gi[:m, 0].cpu().numpy(), gs[:m, 0].cpu().numpy()
+
+    def par(E, gi, gs, Eo):
+        r = parity_object(E, gi, gs, Eo, P_host)
+        return {"segments": m, "min_cos_embedding": r["min_cos_embedding"], "max_abs_dscore_all_pairs": r["max_abs_dscore_all_pairs"], "id_mismatches": r["id_mismatches"]}
+
+    xv = XV.XVector(eng, w)                                                     # the shipped default: bias correction per $SDK_BIAS_CORRECTION (on)
+    ms, prof, E, gi, gs = run(xv, 10)
+    Eo = oecapa.l2_normalise(oxv.xvector_embed(xv.effective_weights(), feats_o, mode="bf16").numpy())
     mac = XV.DEFAULT_XVECTOR.macs_per_frame()
     T = importlib.import_module(f"{PKG}.ops").num_frames(pcm.shape[1])
     gemm_ms = sum(prof[k]["ms"] for k in ("conv_gemm256", "conv_gemm") if k in prof)
-    return {"model": "x-vector 512-512-512-512-1500, statistics pooling, 192-d (SDK_MODEL=xvector)", "value": round(B / ms * 1e3, 1), "unit": "segment-embeddings/sec",
-            "ms_per_step": round(ms, 3), "steps_timed": reps, "gflop_per_segment": round(2.0 * mac * T / 1e9, 3),
-            "frame_layers_ms": round(gemm_ms, 3), "frame_layers_tflops": round(2.0 * mac * T * B / (gemm_ms * 1e-3) / 1e12, 1) if gemm_ms else None,
-            "kernels_ms": {k: round(v["ms"], 3) for k, v in prof.items()},
-            "parity_vs_bf16_oracle": {"segments": m, "min_cos_embedding": par["min_cos_embedding"], "max_abs_dscore_all_pairs": par["max_abs_dscore_all_pairs"],
-                                      "id_mismatches": par["id_mismatches"]},
-            "parity_vs_fp32_oracle": {"segments": m, "min_cos_embedding": par32["min_cos_embedding"], "max_abs_dscore_all_pairs": par32["max_abs_dscore_all_pairs"],
-                                      "id_mismatches": par32["id_mismatches"], "note": "bf16 operands, no bias correction for this family"}}
+    out = {"model": "x-vector 512-512-512-512-1500, statistics pooling, 192-d (SDK_MODEL=xvector)", "value": round(B / ms * 1e3, 1), "unit": "segment-embeddings/sec",
+           "bias_correction": bool(xv.bias_correction), "ms_per_step": round(ms, 3), "steps_timed": 10, "gflop_per_segment": round(2.0 * mac * T / 1e9, 3),
+           "frame_layers_ms": round(gemm_ms, 3), "frame_layers_tflops": round(2.0 * mac * T * B / (gemm_ms * 1e-3) / 1e12, 1) if gemm_ms else None,
+           "kernels_ms": {k: round(v["ms"], 3) for k, v in prof.items()},
+           "parity_vs_bf16_oracle": dict(par(E, gi, gs, Eo), note="oracle on the extractor's effective weights (corrected biases)"),
+           "parity_vs_fp32_oracle": par(E, gi, gs, Eo32)}
+    if xv.bias_correction:
+        _, _, E0, gi0, gs0 = run(XV.XVector(eng, w, bias_correction=False), 2)
+        out["parity_vs_fp32_oracle_uncorrected"] = par(E0, gi0, gs0, Eo32)
+    try:
+        xp = XV.XVector(eng, w, precision=1)
+        msp, profp, Ep, gip, gsp = run(xp, 4)
+        Eo64 = oecapa.l2_normalise(oxv.xvector_embed(w, feats_o, mode="fp32", acc=torch.float64).numpy())
+        pp = par(Ep, gip, gsp, Eo64)
+        hp = profp.get("conv_gemm_hp", {"ms": 0.0})
+        out["precise"] = dict(pp, value=round(B / msp * 1e3, 1), unit="segment-embeddings/sec", ms_per_step=round(msp, 3), steps_timed=4,
+                              operands="fp16 hi+lo planes, 3 MFMAs per product (sdk_conv_gemm_hp per frame layer, pooling on the planes)",
+                              conv_gemm_hp_ms=round(hp["ms"], 3), meets_north_star_1e_5=bool(pp["max_abs_dscore_all_pairs"] <= 1e-5 and pp["id_mismatches"] == 0))
+    finally:
+        eng.set_precision(0)
+    return out
 
 
 def ingest_object(eng, pcm_host, Pn, Pb, rpm, resident_value, n_steps=50):

@@ -295,7 +295,10 @@ int sdk_ecapa_forward_calib(sdk_ctx* ctx, const void* wblob, const sdk_ecapa_des
  *      pooling (mean | std over frames, sdk_asp_stats) and the embedding layer (fp32, sdk_rows_fc).  feats as sdk_fbank writes them
  *      ([B*T, ldf] bf16); emb [B, embed_dim] fp32 (pre-activation of the first segment layer, the usual x-vector).
  *      off[4 l + {0,1,2,3}] = W (bf16 [cout][K]), bias, BN scale, BN shift of frame layer l; off[60] = FC weight (fp32 [2 cout_last, embed_dim],
- *      transposed), off[61] = FC bias.  cout[] are multiples of 128 (pad a 1500-wide layer to 1536 with zero weights). */
+ *      transposed), off[61] = FC bias.  cout[] are multiples of 128 (pad a 1500-wide layer to 1536 with zero weights).
+ *      off[62] = numerical contract of the blob: -1 / 0 = bf16 operands (default mode); 1 = PRECISE mode (round 4): W slots are sdk_conv_gemm_hp
+ *      weight slots (header + fp16 hi / lo planes), feats are fp16 planes [B*T, ldf] (lo plane ldf/2 columns to the right, n_feats = 96 padded
+ *      mel channels, no tap packing), the layers run on sdk_conv_gemm_hp and the pooling on the planes; must equal the context's "precision". */
 typedef struct sdk_xvector_desc {
   int32_t n_frame_layers, n_feats, embed_dim, first_tap_pack;
   int32_t kernel[8], dilation[8], cin[8], cout[8];

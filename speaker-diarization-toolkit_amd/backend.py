@@ -170,11 +170,12 @@ class Backend(EmbeddingBackend):
             from .ops import Engine   # imports torch + dlopens libsdk_hip.so; raises SdkError if absent
             dev = int(os.environ.get("SDK_DEVICE", os.environ.get("LOCAL_RANK", "0")))
             if self.model == "xvector":
-                if int(os.environ.get("SDK_PRECISION", "0")):
-                    raise ValueError("SDK_PRECISION=1 (precise mode) exists for the ECAPA-TDNN family only")
                 from .xvector import XVector
+                prec = int(os.environ.get("SDK_PRECISION", "0"))
                 self._engine = Engine(dev)               # front end, k3, k4; its ECAPA weights are never packed (lazy)
-                self._xvector = XVector(self._engine, self._host_weights())
+                if prec:
+                    self._engine.set_precision(prec)
+                self._xvector = XVector(self._engine, self._host_weights(), precision=prec)      # bias correction: $SDK_BIAS_CORRECTION (default on)
                 return self._engine
             self._engine = Engine(dev, cache_key=self._cache_key(), weights_fn=self._host_weights, digest_fn=self._weights_digest)
             prec = int(os.environ.get("SDK_PRECISION", "0"))

@@ -534,6 +534,10 @@ int check_xdesc(const sdk_xvector_desc* d) {
     if (l > 0) SDK_REQUIRE(d->cin[l] == d->cout[l - 1] && d->cin[l] % 64 == 0, "xvector desc: layer %d cin=%d does not follow cout=%d", l, d->cin[l], d->cout[l - 1]);
     for (int q = 0; q < 4; ++q) SDK_REQUIRE(d->off[4 * l + q] >= 0, "xvector desc: slot %d of layer %d missing", q, l);
   }
+  SDK_REQUIRE(d->off[62] == -1 || d->off[62] == 0 || d->off[62] == 1, "xvector desc: off[62] (precision of the blob) must be -1 / 0 (bf16 operands) or 1 (fp16 planes)");
+  if (d->off[62] == 1)
+    SDK_REQUIRE(d->cin[0] == d->n_feats && d->n_feats % 32 == 0 && d->first_tap_pack == 0, "xvector desc: a precise-mode blob reads %d feature channels (a multiple of 32, no tap packing)", d->n_feats);
+  else
   SDK_REQUIRE(d->cin[0] == d->n_feats && (d->first_tap_pack == 0 ? d->n_feats % 64 == 0 : (d->first_tap_pack == d->n_feats && d->n_feats % 8 == 0 && d->kernel[0] > 1)),
               "xvector desc: first layer over %d features needs them to be a multiple of 64, or its taps packed (first_tap_pack = n_feats, a multiple of 8)", d->n_feats);
   SDK_REQUIRE(d->off[60] >= 0 && d->off[61] >= 0, "xvector desc: embedding layer slots missing");
@@ -543,10 +547,11 @@ size_t xv_layout(const sdk_xvector_desc* d, int B, int T, char* base, uint16_t**
   size_t cmax = 0;
   for (int l = 0; l < d->n_frame_layers; ++l) cmax = (size_t)d->cout[l] > cmax ? (size_t)d->cout[l] : cmax;
   const size_t M = (size_t)B * T;
+  const size_t esz = d->off[62] == 1 ? 4 : 2;                  // precise blob: activations travel as fp16 hi + lo planes (4 bytes per element)
   size_t off = 0;
   auto take = [&](size_t bytes) { char* p = base ? base + off : nullptr; off += a256(bytes); return p; };
-  char* a = take(M * cmax * 2);
-  char* b = take(M * cmax * 2);
+  char* a = take(M * cmax * esz);
+  char* b = take(M * cmax * esz);
   char* c = take((size_t)B * 2 * d->cout[d->n_frame_layers - 1] * 4);
   if (buf0) { *buf0 = (uint16_t*)a; *buf1 = (uint16_t*)b; *stats = (float*)c; }
   return off;
@@ -562,9 +567,13 @@ extern "C" int sdk_xvector_forward(sdk_ctx* ctx, const void* wblob, const sdk_xv
                                    void* ws, size_t ws_bytes, float* emb, void* stream) {
   SDK_REQUIRE(ctx && wblob && feats && ws && emb, "sdk_xvector_forward: null argument");
   if (int rc = check_xdesc(d)) return rc;
-  SDK_REQUIRE(ctx->precision == 0, "sdk_xvector_forward: the x-vector extractor exists in the default (bf16-operand) mode only");
+  const bool hp = d->off[62] == 1;
+  SDK_REQUIRE(ctx->precision == (hp ? 1 : 0), "sdk_xvector_forward: the weight blob was packed for precision %d, the context runs precision %d "
+              "(sdk_set_option \"precision\")", hp ? 1 : 0, ctx->precision);
   SDK_REQUIRE(B > 0 && T > 0 && (int64_t)B * T < (1ll << 31), "sdk_xvector_forward: bad batch (B=%d T=%d)", B, T);
-  SDK_REQUIRE(ldf >= d->n_feats && ldf % 8 == 0, "sdk_xvector_forward: ldf=%d < feature width %d", ldf, d->n_feats);
+  if (hp) SDK_REQUIRE(ldf % 16 == 0 && (ldf >> 1) >= d->n_feats && d->first_tap_pack == 0 && d->n_feats % 32 == 0,
+                      "sdk_xvector_forward: precise mode reads fp16 planes [B*T, ldf] with the lo plane ldf/2 columns to the right: ldf=%d, n_feats=%d (a multiple of 32, no tap packing)", ldf, d->n_feats);
+  else SDK_REQUIRE(ldf >= d->n_feats && ldf % 8 == 0, "sdk_xvector_forward: ldf=%d < feature width %d", ldf, d->n_feats);
   for (int l = 0; l < d->n_frame_layers; ++l)
     SDK_REQUIRE(T > (d->kernel[l] / 2) * d->dilation[l], "sdk_xvector_forward: segments of %d frames are shorter than layer %d's halo", T, l);
   SDK_REQUIRE(ws_bytes >= sdk_xvector_workspace_bytes(d, B, T) && ((uintptr_t)ws % 256) == 0 && ((uintptr_t)wblob % 256) == 0, "sdk_xvector_forward: workspace too small or misaligned");
@@ -575,20 +584,40 @@ extern "C" int sdk_xvector_forward(sdk_ctx* ctx, const void* wblob, const sdk_xv
   const uint16_t* in = feats;
   int64_t ldin = ldf;
   const int M = B * T;
-  for (int l = 0; l < d->n_frame_layers; ++l) {
-    uint16_t* out = (l & 1) ? b1 : b0;
-    sdk_conv_gemm_args g;
-    memset(&g, 0, sizeof(g));
-    g.A = in; g.lda = ldin; g.W = (const uint16_t*)(wb + d->off[4 * l]); g.C = out; g.ldc = d->cout[l];
-    g.bias = (const float*)(wb + d->off[4 * l + 1]); g.scale = (const float*)(wb + d->off[4 * l + 2]); g.shift = (const float*)(wb + d->off[4 * l + 3]);
-    g.M = M; g.N = d->cout[l]; g.Cin = d->cin[l]; g.taps = d->kernel[l]; g.dil = d->dilation[l]; g.T = T; g.flags = SDK_GEMM_RELU;
-    if (l == 0 && d->first_tap_pack) g.tap_pack = d->first_tap_pack;
-    if (int rc = sdk_conv_gemm(ctx, &g, stream)) return rc;
-    in = out;
-    ldin = d->cout[l];
-  }
   const int Cl = d->cout[d->n_frame_layers - 1];
-  if (int rc = sdk_asp_stats(ctx, in, ldin, B, T, Cl, stats, stream)) return rc;
+  if (hp) {
+    // precise mode (north_star's 1e-5): every frame layer on the fp16 hi+lo plane GEMM (three MFMAs per product, csrc/hp.hip), planes between the
+    // layers, statistics pooling on the planes; the embedding layer is fp32 either way
+    int64_t in_lo = ldf >> 1;
+    for (int l = 0; l < d->n_frame_layers; ++l) {
+      uint16_t* out = (l & 1) ? b1 : b0;
+      sdk_conv_gemm_hp_args g;
+      memset(&g, 0, sizeof(g));
+      g.A = in; g.lda = ldin; g.a_lo = in_lo; g.W = (const uint16_t*)(wb + d->off[4 * l]);
+      g.C = out; g.ldc = 2 * (int64_t)d->cout[l]; g.c_lo = d->cout[l];
+      g.bias = (const float*)(wb + d->off[4 * l + 1]); g.scale = (const float*)(wb + d->off[4 * l + 2]); g.shift = (const float*)(wb + d->off[4 * l + 3]);
+      g.M = M; g.N = d->cout[l]; g.Cin = d->cin[l]; g.taps = d->kernel[l]; g.dil = d->dilation[l]; g.T = T; g.flags = SDK_GEMM_RELU;
+      if (int rc = sdk_conv_gemm_hp(ctx, &g, stream)) return rc;
+      in = out;
+      ldin = 2 * (int64_t)d->cout[l];
+      in_lo = d->cout[l];
+    }
+    if (int rc = hp_asp_stats(ctx, in, ldin, in_lo, B, T, Cl, stats, stream)) return rc;
+  } else {
+    for (int l = 0; l < d->n_frame_layers; ++l) {
+      uint16_t* out = (l & 1) ? b1 : b0;
+      sdk_conv_gemm_args g;
+      memset(&g, 0, sizeof(g));
+      g.A = in; g.lda = ldin; g.W = (const uint16_t*)(wb + d->off[4 * l]); g.C = out; g.ldc = d->cout[l];
+      g.bias = (const float*)(wb + d->off[4 * l + 1]); g.scale = (const float*)(wb + d->off[4 * l + 2]); g.shift = (const float*)(wb + d->off[4 * l + 3]);
+      g.M = M; g.N = d->cout[l]; g.Cin = d->cin[l]; g.taps = d->kernel[l]; g.dil = d->dilation[l]; g.T = T; g.flags = SDK_GEMM_RELU;
+      if (l == 0 && d->first_tap_pack) g.tap_pack = d->first_tap_pack;
+      if (int rc = sdk_conv_gemm(ctx, &g, stream)) return rc;
+      in = out;
+      ldin = d->cout[l];
+    }
+    if (int rc = sdk_asp_stats(ctx, in, ldin, B, T, Cl, stats, stream)) return rc;
+  }
   return sdk_rows_fc(ctx, stats, 2 * Cl, nullptr, nullptr, (const float*)(wb + d->off[60]), (const float*)(wb + d->off[61]), emb, d->embed_dim, B, 2 * Cl,
                      d->embed_dim, 0, stream);
 }

@@ -136,9 +136,32 @@ class LiteEngine:
         self.cache_hit = True
 
     def load_xvector(self, weights: Dict[str, np.ndarray]) -> None:
+        """Pack and upload the x-vector family; with the bias correction on (the shipped default) the same calibration pass ops-side XVector runs
+        (xvector.calibration_means: library calls only), so both host paths hold bit-identical blobs."""
         from . import xvector
+        from .weights_pack import calibration_pcm
         blob, desc = xvector.pack_weights(weights)
-        self._xv = (DevBuf(self, blob.size).upload(blob), desc)
+        dev = DevBuf(self, blob.size).upload(blob)
+        if self.bias_correction:
+            pcm = calibration_pcm()
+            B, S = pcm.shape
+            feats = self.fbank(self._buf("pcm", pcm.nbytes).upload(pcm), B, S)
+            keep = []
+
+            def alloc(nbytes):
+                keep.append(DevBuf(self, nbytes))
+                return keep[-1].ptr
+
+            def download(ptr, n_floats):
+                return next(k for k in keep if k.ptr == ptr).download(np.float32, (n_floats,))
+            means = xvector.calibration_means(self.lib, self.ctx, desc, xvector.DEFAULT_XVECTOR, dev.ptr, feats.ptr, N_MELS_PADDED, B, num_frames(S),
+                                              alloc, download, None)
+            blob, desc = xvector.pack_weights(dict(weights, **xvector.bias_corrections(weights, means)))
+            dev.free()
+            dev = DevBuf(self, blob.size).upload(blob)
+            for k in keep:
+                k.free()
+        self._xv = (dev, desc)
 
     # ---------------------------------------------------------------- the path (device buffers in, device buffers out)
     def fbank(self, pcm_dev: DevBuf, B: int, S: int) -> DevBuf:

@@ -21,7 +21,7 @@ from typing import Dict, Tuple
 import numpy as np
 
 from .weights import bn_affine
-from .weights_pack import ALIGN, conv_weight_kmajor
+from .weights_pack import ALIGN, N_MELS_PADDED_HP, bf16_bits_to_f32, conv_weight_kmajor, conv_weight_kmajor_f32, f32_to_bf16_bits, hp_weight_planes
 
 
 @dataclass(frozen=True)
@@ -79,19 +79,27 @@ def synthetic_weights(seed: int = 0, cfg: XVectorConfig = DEFAULT_XVECTOR) -> Di
     return out
 
 
-def pack_weights(weights: Dict[str, np.ndarray], cfg: XVectorConfig = DEFAULT_XVECTOR):
+def pack_weights(weights: Dict[str, np.ndarray], cfg: XVectorConfig = DEFAULT_XVECTOR, precision: int = 0):
     """-> (blob uint8, XVectorDesc).  Channel counts are padded to multiples of 128 with zero weights / bias, BN scale 1, shift 0 (a padded
-    channel is exactly 0 after ReLU; its pooled mean is 0, its std the 1e-6 floor, and the embedding layer's weights for it are zero)."""
+    channel is exactly 0 after ReLU; its pooled mean is 0, its std the 1e-6 floor, and the embedding layer's weights for it are zero).
+    precision 1: the precise mode's blob (off[62] = 1): every frame layer's weights as a power-of-two-scaled fp16 hi + lo plane slot
+    (weights_pack.hp_weight_planes), the first layer over the 96 padded mel channels of the plane-format features, no tap packing."""
     for k, s in param_shapes(cfg).items():
         if k not in weights or tuple(weights[k].shape) != s:
             raise ValueError(f"x-vector weight {k}: expected shape {s}, got {None if k not in weights else tuple(weights[k].shape)}")
+    if precision not in (0, 1):
+        raise ValueError(f"precision must be 0 or 1, got {precision}")
     pc = cfg.padded_channels()
     cin_real = (cfg.n_feats,) + cfg.channels[:-1]
-    cin_pad = (cfg.n_feats,) + pc[:-1]
+    n_in = N_MELS_PADDED_HP if precision == 1 else cfg.n_feats
+    if precision == 1 and cfg.n_feats > N_MELS_PADDED_HP:
+        raise ValueError(f"precise mode reads {N_MELS_PADDED_HP} padded feature channels, the configuration has {cfg.n_feats}")
+    cin_pad = (n_in,) + pc[:-1]
     d = XVectorDesc()
-    d.n_frame_layers, d.n_feats, d.embed_dim = len(cfg.kernels), cfg.n_feats, cfg.embed_dim
-    d.first_tap_pack = cfg.n_feats if cfg.n_feats % 64 else 0
+    d.n_frame_layers, d.n_feats, d.embed_dim = len(cfg.kernels), n_in, cfg.embed_dim
+    d.first_tap_pack = 0 if precision == 1 else (cfg.n_feats if cfg.n_feats % 64 else 0)
     off = [-1] * 64
+    off[62] = precision
     chunks, cur = [], 0
 
     def put(slot, arr):
@@ -105,12 +113,15 @@ def pack_weights(weights: Dict[str, np.ndarray], cfg: XVectorConfig = DEFAULT_XV
     for l in range(len(cfg.kernels)):
         w = np.zeros((pc[l], cin_pad[l], cfg.kernels[l]), np.float32)
         w[:cfg.channels[l], :cin_real[l], :] = weights[f"frame{l}.conv.w"]
-        wk = conv_weight_kmajor(w)                                          # bf16 bits [cout, k * cin]
-        if l == 0 and d.first_tap_pack:
-            kp = (wk.shape[1] + 63) // 64 * 64
-            wp = np.zeros((wk.shape[0], kp), np.uint16)
-            wp[:, :wk.shape[1]] = wk
-            wk = wp
+        if precision == 1:
+            wk = hp_weight_planes(conv_weight_kmajor_f32(w))                    # 256-byte header + fp16 hi / lo planes of 2^s W, [cout, k * cin] each
+        else:
+            wk = conv_weight_kmajor(w)                                          # bf16 bits [cout, k * cin]
+            if l == 0 and d.first_tap_pack:
+                kp = (wk.shape[1] + 63) // 64 * 64
+                wp = np.zeros((wk.shape[0], kp), np.uint16)
+                wp[:, :wk.shape[1]] = wk
+                wk = wp
         put(4 * l, wk)
         b = np.zeros(pc[l], np.float32); b[:cfg.channels[l]] = weights[f"frame{l}.conv.b"]
         s, sh = bn_affine(weights, f"frame{l}.bn")
@@ -131,21 +142,101 @@ def pack_weights(weights: Dict[str, np.ndarray], cfg: XVectorConfig = DEFAULT_XV
     return blob, d
 
 
-class XVector:
-    """Resident x-vector extractor on an ops.Engine (device blob + descriptor); embed_pcm mirrors Engine.embed_pcm."""
+def bias_corrections(weights: Dict[str, np.ndarray], means: Dict[int, np.ndarray], cfg: XVectorConfig = DEFAULT_XVECTOR) -> Dict[str, np.ndarray]:
+    """frame layer l -> corrected fp32 bias  b + (W - bf16(W)) . mu_l  (float64 inside; every tap sees the same channel means) - the same
+    post-training bias correction of the bf16 weight rounding the ECAPA-TDNN family gets (weights_pack.bias_corrections)."""
+    out = {}
+    for l, mu in means.items():
+        w = weights[f"frame{l}.conv.w"].astype(np.float64)
+        dw = w - bf16_bits_to_f32(f32_to_bf16_bits(w.astype(np.float32))).astype(np.float64)
+        corr = np.tensordot(dw.sum(axis=2), np.asarray(mu, np.float64)[:dw.shape[1]], axes=([1], [0]))
+        out[f"frame{l}.conv.b"] = (weights[f"frame{l}.conv.b"].astype(np.float64) + corr).astype(np.float32)
+    return out
 
-    def __init__(self, engine, weights: Dict[str, np.ndarray] = None, cfg: XVectorConfig = DEFAULT_XVECTOR, seed: int = 0):
+
+def calibration_means(lib, ctx, d: "XVectorDesc", cfg: XVectorConfig, blob_ptr: int, feats_ptr: int, ldf: int, B: int, T: int, alloc, download,
+                      stream) -> Dict[int, np.ndarray]:
+    """Per-channel means of the INPUT of frame layers 1..L-1 of a default-mode blob: the layers run one at a time through sdk_conv_gemm, the
+    per-segment channel means come from sdk_asp_stats - C-ABI calls only, so ops.Engine (torch tensors) and lite.LiteEngine (sdk_device_malloc)
+    run the identical sequence and get identical means.  alloc(nbytes) -> device pointer (kept alive by the caller); download(ptr, n_floats)
+    -> float32 host array (synchronising)."""
+    from ._lib import ConvGemmArgs, GEMM_RELU, check
+    means: Dict[int, np.ndarray] = {}
+    x, ldx = feats_ptr, ldf
+    M = B * T
+    for l in range(d.n_frame_layers - 1):
+        cout = d.cout[l]
+        out = alloc(M * cout * 2)
+        g = ConvGemmArgs()
+        g.A, g.lda, g.W = x, ldx, blob_ptr + int(d.off[4 * l])
+        g.C, g.ldc = out, cout
+        g.bias, g.scale, g.shift = blob_ptr + int(d.off[4 * l + 1]), blob_ptr + int(d.off[4 * l + 2]), blob_ptr + int(d.off[4 * l + 3])
+        g.M, g.N, g.Cin, g.taps, g.dil, g.T = M, cout, d.cin[l], d.kernel[l], d.dilation[l], T
+        g.flags = GEMM_RELU
+        g.tap_pack = d.first_tap_pack if l == 0 else 0
+        check(lib.sdk_conv_gemm(ctx, C.byref(g), stream), "sdk_conv_gemm")
+        st = alloc(B * 2 * cout * 4)
+        check(lib.sdk_asp_stats(ctx, out, cout, B, T, cout, st, stream), "sdk_asp_stats")
+        stats = download(st, B * 2 * cout).reshape(B, 2 * cout)                  # mean | std per segment
+        means[l + 1] = stats[:, :cout].astype(np.float64).mean(axis=0)[:cfg.channels[l]]
+        x, ldx = out, cout
+    return means
+
+
+class XVector:
+    """Resident x-vector extractor on an ops.Engine (device blob + descriptor); embed_pcm mirrors Engine.embed_pcm.
+    bias_correction (default: $SDK_BIAS_CORRECTION, on): default mode only - fold the constant part of the bf16 weight-rounding error of frame
+    layers 1.. into their biases, from ONE calibration pass on the engine's built-in synthetic audio (the layer inputs' channel means are
+    measured on the GPU with the library's own kernels; layer 0 needs none: its input is mean-normalised).  precision 1: the precise mode
+    (fp16 hi+lo planes, three MFMAs per product) - the engine must run precision 1 too (Engine.set_precision), which XVector does itself."""
+
+    def __init__(self, engine, weights: Dict[str, np.ndarray] = None, cfg: XVectorConfig = DEFAULT_XVECTOR, seed: int = 0,
+                 bias_correction=None, precision: int = 0):
+        import os
         import torch
-        self.eng, self.cfg = engine, cfg
-        blob, self.desc = pack_weights(weights if weights is not None else synthetic_weights(seed, cfg), cfg)
+        self.eng, self.cfg, self.precision = engine, cfg, int(precision)
+        self.weights = dict(weights if weights is not None else synthetic_weights(seed, cfg))
+        self.bias_correction = ((os.environ.get("SDK_BIAS_CORRECTION", "1") != "0") if bias_correction is None else bool(bias_correction)) and self.precision == 0
+        blob, self.desc = pack_weights(self.weights, cfg, precision=self.precision)
         self.blob = torch.from_numpy(blob).to(engine.device)
+        self._effective = self.weights
+        if self.bias_correction:
+            self._effective = dict(self.weights, **bias_corrections(self.weights, self._calibrate(), cfg))
+            blob, self.desc = pack_weights(self._effective, cfg)
+            self.blob = torch.from_numpy(blob).to(engine.device)
+
+    def effective_weights(self) -> Dict[str, np.ndarray]:
+        """The weights whose bf16 layer-boundary model the default mode computes (= the loaded ones with the corrected biases)."""
+        return self._effective
+
+    def _calibrate(self) -> Dict[int, np.ndarray]:
+        """Channel means of the inputs of frame layers 1..L-1 on the built-in calibration audio (calibration_means: library calls only)."""
+        import torch
+        from .ops import _stream, num_frames
+        from .weights_pack import calibration_pcm
+        eng = self.eng
+        pcm = torch.from_numpy(calibration_pcm()).to(eng.device)
+        B, S = pcm.shape
+        feats = eng.fbank(pcm)
+        keep = []
+
+        def alloc(nbytes):
+            keep.append(torch.empty(nbytes, dtype=torch.uint8, device=eng.device))
+            return keep[-1].data_ptr()
+
+        def download(ptr, n_floats):
+            t = next(k for k in keep if k.data_ptr() == ptr)
+            return t[:4 * n_floats].view(torch.float32).cpu().numpy()
+        return calibration_means(eng.lib, eng.ctx, self.desc, self.cfg, self.blob.data_ptr(), feats.data_ptr(), feats.stride(0), B, num_frames(S),
+                                 alloc, download, _stream())
 
     def forward(self, feats, B: int, T: int):
-        """feats [B*T, ldf] bf16 (as Engine.fbank writes them) -> raw embeddings [B, embed_dim] fp32."""
+        """feats [B*T, ldf] bf16 as Engine.fbank writes them (precise mode: fp16 planes) -> raw embeddings [B, embed_dim] fp32."""
         import torch
         from ._lib import check
         from .ops import _stream
         lib = self.eng.lib
+        check(lib.sdk_set_option(self.eng.ctx, b"precision", self.precision), "sdk_set_option")
         ws = self.eng._scratch_bytes("xvector", lib.sdk_xvector_workspace_bytes(C.byref(self.desc), B, T))
         emb = torch.empty((B, self.cfg.embed_dim), dtype=torch.float32, device=self.eng.device)
         check(lib.sdk_xvector_forward(self.eng.ctx, self.blob.data_ptr(), C.byref(self.desc), feats.data_ptr(), feats.stride(0), B, T,
@@ -155,4 +246,6 @@ class XVector:
     def embed_pcm(self, pcm):
         from .ops import num_frames
         B, S = pcm.shape
+        if self.eng.precision != self.precision:
+            self.eng.set_precision(self.precision)              # the front end's output format follows the numerical contract
         return self.eng.l2norm(self.forward(self.eng.fbank(pcm), B, num_frames(S)))

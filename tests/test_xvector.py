@@ -100,12 +100,18 @@ def test_xvector_pcm_to_assignment(engine):
     torch.cuda.synchronize()
     oidx, osc = oscoring.affinity_topk(E.cpu().numpy(), Pn.cpu().numpy(), 1)
     assert np.array_equal(idx.cpu().numpy(), oidx) and np.abs(sc.cpu().numpy() - osc).max() <= 1e-5
-    engine.set_precision(1)
+    # a blob packed for one numerical contract is refused by a context running the other (the library call itself: XVector.forward always
+    # makes the context agree with its blob first)
+    L = sub("_lib")
+    ws = torch.empty(engine.lib.sdk_xvector_workspace_bytes(C.byref(xv.desc), 1, 201), dtype=torch.uint8, device="cuda")
+    out = torch.empty(1, 192, device="cuda")
+    engine.set_option("precision", 1)
     try:
-        with pytest.raises(sub("_lib").SdkError, match="default .* mode only"):
-            xv.forward(torch.zeros(201, 192, dtype=torch.float16, device="cuda"), 1, 201)
+        with pytest.raises(L.SdkError, match="packed for precision 0"):
+            L.check(engine.lib.sdk_xvector_forward(engine.ctx, xv.blob.data_ptr(), C.byref(xv.desc), torch.zeros(201, 192, dtype=torch.float16, device="cuda").data_ptr(),
+                                                   192, 1, 201, ws.data_ptr(), ws.numel(), out.data_ptr(), None), "sdk_xvector_forward")
     finally:
-        engine.set_precision(0)
+        engine.set_option("precision", 0)
 
 
 def test_backend_model_selection_metadata(monkeypatch):
@@ -185,3 +191,64 @@ def test_backend_xvector_enroll_identify_roundtrip(tmp_path, monkeypatch):
     monkeypatch.setenv("SDK_MODEL", "ecapa")
     with pytest.raises(ValueError, match="enrolled under other weights"):
         sub("backend").Backend().identify_speaker(tpath, profiles)
+
+
+@pytest.mark.gpu
+def test_xvector_bias_correction_is_the_bf16_model_of_its_effective_weights_and_closer_to_fp32(engine):
+    """the second model family gets the same post-training bias correction of the bf16 weight rounding
+    (b' = b + (W - bf16(W)) . mu on frame layers 1..4, means measured on the GPU by a calibration pass).  The corrected extractor computes exactly
+    the bf16 layer-boundary model of its EFFECTIVE weights, and its PCM -> score deviation from the fp32 model shrinks."""
+    import importlib, sys
+    from conftest import ROOT
+    from oracle import fbank as ofbank
+    sys.path.insert(0, str(ROOT))
+    bench = importlib.import_module("bench")
+    w = XV.synthetic_weights(0)
+    plain = XV.XVector(engine, w, bias_correction=False)
+    corr = XV.XVector(engine, w, bias_correction=True)
+    eff = corr.effective_weights()
+    changed = [k for k in w if not np.array_equal(eff[k], w[k])]
+    assert sorted(changed) == [f"frame{l}.conv.b" for l in (1, 2, 3, 4)]              # layer 0 reads mean-normalised features: nothing to correct
+    assert plain.effective_weights() is plain.weights
+    pcm = bench.synth_pcm(48, seed=2)
+    feats = torch.from_numpy(ofbank.fbank(pcm))
+    P = bench.unit_rows(100, 192, seed=1).astype(np.float64)
+    Ec = corr.embed_pcm(torch.from_numpy(pcm).cuda())[0].cpu()
+    Ep = plain.embed_pcm(torch.from_numpy(pcm).cuda())[0].cpu()
+    want = torch.from_numpy(oecapa.l2_normalise(oxv.xvector_embed(eff, feats, mode="bf16").numpy()))
+    assert (_cos(Ec, want) > 1 - 2e-5).all()
+    E32 = oecapa.l2_normalise(oxv.xvector_embed(w, feats, mode="fp32").numpy()).astype(np.float64)
+    dev = {n: float(np.abs(E.numpy().astype(np.float64) @ P.T - E32 @ P.T).max()) for n, E in (("plain", Ep), ("corrected", Ec))}
+    print("\nx-vector PCM -> score deviation from the fp32 model (48 segments x 100 profiles):", dev)
+    assert dev["corrected"] < 0.75 * dev["plain"], dev
+
+
+@pytest.mark.gpu
+def test_xvector_precise_mode_meets_1e5(engine):
+    """the x-vector family in the precise mode (fp16 hi+lo planes, three MFMAs per product, sdk_conv_gemm_hp per frame layer,
+    pooling on the planes): PCM -> cosine score within north_star's 1e-5 of the un-rounded model (float64 accumulation), IDs identical."""
+    import importlib, sys
+    from conftest import ROOT
+    from oracle import fbank as ofbank
+    sys.path.insert(0, str(ROOT))
+    bench = importlib.import_module("bench")
+    w = XV.synthetic_weights(0)
+    xv = XV.XVector(engine, w, precision=1)
+    assert xv.bias_correction is False and int(xv.desc.off[62]) == 1 and xv.desc.n_feats == 96 and xv.desc.first_tap_pack == 0
+    pcm = bench.synth_pcm(32, seed=4)
+    P = bench.unit_rows(100, 192, seed=1)
+    try:
+        E, Eb, re = xv.embed_pcm(torch.from_numpy(pcm).cuda())
+        assert engine.precision == 1
+        Pn, Pb, rp = engine.l2norm(torch.from_numpy(P).cuda())
+        gi, gs = engine.affinity_topk(E, Eb, re, Pn, Pb, rp.max().reshape(1), k=1)
+        torch.cuda.synchronize()
+    finally:
+        engine.set_precision(0)
+    Eo = oecapa.l2_normalise(oxv.xvector_embed(w, torch.from_numpy(ofbank.fbank(pcm)), mode="fp32", acc=torch.float64).numpy())
+    par = bench.parity_object(E.cpu().numpy(), gi.cpu().numpy()[:, 0], gs.cpu().numpy()[:, 0], Eo, P)
+    print("\nx-vector precise mode vs the un-rounded oracle:", {k: par[k] for k in ("max_abs_dscore_all_pairs", "max_abs_dscore_top1", "min_cos_embedding", "id_mismatches")})
+    assert par["max_abs_dscore_all_pairs"] <= 1e-5 and par["id_mismatches"] == 0
+    # and the default-mode extractor still runs afterwards on the same engine (the context follows each extractor's contract)
+    E0 = XV.XVector(engine, w, bias_correction=False).embed_pcm(torch.from_numpy(pcm).cuda())[0]
+    assert float((E0.cpu().double() * torch.from_numpy(Eo).double()).sum(1).min()) > 0.999
