@@ -81,7 +81,8 @@ int sdk_stream_synchronize(sdk_ctx* ctx, void* stream);
  * 0 = 8-wave workgroups, one segment per CU), "asp_packed_weights"
  * (likewise for the ASP logit weights, EL_ASP_W2PACK), "asp_per_segment"
  * (1 default / 0 = one workgroup per (segment, 128 channels)), "affinity_fast_path" / "affinity_variant" /
- * "affinity_whole_groups" / "affinity_boundary_penalty" (k = 1 affinity kernel selection and work split), "matvec_variant" (0 default: persistent row-group kernel / 1 = round 1's
+ * "affinity_whole_groups" / "affinity_boundary_penalty" (k = 1 affinity kernel selection and work split), "chol_pivot_rtol_ppb" / "chol_shift_ppb"
+ * (sdk_chol_inverse, below), "matvec_variant" (0 default: persistent row-group kernel / 1 = round 1's
  * kernel; sums differ in the last bits only), "gemm_variant" (see sdk_set_gemm_variant).  Results do not depend on them.
  * NOT a knob - a numerical contract: "precision" 0 (default: bf16 operands, bf16 layer-boundary storage; PCM -> score within ~4e-3 of
  * the fp32 model) / 1 (fp16 hi+lo planes, three MFMAs per product: within 1e-5, ~3x the GEMM time).  It selects the output format of
@@ -355,9 +356,14 @@ int sdk_affinity_topk(sdk_ctx* ctx, const float* E, const uint16_t* Eb, const fl
  *   sdk_rows_gram       : G [k,k] = X^T Y over n rows (order-fixed two-stage reduction)
  *   sdk_rows_apply      : Y[i,:] = scale[i] * (X[i,:] @ R),  R [k,k] row-major, scale may be NULL
  *   sdk_chol_inverse    : Rinv [k,k] = (L^T)^-1 with (G + G^T)/2 = L L^T, float64 inside (CholeskyQR without leaving the stream);
- *                         *not_spd (device int32, may be NULL) is SET to 1 if a pivot was not positive or not a number (never cleared:
- *                         zero it once, run any number of passes, read it at the next host synchronisation); the offending pivot is
- *                         replaced by 1 so the stream keeps running, the result is then meaningless
+ *                         *not_spd (device int32, may be NULL) is SET to 1 if a pivot is not a number, not positive, OR at most 1e-6 of its
+ *                         diagonal entry (the relative-pivot rule: column i lies within 1e-3 of the span of the columns before it, i.e.
+ *                         cond(Y) > ~1e3 - beyond that the fp32 Gram matrix is rounding noise; sdk_set_option "chol_pivot_rtol_ppb", in 1e-9,
+ *                         default 1000).  Never cleared: zero it once, run any number of passes, read it at the next host synchronisation.
+ *                         Only a non-positive / NaN pivot is replaced (by 1, so the stream keeps running; the result is then meaningless).
+ *                         "chol_shift_ppb" > 0: shifted CholeskyQR (G + s I, s = that fraction, in 1e-9, of the mean diagonal entry) for
+ *                         nearly rank-deficient blocks; follow it with unshifted passes (cluster.spectral_cluster retries once that way
+ *                         when the flag was raised - over-clustered or near-duplicate inputs - before it reports a lost rank)
  *   sdk_rows_unit       : rows scaled to unit length
  *   sdk_kmeans_mindist  : d2[i] = (first ? : min(d2[i],)) |R[i] - centre|^2      (maximin initialisation)
  *   sdk_kmeans_assign   : label[i] = nearest of kc centres (ties -> lowest), dist2, optional per-256-row-block

@@ -95,9 +95,7 @@ def spectral_cluster(provider, E_local: torch.Tensor, Eb_local: torch.Tensor, n_
     V = torch.from_numpy(G0[lo:hi].astype(np.float32)).to(dev)
     # not-positive-definite flag of every CholeskyQR pass (sticky, device side): read once, at the Ritz step's host synchronisation
     spd_flag = torch.zeros((1,), dtype=torch.int32, device=dev)
-    V = _orth(provider, comm, V, k, spd_flag)
-    mark("init")
-
+    V0 = V
     eye = torch.eye(k, dtype=torch.float32, device=dev)
 
     def apply_S(Vloc: torch.Tensor) -> torch.Tensor:
@@ -105,15 +103,28 @@ def spectral_cluster(provider, E_local: torch.Tensor, Eb_local: torch.Tensor, n_
         Y = provider.affinity_matvec(Eb_all, Vall, lo, n_loc, xscale=dinv_all)[lo:hi].contiguous()
         return provider.rows_apply(Y, eye, scale=dinv_loc)
 
-    for _ in range(n_iter):
-        Y = apply_S(V)
+    def iterate(shifted: bool):
+        Vc = _orth(provider, comm, V0, k, spd_flag, shifted)
+        mark("init")
+        for _ in range(n_iter):
+            Y = apply_S(Vc)
+            mark("apply_S")
+            Vc = _orth(provider, comm, Y, k, spd_flag, shifted)
+            mark("orth")
+        SVc = apply_S(Vc)
         mark("apply_S")
-        V = _orth(provider, comm, Y, k, spd_flag)
-        mark("orth")
-    SV = apply_S(V)
-    mark("apply_S")
-    H = comm.sum_(provider.rows_gram(V, SV)).double().cpu().numpy()
-    if int(spd_flag.item()) or not np.isfinite(H).all():
+        return Vc, comm.sum_(provider.rows_gram(Vc, SVc)).double().cpu().numpy()
+
+    V, H = iterate(False)
+    flagged = int(comm.sum_(spd_flag.float()).item()) > 0                # every rank takes the same branch (the Gram matrices are all-reduced: normally equal anyway)
+    if flagged and np.isfinite(H).all() and hasattr(provider, "set_option"):
+        # A pivot fell under the relative-pivot rule (sdk_chol_inverse: cond(Y) > ~1e3): over-clustered or near-duplicate input - lambda_k / lambda_1
+        # near 1e-3 - where plain CholeskyQR2 is at the edge of what an fp32 Gram matrix carries.  One retry with SHIFTED CholeskyQR
+        # (first pass on G + 1e-5 mean(diag) I, then two plain passes: "CholeskyQR3"), judged by the same rule on its plain passes.
+        spd_flag.zero_()
+        V, H = iterate(True)
+        flagged = int(comm.sum_(spd_flag.float()).item()) > 0
+    if flagged or not np.isfinite(H).all():
         # a Gram matrix of the iteration was not positive definite: k exceeds the rank of the embeddings (duplicated rows, fewer
         # distinct segments than clusters) or the input holds NaN.  The host-side CholeskyQR of round 1 raised here too.
         raise np.linalg.LinAlgError(f"spectral_cluster: the k = {k} subspace lost rank (Gram matrix not positive definite): "
@@ -134,9 +145,17 @@ def spectral_cluster(provider, E_local: torch.Tensor, Eb_local: torch.Tensor, n_
     return SpectralResult(labels, lam[order], n_iter, timing)
 
 
-def _orth(provider, comm: _Comm, Y: torch.Tensor, k: int, spd_flag: Optional[torch.Tensor] = None) -> torch.Tensor:
+def _orth(provider, comm: _Comm, Y: torch.Tensor, k: int, spd_flag: Optional[torch.Tensor] = None, shifted: bool = False) -> torch.Tensor:
     """CholeskyQR2: Q = Y R^-1 with R^T R = sum_ranks Y^T Y; applied twice for fp32 stability.  Nothing here synchronises with the
-    host: Gram (two-stage, order-fixed) -> all-reduce -> k x k Cholesky + triangular inverse in float64 on the device -> apply."""
+    host: Gram (two-stage, order-fixed) -> all-reduce -> k x k Cholesky + triangular inverse in float64 on the device -> apply.
+    shifted: a first pass on G + 1e-5 mean(diag G) I (not judged by the pivot rule), then the two plain passes."""
+    if shifted:
+        provider.set_option("chol_shift_ppb", 10_000)
+        try:
+            G = comm.sum_(provider.rows_gram(Y, Y))
+            Y = provider.rows_apply(Y, provider.chol_inverse(G, None))
+        finally:
+            provider.set_option("chol_shift_ppb", 0)
     for _ in range(2):
         G = comm.sum_(provider.rows_gram(Y, Y))
         Y = provider.rows_apply(Y, provider.chol_inverse(G, spd_flag))

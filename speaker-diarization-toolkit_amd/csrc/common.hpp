@@ -44,6 +44,8 @@ struct sdk_ctx {
   int hp_gemm_variant = 0;        // A/B + test knob: 1 = the precise mode's GEMM always as the 128^2 register-staged kernel
   int matvec_variant = 0;         // A/B + test knob: 1 = round 1's affinity_matvec_kernel (one 32-row block per wave, a barrier per tile)
   int aff_boundary_pen = 0;       // k = 1 coarse pass: cost of a group boundary inside a workgroup's range, in stages (affinity_rowcol.hip Geom.pen; 0 = equal unit counts)
+  int chol_pivot_rtol_ppb = 1000; // sdk_chol_inverse: a pivot <= this fraction (in 1e-9) of its diagonal entry sets the sticky not_spd flag (default 1e-6: cond(Y) > ~1e3)
+  int chol_shift_ppb = 0;         // sdk_chol_inverse: shifted CholeskyQR, G + s I with s = this fraction (in 1e-9) of the mean diagonal entry (0 = off)
   int aff_variant = 0;            // A/B knob: workgroup shape of the row/column kernel (see affinity_rowcol.hip)
   std::vector<const void*> lds_optin;   // kernels of THIS context's device already opted in to > 64 KiB dynamic LDS
   std::vector<sdk_prof_rec> prof;

@@ -449,21 +449,29 @@ __global__ __launch_bounds__(256) void kmeans_mindist_kernel(const float* __rest
 // k x k (k <= 32) Cholesky-QR step on the device: G = sum_ranks Y^T Y  ->  Rinv with Y Rinv orthonormal, i.e.
 // G_s = (G + G^T) / 2, G_s = L L^T, Rinv = (L^T)^-1, all in float64 by ONE lane (5 k flop at k = 16: the point is not speed but
 // that the subspace iteration never leaves the stream - the host-side form synchronised twice per CholeskyQR pass).
-__global__ __launch_bounds__(64) void chol_inverse_kernel(const float* __restrict__ G, int k, float* __restrict__ Rinv, int* __restrict__ bad) {
+__global__ __launch_bounds__(64) void chol_inverse_kernel(const float* __restrict__ G, int k, float* __restrict__ Rinv, int* __restrict__ bad,
+                                                          double pivot_rtol, double shift_rel) {
   __shared__ double L[KV][KV + 1];
   __shared__ double X[KV][KV + 1];
   if (threadIdx.x != 0) return;
   int fail = 0;
+  // shifted CholeskyQR ("chol_shift_ppb"): G + s I with s = shift_rel x the mean diagonal entry keeps a nearly rank-deficient block factorisable;
+  // the factor is then only approximately orthonormalising, which the following unshifted passes repair (cluster._orth runs three in that mode)
+  double shift = 0.0;
+  if (shift_rel > 0.0) {
+    for (int i = 0; i < k; ++i) shift += (double)G[i * k + i];
+    shift *= shift_rel / (double)k;
+  }
   for (int i = 0; i < k; ++i)
     for (int j = 0; j <= i; ++j) {
       double a = 0.5 * ((double)G[i * k + j] + (double)G[j * k + i]);
-      if (i == j) a += 1e-30;
+      if (i == j) a += 1e-30 + shift;
       for (int q = 0; q < j; ++q) a -= L[i][q] * L[j][q];
       if (i == j) {
         // a pivot at or below 1e-6 of its diagonal entry is rounding noise of the fp32 Gram matrix (cond(Y) > 1e3: the subspace
         // has lost rank) - flagged like a non-positive or NaN one; only an unusable pivot is replaced
-        const double dii = (double)G[i * k + i];
-        if (!(a > 1e-6 * dii)) fail = 1;
+        const double dii = (double)G[i * k + i] + shift;
+        if (!(a > pivot_rtol * dii)) fail = 1;
         if (!(a > 0.0)) a = 1.0;
         L[i][i] = sqrt(a);
       } else {
@@ -589,7 +597,8 @@ extern "C" int sdk_kmeans_mindist(sdk_ctx* ctx, const float* R, int n, int k, co
 
 extern "C" int sdk_chol_inverse(sdk_ctx* ctx, const float* G, int k, float* Rinv, int32_t* not_spd, void* stream) {
   SDK_REQUIRE(ctx && G && Rinv && k >= 1 && k <= KV && G != Rinv, "sdk_chol_inverse: bad arguments (k=%d, in-place not allowed)", k);
-  hipLaunchKernelGGL(chol_inverse_kernel, dim3(1), dim3(64), 0, (hipStream_t)stream, G, k, Rinv, not_spd);
+  hipLaunchKernelGGL(chol_inverse_kernel, dim3(1), dim3(64), 0, (hipStream_t)stream, G, k, Rinv, not_spd, (double)ctx->chol_pivot_rtol_ppb * 1e-9,
+                     (double)ctx->chol_shift_ppb * 1e-9);
   SDK_LAUNCH_CHECK();
   return 0;
 }

@@ -578,6 +578,25 @@ def test_spectral_cluster_raises_when_k_exceeds_the_rank(engine):
     assert np.array_equal(res.labels, np.repeat(np.arange(3), 200))
 
 
+def test_spectral_cluster_survives_over_clustering_on_tight_data(engine, monkeypatch):
+    """k just above the true number of speakers on low-noise embeddings puts lambda_k / lambda_1 near the relative-pivot rule of
+    sdk_chol_inverse (1e-6 of the diagonal: cond(Y) ~ 1e3), where plain CholeskyQR2 used to end the whole shard in LinAlgError after all
+    embeddings had been computed.  spectral_cluster now retries once with shifted CholeskyQR; exact duplicates (a true rank loss: the test
+    above) still raise.  Every cluster found must lie inside one true speaker (over-clustering splits speakers, it never mixes them)."""
+    shifted = []
+    real = engine.set_option
+    monkeypatch.setattr(engine, "set_option", lambda n, v: (shifted.append((n, v)), real(n, v))[1])
+    for noise, c, k in ((0.02, 4, 5), (0.005, 3, 5), (0.05, 6, 8)):
+        E, truth = ospec.vmf_mixture(1500, 192, c, seed=7 + c, noise=noise)
+        En, Eb, _ = engine.l2norm(dev(E))
+        res = CL.spectral_cluster(engine, En, Eb, 1500, k, n_iter=12, n_kmeans=10, seed=0)
+        assert np.isfinite(res.eigenvalues).all() and len(np.unique(res.labels)) <= k
+        for lab in np.unique(res.labels):
+            assert len(np.unique(truth[res.labels == lab])) == 1, (noise, c, k, lab)
+    print("\nshifted CholeskyQR retries:", sum(1 for n, v in shifted if n == "chol_shift_ppb" and v > 0))
+    assert all(v in (0, 10_000) for n, v in shifted if n == "chol_shift_ppb")
+
+
 @pytest.mark.parametrize("N,k", [(2000, 6), (5000, 16)])
 def test_laplacian_topk_c_driver_matches_the_host_driver(engine, N, k):
     """sdk_laplacian_topk (the k6 driver a non-Python host binds) runs cluster.spectral_cluster's subspace iteration in ONE C call
