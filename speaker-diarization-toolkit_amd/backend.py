@@ -22,6 +22,10 @@ Environment:
                       weights come from the on-disk cache; a missing entry is built once in a child process (through the torch engine)
   SDK_BIAS_CORRECTION 1 (default) / 0: fold the constant part of the bf16 weight-rounding error into the layer biases (one calibration pass at the
                       first load of a weight set, cached): scores within ~8e-4 of the fp32 model instead of ~4e-3, no run-time cost
+  SDK_CALIBRATION_WAV a 16 kHz mono s16 WAVE file whose two-second windows replace the built-in synthetic calibration audio of the bias correction
+                      (with a trained checkpoint, calibrate on speech); the corrected blob is cached per calibration file
+  SDK_PROFILE_PACK    1 (default) / 0: serve a candidate set from its packed profile matrix (embeddings/packs/, built at the first identify over
+                      the set: one file mapped, no per-embedding I/O); SDK_PROFILE_PACK_MIN (16): smallest set that is packed
   SDK_PRECISION       0 (default: bf16 operands) / 1 (precise mode: fp16 hi+lo planes, within 1e-5,
                       ~3.6x the step time).  Both modes embed into the SAME space (they differ from each other at the 4e-3 level), so
                       model_version does not depend on it
@@ -133,6 +137,12 @@ class Backend(EmbeddingBackend):
                 self._digest = weights_digest(self._host_weights())
         return self._digest
 
+    def numerics(self) -> Dict[str, Any]:
+        """The numerical setting embeddings are made under (stored beside every enrolled vector; identify warns when a candidate was made
+        under another one): model_version names the WEIGHTS - both settings embed into the same space, ~4e-3 apart."""
+        prec = int(os.environ.get("SDK_PRECISION", "0"))
+        return {"precision": prec, "bias_correction": bool(os.environ.get("SDK_BIAS_CORRECTION", "1") != "0") and prec == 0}
+
     @property
     def lite(self) -> bool:
         return os.environ.get("SDK_NO_TORCH") == "1"
@@ -155,10 +165,15 @@ class Backend(EmbeddingBackend):
             env = {k: v for k, v in os.environ.items() if k != "SDK_NO_TORCH"}
             env["PYTHONPATH"] = root + os.pathsep + env.get("PYTHONPATH", "")
             code = f"import importlib; b = importlib.import_module('{__package__}.backend').Backend(); b.engine().desc"
-            r = subprocess.run([sys.executable, "-c", code], env=env, capture_output=True, text=True)
-            if r.returncode != 0 or not eng.has_cached_weights():
+            try:                                  # bounded: a stuck child must not hang the CLI; the build takes ~2 s
+                r = subprocess.run([sys.executable, "-c", code], env=env, capture_output=True, text=True,
+                                   timeout=float(os.environ.get("SDK_CACHE_BUILD_TIMEOUT_S", "300")))
+                err = r.stderr.strip()[-400:] if r.returncode != 0 else ""
+            except subprocess.TimeoutExpired:
+                r, err = None, "the child process did not finish in time (SDK_CACHE_BUILD_TIMEOUT_S)"
+            if r is None or r.returncode != 0 or not eng.has_cached_weights():
                 raise RuntimeError("SDK_NO_TORCH=1: building the packed-weight cache entry in a child process failed "
-                                   f"(is the cache writable? SDK_CACHE_DIR / SDK_WEIGHTS_CACHE): {r.stderr.strip()[-400:]}")
+                                   f"(is the cache writable? SDK_CACHE_DIR / SDK_WEIGHTS_CACHE): {err}")
         eng.load_weights()
         self._cache_hit = eng.cache_hit
         return eng
@@ -316,7 +331,7 @@ class Backend(EmbeddingBackend):
         else:
             mean = E.double().mean(dim=0)
             vec = (mean / mean.norm().clamp_min(1e-12)).float().cpu().numpy()
-        ext = save_vector(vec)
+        ext = save_vector(vec, meta=self.numerics())
         return {
             "external_id": ext,                      # the only backend field cmd_enroll persists (speaker_detection:890-904)
             "file": str(vector_path(ext)),
@@ -358,9 +373,14 @@ class Backend(EmbeddingBackend):
         return idx.cpu().numpy(), sc.cpu().numpy()
 
     def identify_speaker(self, audio_path: Path, candidates: List[Dict[str, Any]], threshold: float = 0.354) -> List[Dict[str, Any]]:
-        batch = self.last_batch = load_profile_batch(candidates, self.name, model_prefix=f"{self.name}-", model_version=self.model_version)
+        batch = self.last_batch = load_profile_batch(candidates, self.name, model_prefix=f"{self.name}-", model_version=self.model_version,
+                                                     settings=self.numerics())
         for why in batch.skipped:
             print(f"mi355x backend: skipped embedding {why}", file=sys.stderr)
+        for why in batch.warnings[:5]:
+            print(f"mi355x backend: warning: {why}", file=sys.stderr)
+        if len(batch.warnings) > 5:
+            print(f"mi355x backend: warning: ... and {len(batch.warnings) - 5} more embeddings enrolled under another numerical setting", file=sys.stderr)
         if batch.all_skipped_message():
             # candidates exist but none is comparable: "no match" would be a lie.  The CLI prints "Error during identification: ..."
             # and exits 1 (speaker_detection:1072-1074); speaker-assign then records no embedding signal (speaker-assign:296)

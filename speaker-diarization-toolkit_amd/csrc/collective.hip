@@ -43,7 +43,8 @@ int rccl_resolve() {
     }
   }
   if (!g_rccl.all_gather || !g_rccl.all_reduce) {
-    sdk_set_error("RCCL not available: librccl.so.1 could not be loaded (%s); multi-GPU entry points need it", dlerror() ? dlerror() : "symbols missing");
+    const char* why = dlerror();          // (one call: dlerror() clears the message it returns)
+    sdk_set_error("RCCL not available: librccl.so.1 could not be loaded (%s); multi-GPU entry points need it", why ? why : "symbols missing");
     return 1;
   }
   return 0;

@@ -73,7 +73,7 @@ def make_rows_fn(audio_path: Path, tags: Optional[List[str]] = None, per_label: 
         return lambda label, segs: rows
 
     from .wav import decode_to_profile
-    batch = load_profile_batch(cands, be.name, model_prefix=f"{be.name}-", model_version=be.model_version)
+    batch = load_profile_batch(cands, be.name, model_prefix=f"{be.name}-", model_version=be.model_version, settings=be.numerics())
     for why in batch.skipped:
         print(f"mi355x backend: skipped embedding {why}", file=sys.stderr)
     if batch.all_skipped_message():           # loud, once: the in-process counterpart of the CLI's rc 1 (Backend.identify_speaker raises)

@@ -107,12 +107,14 @@ class LiteEngine:
         return self._tabs
 
     def cache_entry_name(self):
-        return "0c" if self.bias_correction else 0
+        from .weights_pack import calibration_tag
+        return ("0c" + calibration_tag()) if self.bias_correction else 0
 
     def has_cached_weights(self) -> bool:
+        """True only if the entry LOADS: meta present, blob present, size / offset table / SHA-256 good (weights_cache.load_blob) - a meta file whose
+        blob is missing, truncated or was rewritten for another precision is a miss, and the caller rebuilds the entry."""
         from . import weights_cache
-        return bool(self._cache_key) and weights_cache.load_meta(self._cache_key) is not None and \
-            str(self.cache_entry_name()) in weights_cache.load_meta(self._cache_key).get("fields", {})
+        return bool(self._cache_key) and weights_cache.load_blob(self._cache_key, self.cache_entry_name()) is not None
 
     def load_weights(self) -> None:
         """ECAPA-TDNN blob from the cache entry ops.Engine wrote (memory-mapped, validated, one upload)."""

@@ -101,7 +101,8 @@ class Engine:
         if self.precision not in self._packed:
             from . import weights_cache
             correct = self.bias_correction and self.precision == 0
-            ckey = "0c" if correct else self.precision            # a bias-corrected blob is its own cache entry
+            from .weights_pack import calibration_tag
+            ckey = ("0c" + calibration_tag()) if correct else self.precision            # a bias-corrected blob is its own cache entry (per calibration recording)
             hit = weights_cache.load_blob(self._cache_key, ckey) if self._cache_key else None
             need_store = False
             if hit is not None:

@@ -45,8 +45,10 @@ def vector_key(vec: np.ndarray) -> str:
     return hashlib.sha256(np.ascontiguousarray(vec, dtype="<f4").tobytes()).hexdigest()[:24]
 
 
-def save_vector(vec: np.ndarray, root: Optional[Path] = None) -> str:
-    """Write one embedding; returns its external_id ('npy:<key>')."""
+def save_vector(vec: np.ndarray, root: Optional[Path] = None, meta: Optional[Dict[str, Any]] = None) -> str:
+    """Write one embedding; returns its external_id ('npy:<key>').  meta (optional): the numerical setting it was made under (Backend: bias
+    correction on / off, precision), kept beside it as <key>.meta.json - model_version names the weights, not the setting, and vectors made under
+    another setting are COMPARABLE but differ at the ~4e-3 level, so identify warns instead of skipping them."""
     vec = np.ascontiguousarray(vec, dtype=np.float32).reshape(-1)
     if vec.shape[0] != EMBED_DIM:
         raise ValueError(f"embedding has {vec.shape[0]} dims, expected {EMBED_DIM}")
@@ -58,7 +60,22 @@ def save_vector(vec: np.ndarray, root: Optional[Path] = None) -> str:
         tmp = d / f".{key}.{os.getpid()}.tmp.npy"   # atomic publish: up to 4 CLI processes run at once
         np.save(tmp, vec)
         os.replace(tmp, path)
+    if meta:
+        mp = d / f"{key}.meta.json"
+        if not mp.exists():
+            import json
+            tmpm = d / f".{key}.{os.getpid()}.tmp.json"
+            tmpm.write_text(json.dumps(meta, sort_keys=True))
+            os.replace(tmpm, mp)
     return EXTERNAL_PREFIX + key
+
+
+def load_vector_meta(external_id: str, root: Optional[Path] = None) -> Optional[Dict[str, Any]]:
+    import json
+    try:
+        return json.loads(vector_path(external_id, root).with_suffix("").with_suffix(".meta.json").read_text())
+    except (OSError, ValueError):
+        return None
 
 
 def vector_path(external_id: str, root: Optional[Path] = None) -> Path:
@@ -110,6 +127,7 @@ class ProfileBatch:
     embedding_ids: List[Optional[str]] = field(default_factory=list)
     trust_levels: List[str] = field(default_factory=list)
     skipped: List[str] = field(default_factory=list)   # human-readable reasons
+    warnings: List[str] = field(default_factory=list)  # usable, but enrolled under another numerical setting (bias correction / precision)
     # packed store (see pack_*): `norm` = (E fp32 [P,192], Eb bf16 bits uint16 [P,192], resid fp32 [P]) exactly as sdk_l2norm produced them when
     # the pack was built (pack hit: memory-mapped, upload and score; None: normalise on the device); `pack_ref` = where to publish them after
     # the first normalisation of a batch that was loaded file by file (pack miss); `from_pack` says which of the two happened
@@ -146,11 +164,12 @@ def pack_min_rows() -> int:
     return max(1, int(os.environ.get("SDK_PROFILE_PACK_MIN", "16")))
 
 
-def candidate_digest(candidates: List[Dict[str, Any]], backend_name: str, model_prefix: Optional[str], model_version: Optional[str]) -> str:
+def candidate_digest(candidates: List[Dict[str, Any]], backend_name: str, model_prefix: Optional[str], model_version: Optional[str],
+                     settings: Optional[Dict[str, Any]] = None) -> str:
     """Identity of a candidate set as the loader sees it: every (speaker id, embedding id, external_id, model_version, trust level) of the
     backend's records, in order, plus the filter arguments.  The by-hash files are content-addressed (external_id = hash of the vector), so
     the keys alone pin the matrix: no stat() per embedding is needed to notice a change - a re-enrolment changes a key, a deletion removes one."""
-    h = hashlib.sha256(f"pack{PACK_FORMAT}|{backend_name}|{model_prefix}|{model_version}|{EMBED_DIM}\n".encode())
+    h = hashlib.sha256(f"pack{PACK_FORMAT}|{backend_name}|{model_prefix}|{model_version}|{EMBED_DIM}|{sorted((settings or {}).items())}\n".encode())
     for prof in candidates:
         sid = prof.get("id")
         for rec in prof.get("embeddings", {}).get(backend_name, []) or []:
@@ -165,11 +184,11 @@ def _pack_paths(root: Optional[Path], model_version: Optional[str], digest: str)
 
 
 def load_pack(candidates: List[Dict[str, Any]], backend_name: str, model_prefix: Optional[str] = None, root: Optional[Path] = None,
-              model_version: Optional[str] = None) -> Optional[ProfileBatch]:
+              model_version: Optional[str] = None, settings: Optional[Dict[str, Any]] = None) -> Optional[ProfileBatch]:
     """The packed matrix of exactly this candidate set, memory-mapped, or None (no pack, stale format, truncated file).  One JSON read +
     one mmap whatever P is."""
     import json
-    digest = candidate_digest(candidates, backend_name, model_prefix, model_version)
+    digest = candidate_digest(candidates, backend_name, model_prefix, model_version, settings)
     npy, side = _pack_paths(root, model_version, digest)
     try:
         t = json.loads(side.read_text())
@@ -192,7 +211,7 @@ def _pack_batch(blob: np.ndarray, P: int, t: dict) -> ProfileBatch:
     Eb = blob[2 * a:2 * a + P * EMBED_DIM * 2].view(np.uint16).reshape(P, EMBED_DIM)
     r = blob[2 * a + P * EMBED_DIM * 2:].view(np.float32)
     return ProfileBatch(mat, list(t["speaker_ids"]), list(t["embedding_ids"]), list(t["trust_levels"]), list(t.get("skipped", [])),
-                        norm=(E, Eb, r), from_pack=True)
+                        warnings=list(t.get("warnings", [])), norm=(E, Eb, r), from_pack=True)
 
 
 def publish_pack(batch: ProfileBatch, E: np.ndarray, Eb_bits: np.ndarray, resid: np.ndarray) -> Optional[Path]:
@@ -219,7 +238,8 @@ def publish_pack(batch: ProfileBatch, E: np.ndarray, Eb_bits: np.ndarray, resid:
         os.replace(tmp, npy)
         tmpj = npy.parent / f".{side.stem}.{os.getpid()}.tmp.json"
         tmpj.write_text(json.dumps({"format": PACK_FORMAT, "digest": digest, "dim": EMBED_DIM, "rows": P, "speaker_ids": batch.speaker_ids,
-                                    "embedding_ids": batch.embedding_ids, "trust_levels": batch.trust_levels, "skipped": batch.skipped}))
+                                    "embedding_ids": batch.embedding_ids, "trust_levels": batch.trust_levels, "skipped": batch.skipped,
+                                    "warnings": batch.warnings}))
         os.replace(tmpj, side)
         packs = sorted(npy.parent.glob("pack-*.json"), key=lambda q: q.stat().st_mtime, reverse=True)
         for old in packs[PACK_KEEP:]:                                      # bounded: one pack per (candidate set, model)
@@ -236,7 +256,7 @@ def publish_pack(batch: ProfileBatch, E: np.ndarray, Eb_bits: np.ndarray, resid:
 
 def load_profile_batch(candidates: List[Dict[str, Any]], backend_name: str, model_prefix: Optional[str] = None,
                        root: Optional[Path] = None, link: bool = True, model_version: Optional[str] = None,
-                       use_pack: Optional[bool] = None) -> ProfileBatch:
+                       use_pack: Optional[bool] = None, settings: Optional[Dict[str, Any]] = None) -> ProfileBatch:
     """Gather every usable embedding of every candidate into one matrix.
     use_pack (default: $SDK_PROFILE_PACK != 0): serve the set from its packed matrix when one exists (`from_pack`, `norm` set: ONE file mapped,
     no per-embedding I/O); otherwise load file by file and leave `pack_ref` set so the caller publishes the pack after the first device
@@ -248,10 +268,10 @@ def load_profile_batch(candidates: List[Dict[str, Any]], backend_name: str, mode
     different embedding space - its cosines against the current model's embeddings are noise, so it is skipped too."""
     use_pack = pack_enabled() if use_pack is None else use_pack
     if use_pack:
-        hit = load_pack(candidates, backend_name, model_prefix, root, model_version)
+        hit = load_pack(candidates, backend_name, model_prefix, root, model_version, settings)
         if hit is not None:
             return hit
-    rows, sids, eids, trusts, skipped = [], [], [], [], []
+    rows, sids, eids, trusts, skipped, warns = [], [], [], [], [], []
     for prof in candidates:
         sid = prof.get("id")
         for rec in prof.get("embeddings", {}).get(backend_name, []) or []:
@@ -270,13 +290,18 @@ def load_profile_batch(candidates: List[Dict[str, Any]], backend_name: str, mode
                 continue
             if link and sid and rec.get("id"):
                 adopt(ext, sid, rec["id"], root)
+            if settings:
+                made = load_vector_meta(ext, root)
+                if made and any(made.get(k) != v for k, v in settings.items() if k in made):
+                    warns.append(f"{tag}: enrolled with {made}, this process runs {settings} - comparable, but scores differ at the ~4e-3 level (re-enroll for "
+                                 "the tightest match)")
             rows.append(vec)
             sids.append(sid)
             eids.append(rec.get("id"))
             trusts.append(rec.get("trust_level", "unknown"))
     mat = np.stack(rows).astype(np.float32) if rows else np.zeros((0, EMBED_DIM), np.float32)
-    batch = ProfileBatch(mat, sids, eids, trusts, skipped)
+    batch = ProfileBatch(mat, sids, eids, trusts, skipped, warns)
     if use_pack and len(batch) >= pack_min_rows():
-        digest = candidate_digest(candidates, backend_name, model_prefix, model_version)
+        digest = candidate_digest(candidates, backend_name, model_prefix, model_version, settings)
         batch.pack_ref = _pack_paths(root, model_version, digest) + (digest,)
     return batch

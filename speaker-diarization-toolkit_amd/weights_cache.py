@@ -72,7 +72,7 @@ def load_blob(key: str, precision) -> Optional[Tuple[np.ndarray, dict]]:
     # the descriptor's offsets are dereferenced on the device: never trust an entry whose table points outside the blob, and never a blob
     # whose bytes are not the ones the table was written for (one SHA-256 pass over ~50 MB: 30 ms, against 2 s of generate + digest + pack)
     off = f.get("off")
-    if (not isinstance(off, list) or len(off) != 256 or f.get("precision") != int(str(precision).rstrip("c"))      # ("0c" = default mode, bias-corrected)
+    if (not isinstance(off, list) or len(off) != 256 or f.get("precision") != int(str(precision).split("c")[0])      # ("0c", "0c-<tag>" = default mode, bias-corrected)
             or any(not isinstance(o, int) or o < -1 or (o >= 0 and (o % 256 or o >= blob.size)) for o in off)):
         return None
     if hashlib.sha256(blob).hexdigest() != f.get("_sha256"):
@@ -89,11 +89,16 @@ def store(key: str, digest: str, precision: int, blob: np.ndarray, fields: dict)
         tmp = d / f".{key}.p{precision}.{os.getpid()}.tmp.npy"
         np.save(tmp, np.ascontiguousarray(blob, dtype=np.uint8))
         os.replace(tmp, d / f"{key}.p{precision}.npy")
-        m = load_meta(key) or {"format": FORMAT, "digest": digest, "fields": {}}
-        m["digest"] = digest
-        m["fields"][str(precision)] = dict(fields, _bytes=int(blob.size), _sha256=hashlib.sha256(np.ascontiguousarray(blob, dtype=np.uint8)).hexdigest())
-        tmpj = d / f".{key}.{os.getpid()}.tmp.json"
-        tmpj.write_text(json.dumps(m))
-        os.replace(tmpj, _meta_path(key))
+        # the meta file is shared by the entries of every precision: read-modify-write under an advisory lock, so two processes storing
+        # different entries (default / corrected / precise) at once cannot drop each other's fields
+        import fcntl
+        with open(d / f".{key}.lock", "a+") as lk:
+            fcntl.flock(lk, fcntl.LOCK_EX)
+            m = load_meta(key) or {"format": FORMAT, "digest": digest, "fields": {}}
+            m["digest"] = digest
+            m["fields"][str(precision)] = dict(fields, _bytes=int(blob.size), _sha256=hashlib.sha256(np.ascontiguousarray(blob, dtype=np.uint8)).hexdigest())
+            tmpj = d / f".{key}.{os.getpid()}.tmp.json"
+            tmpj.write_text(json.dumps(m))
+            os.replace(tmpj, _meta_path(key))
     except OSError:
         pass            # a read-only home directory must not break the backend: the cache is an optimisation

@@ -273,7 +273,34 @@ def bias_slot(name: str, cfg: EcapaConfig = DEFAULT_CONFIG) -> int:
     return b + res2net_slot(int(kind.split(".")[1])) + EL_B
 
 
+def calibration_tag() -> str:
+    """'' for the built-in calibration audio, '-<8 hex>' naming the file in $SDK_CALIBRATION_WAV (path, size, mtime): part of the corrected blob's
+    cache entry name, so another calibration recording is another entry."""
+    import hashlib
+    import os
+    path = os.environ.get("SDK_CALIBRATION_WAV")
+    if not path:
+        return ""
+    st = os.stat(path)
+    return "-" + hashlib.sha256(f"{os.path.abspath(path)}|{st.st_size}|{st.st_mtime_ns}".encode()).hexdigest()[:8]
+
+
 def calibration_pcm(n: int = 24, seed: int = 20240) -> np.ndarray:
+    """Calibration audio of the bias correction: [segments, 32000] int16.  $SDK_CALIBRATION_WAV (a 16 kHz mono s16 WAVE file, the backend's audio
+    contract): its two-second windows at a one-second hop, at most 64 - with a trained checkpoint, calibrate on SPEECH.
+    Otherwise the built-in deterministic set, see _builtin_calibration_pcm."""
+    import os
+    path = os.environ.get("SDK_CALIBRATION_WAV")
+    if path:
+        from .wav import cut_windows, read_wav_s16
+        pcm, _ = cut_windows(read_wav_s16(path), None)
+        if len(pcm) == 0:
+            raise ValueError(f"SDK_CALIBRATION_WAV={path}: shorter than 0.5 s")
+        return np.ascontiguousarray(pcm[:64])
+    return _builtin_calibration_pcm(n, seed)
+
+
+def _builtin_calibration_pcm(n: int = 24, seed: int = 20240) -> np.ndarray:
     """Built-in calibration audio (deterministic): n two-second segments, half of them noise at several levels plus two tones, half of them
     harmonic stacks with a pitch, a spectral tilt and a slow amplitude modulation ("voices").  Only the per-channel MEANS of the layer inputs
     are taken from it; measured on noise, voices, quiet / clipped noise, 0.5-s and 5-s windows the correction always helps (2.3-5.7x,

@@ -165,3 +165,38 @@ def test_corrected_budget_holds_on_other_input_kinds(corrected, engine):
         assert dev["corrected"] < bounds[kind], (kind, dev)
         assert dev["corrected"] < dev["plain"], (kind, dev)
     print("\nbias correction on other input kinds (max |dscore| vs the fp32 model):", json.dumps(rep))
+
+
+def test_calibration_on_caller_supplied_audio(tmp_path, monkeypatch, engine):
+    """SDK_CALIBRATION_WAV: the calibration pass runs on the caller's recording (with a trained checkpoint: speech) instead of
+    the built-in synthetic set; the engine is then the bf16 model of THOSE effective weights, the correction still helps, and the cache entry is
+    named after the calibration file."""
+    sys.path.insert(0, str(ROOT))
+    bench = importlib.import_module("bench")
+    wav = sub("wav")
+    WC = sub("weights_cache")
+    rec = np.concatenate(list(_input_kinds(6)["harmonic_voices"]))                       # 12 s of "voices"
+    wav.write_wav_s16(tmp_path / "cal.wav", rec)
+    monkeypatch.setenv("SDK_CALIBRATION_WAV", str(tmp_path / "cal.wav"))
+    monkeypatch.setenv("SDK_CACHE_DIR", str(tmp_path / "cache"))
+    assert WP.calibration_pcm().shape == (11, 32000) and WP.calibration_tag().startswith("-")
+    w = W.synthetic_weights(0)
+    key = WC.key_for_seed(0, W.DEFAULT_CONFIG)
+    eng = OPS.Engine(0, cache_key=key, weights_fn=lambda: w, digest_fn=lambda: "d", bias_correction=True)
+    eff = eng.effective_weights()
+    assert WC.load_blob(key, "0c" + WP.calibration_tag()) is not None and WC.load_blob(key, "0c") is None
+    monkeypatch.delenv("SDK_CALIBRATION_WAV")
+    builtin = OPS.Engine(0, bias_correction=True).effective_weights()
+    assert any(not np.array_equal(eff[k], builtin[k]) for k in eff)                        # other audio, other means, other biases
+    pcm = bench.synth_pcm(16, seed=3)
+    P = bench.unit_rows(100, 192, seed=1).astype(np.float64)
+    feats = torch.from_numpy(ofbank.fbank(pcm))
+    E = eng.embed_pcm(torch.from_numpy(pcm).cuda())[0].cpu()
+    want = torch.from_numpy(oecapa.l2_normalise(oecapa.EcapaOracle(eff, "bf16", torch.float64).embed(feats).numpy()))
+    assert float(((E.double() * want.double()).sum(1)).min()) > 1 - 2e-5
+    E32 = oecapa.l2_normalise(oecapa.EcapaOracle(w, "fp32", torch.float32).embed(feats).numpy()).astype(np.float64)
+    Ep = engine.embed_pcm(torch.from_numpy(pcm).cuda())[0].cpu().numpy().astype(np.float64)
+    d_corr = float(np.abs(E.numpy().astype(np.float64) @ P.T - E32 @ P.T).max())
+    d_plain = float(np.abs(Ep @ P.T - E32 @ P.T).max())
+    print("\ncalibrated on a caller-supplied recording: plain", d_plain, "corrected", d_corr)
+    assert d_corr < 0.6 * d_plain

@@ -463,3 +463,31 @@ def test_window_start_tables_reproduce_the_host_cut_windows():
     assert wins == wins2 and dropped == dropped2 == [3] and set(tabs) == set(pcm_by_len)
     for S, st in tabs.items():
         assert np.array_equal(wav.materialise_windows(x, st, S), pcm_by_len[S]) and (st + S <= len(x)).all()
+
+
+def test_vectors_remember_their_numerical_setting(tmp_path, monkeypatch):
+    """model_version names the weights, not SDK_BIAS_CORRECTION / SDK_PRECISION; a vector enrolled under another setting is
+    comparable (same space, ~4e-3 apart) - it is kept and WARNED about, never silently mixed; the pack is per setting."""
+    monkeypatch.setenv("SPEAKERS_EMBEDDINGS_DIR", str(tmp_path))
+    rng = np.random.default_rng(2)
+    made = {"precision": 0, "bias_correction": True}
+    cands = []
+    for i in range(20):
+        v = rng.standard_normal(192).astype(np.float32)
+        ext = store.save_vector(v, meta=made if i % 2 == 0 else None)          # odd ones: enrolled before the sidecar existed - no claim, no warning
+        cands.append(_profile(f"s{i}", [{"id": f"e{i}", "external_id": ext, "model_version": "mi355x-ecapa1024-x"}]))
+    assert store.load_vector_meta(cands[0]["embeddings"]["mi355x"][0]["external_id"]) == made
+    assert store.load_vector_meta(cands[1]["embeddings"]["mi355x"][0]["external_id"]) is None
+    kw = dict(model_prefix="mi355x-", model_version="mi355x-ecapa1024-x")
+    same = store.load_profile_batch(cands, "mi355x", settings=made, **kw)
+    assert len(same) == 20 and same.warnings == []
+    other = store.load_profile_batch(cands, "mi355x", settings={"precision": 0, "bias_correction": False}, **kw)
+    assert len(other) == 20 and len(other.warnings) == 10 and "bias_correction" in other.warnings[0]
+    assert other.pack_ref[2] != same.pack_ref[2]                                # another setting, another pack
+    store.publish_pack(other, *_fake_norm(other.matrix))
+    again = store.load_profile_batch(cands, "mi355x", settings={"precision": 0, "bias_correction": False}, **kw)
+    assert again.from_pack and again.warnings == other.warnings                  # the warnings travel with the pack
+    assert not store.load_profile_batch(cands, "mi355x", settings=made, **kw).from_pack
+    be = backend.Backend()
+    monkeypatch.setenv("SDK_PRECISION", "1")
+    assert be.numerics() == {"precision": 1, "bias_correction": False}
