@@ -560,7 +560,16 @@ def main() -> int:
         # ---- affinity pairs/sec at config #3 (100k segments x 1k profiles) and at config #4's per-GPU shape (125k x 10k), HIP events
         aff = None
         if not args.no_affinity_config3:
-            def affinity_leg(N3, P3, label):
+            def aff_traffic(tag):
+                """bytes leaving L2 per launch of aff_rowcol_kernel from the committed rocprofv3 --pmc pass at this shape (tools/pmc_any.sh tools/one_aff.py)"""
+                files = sorted((ROOT / "profiles").glob(f"*pmc_aff_{tag}.json"))
+                try:
+                    pm = json.loads(files[-1].read_text())["aff_rowcol_kernel"]
+                    return round((2.0 * pm["FETCH_SIZE"] + pm["WRITE_SIZE"]) * 1024.0, 1), f"profiles/{files[-1].name}"
+                except Exception:  # noqa: BLE001
+                    return None, None
+
+            def affinity_leg(N3, P3, label, tag=None):
                 E3, E3b, r3 = eng.l2norm(torch.randn(N3, 192, device=dev, generator=torch.Generator(device=dev).manual_seed(3)))
                 Q3, Q3b, q3 = eng.l2norm(torch.randn(P3, 192, device=dev, generator=torch.Generator(device=dev).manual_seed(4)))
                 q3m = q3.max().reshape(1)
@@ -579,9 +588,11 @@ def main() -> int:
                         "total_over_coarse": round(total_ms / coarse_ms, 3), "rows_rescanned": int(cnt.item()),
                         "roofline": {"kernel": "aff_rowcol_kernel", "bound": "mfma", "achieved": round(fl / (coarse_ms * 1e-3) / 1e12, 2),
                                      "peak": PEAK_BF16_MFMA / 1e12, "unit": "TFLOP/s", "frac": round(fl / (coarse_ms * 1e-3) / PEAK_BF16_MFMA, 4),
-                                     "traffic": None}}
-            aff = affinity_leg(100_000, 1000, "config #3: 100k segments x 1k profiles, row/column-maxima coarse pass + exact fp32 re-score (argmax)")
-            aff["config4_shard_shape"] = affinity_leg(125_000, 10_000, "config #4, one GPU's shard: 125k segments x 10k replicated profiles")
+                                     "traffic": aff_traffic(tag)[0] if tag else None, "traffic_source": aff_traffic(tag)[1] if tag else None,
+                                     "algorithmic_bytes_per_launch": 2.0 * (N3 + P3) * 192 + 64.0 * N3,
+                                     "traffic_note": "bytes leaving L2 per launch (FETCH_SIZE x2 + WRITE_SIZE), separate --pmc pass"}}
+            aff = affinity_leg(100_000, 1000, "config #3: 100k segments x 1k profiles, row/column-maxima coarse pass + exact fp32 re-score (argmax)", "cfg3")
+            aff["config4_shard_shape"] = affinity_leg(125_000, 10_000, "config #4, one GPU's shard: 125k segments x 10k replicated profiles", "cfg4shape")
 
         # ---- config #5 kernel: rectified-affinity mat-vec A X (A = max(E E^T, 0) recomputed on MFMA), 100k x 100k
         clus = None

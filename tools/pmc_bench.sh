@@ -2,7 +2,9 @@
 # HBM-side traffic of the bench step per kernel: separate --pmc passes (FETCH_SIZE and WRITE_SIZE do not fit one pass)
 cd "${GRAFT_REPO_ROOT:-/root/repo}"; mkdir -p gpurun_out/pmcb; export TMPDIR=/tmp
 for c in FETCH_SIZE WRITE_SIZE; do
-  SDK_BENCH_PMC=1 timeout -k 10 400 rocprofv3 --kernel-trace --pmc $c --output-format csv -d gpurun_out/pmcb/$c -o b -- python3 bench.py --steps 1 --warmup 1 --no-cpu-baseline --no-affinity-config3 > gpurun_out/pmcb/$c.log 2>&1 || { tail -5 gpurun_out/pmcb/$c.log; exit 1; }
+  # SDK_BIAS_CORRECTION=0: without it the first weight load runs a calibration forward (24 segments) whose launches would be counted as half a pass;
+  # the hot path's kernels and bytes are the same either way (only bias VALUES differ)
+  SDK_BIAS_CORRECTION=0 SDK_BENCH_PMC=1 timeout -k 10 400 rocprofv3 --kernel-trace --pmc $c --output-format csv -d gpurun_out/pmcb/$c -o b -- python3 bench.py --steps 1 --warmup 1 --no-cpu-baseline --no-affinity-config3 > gpurun_out/pmcb/$c.log 2>&1 || { tail -5 gpurun_out/pmcb/$c.log; exit 1; }
 done
 python3 - <<'PY'
 import csv, glob, json, collections
