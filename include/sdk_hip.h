@@ -33,7 +33,7 @@
  *     sdk_rows_apply  sdk_chol_inverse  sdk_rows_unit  sdk_kmeans_mindist  sdk_kmeans_assign            k6 (driven by cluster.py)
  * BUILDING BLOCKS AND KNOBS - exported for the parity tests and the A/B tools, free to change between rounds, not for binding:
  *     sdk_conv_gemm*  sdk_colstats_finish  sdk_res2net_chain*  sdk_se_*  sdk_asp_*  sdk_rows_fc  (pieces of sdk_ecapa_forward)
- *     sdk_set_option  sdk_set_gemm_variant  sdk_profile_begin / _end  sdk_debug_set_ptr  sdk_affinity_plan  sdk_affinity_matvec_plan  sdk_conv_gemm_hp
+ *     sdk_set_option  sdk_set_gemm_variant  sdk_profile_begin / _end  sdk_debug_set_ptr  sdk_affinity_plan*  sdk_affinity_block_plan*  sdk_affinity_matvec_plan  sdk_conv_gemm_hp
  *     sdk_allgather  sdk_laplacian_topk_workspace_bytes  sdk_laplacian_topk        k5 / k6 drivers for a non-Python host (the library holds no
  *                                                                                     communicator: the caller passes its ncclComm_t; the Python
  *                                                                                     host layer uses torch.distributed, dist.py / cluster.py)
@@ -342,6 +342,13 @@ int sdk_affinity_plan(int N, int P, int num_cu, int32_t* out5, int64_t* units);
 /* Host-only: the unit range [u0, u1) of workgroup `wg` under that plan and the record slot of its first portion.  The ranges can be balanced by
  * cost instead of unit count ("affinity_boundary_penalty" p: a group boundary inside a range counts as p stages; default 0 - measured, not a robust win). */
 int sdk_affinity_plan_range(int N, int P, int num_cu, int wg, int64_t* u0, int64_t* u1, int32_t* first_slot);
+/* Host-only (round 4): the BLOCK plan the coarse pass takes for short sweeps (config #3), for tests.  Unit of work = a block of 32 segments with its whole
+ * sweep; workgroup g owns blocks [g q, (g + 1) q), the leftover blocks are swept in `parts` stage ranges by waves with a free second slot.
+ * sdk_affinity_block_plan: out6 = {1 = plan taken / 0 = the range plan stays (force != 0: taken whenever the shape fits), q, workgroups, stages per
+ * sweep, parts per leftover block, leftover items}.  sdk_affinity_block_plan_wave: wave `wave` (0..7) of workgroup `wg`: out6 = {block of slot 0, block of
+ * slot 1 or -1, its first stage, its end stage, its record slot, parts of that block}. */
+int sdk_affinity_block_plan(int N, int P, int num_cu, int force, int32_t* out6);
+int sdk_affinity_block_plan_wave(int N, int P, int num_cu, int wg, int wave, int32_t* out6);
 int sdk_affinity_topk(sdk_ctx* ctx, const float* E, const uint16_t* Eb, const float* resid_e,
                       const float* P, const uint16_t* Pb, const float* resid_p,
                       int N, int Pn, int d, int k, int32_t* idx, float* score,

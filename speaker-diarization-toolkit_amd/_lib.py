@@ -121,6 +121,8 @@ SIGNATURES = {
     "sdk_affinity_workspace_bytes": (_sz, [_i, _i]),
     "sdk_affinity_plan": (_i, [_i, _i, _i, _vp, _vp]),
     "sdk_affinity_plan_range": (_i, [_i, _i, _i, _i, _vp, _vp, _vp]),
+    "sdk_affinity_block_plan": (_i, [_i, _i, _i, _i, _vp]),
+    "sdk_affinity_block_plan_wave": (_i, [_i, _i, _i, _i, _i, _vp]),
     "sdk_affinity_matvec_workspace_bytes": (_sz, [_i]),
     "sdk_affinity_matvec_plan": (_i, [_i, _i, _i, _vp, _vp]),
     "sdk_affinity_matvec": (_i, [_vp, _vp, _i, _i, _i, _i, _vp, _vp, _i, _vp, _vp, _sz, _vp]),

@@ -379,6 +379,240 @@ __global__ __launch_bounds__(WAVES * 64, 2) void aff_rowcol_kernel(const bf16_t*
   }
 }
 
+
+// ---- round 4: the BLOCK plan (short sweeps, e.g. config #3: 100 000 x 1 000) ------------------------------------------------------------------
+// What the range plan above loses at config #3 (profiles/r03_aff_timeline_config3.txt): a portion's 192 KB of segment fragments
+// arrive at ~35-40 GB/s per CU (the Infinity-Cache rate) = 4.8 us at kernel start and ~6 us at every group boundary, three workgroups in four
+// cross a boundary (16 stages per group, 12.25 per workgroup), and the fragments of a split group are fetched by every workgroup that takes part
+// in its sweep (105 MB through the fabric against 45 MB).  Here NO workgroup changes its segments: the unit of work is a BLOCK of 32 segments
+// with its whole sweep, blocks are dealt to (workgroup, wave, slot) - every workgroup sweeps all stages exactly once, in step with all others -
+// and the blocks that do not divide evenly are swept in PARTS (thirds / halves of the stage range) by waves with a free second slot:
+//   main    workgroup g owns blocks [g q, (g + 1) q), q a multiple of 4 (8 or 12): slot j -> wave j % 8, sub-slot j / 8: every SIMD carries q / 4
+//           blocks (at q = 12: waves 0-3 two blocks, waves 4-7 one), so a stage costs q / 16 of a full workgroup's
+//   extra   leftover block i, part p = item t = i PARTS + p -> workgroup t % G, its (t / G)-th free slot, active for stages [e0, e1) only
+// Records are per BLOCK (segs = 32 for the exact pass): a main block has one part (slot 0, base tile 0), a leftover block PARTS parts (<= MAXP).
+// The host picks this plan when its estimated cost (block-stages on the busiest SIMD) is under the range plan's (plan_blocks).
+struct BlockPlan {
+  int q, G, nst, parts, items;      // main blocks per workgroup, workgroups, stages per sweep, parts per leftover block, leftover items
+  int prio;
+};
+
+// the blocks of wave `wid` of workgroup `g` (host and device share this; tests/test_cabi_cpu.py replays it through sdk_affinity_block_plan_wave)
+__host__ __device__ inline void block_slots(const BlockPlan& pl, int g, int wid, int& blk0, int& blk1, int& e0, int& e1, int& slot1, int& cnt1) {
+  blk0 = g * pl.q + wid;
+  blk1 = -1; e0 = 0; e1 = 0; slot1 = 0; cnt1 = 1;
+  const int j1 = 8 + wid;
+  if (j1 < pl.q) {
+    blk1 = g * pl.q + j1; e0 = 0; e1 = pl.nst;
+  } else {
+    const long long t = (long long)(j1 - pl.q) * pl.G + g;
+    if (t < pl.items) {
+      const int i = (int)(t / pl.parts), pp = (int)(t - (long long)i * pl.parts);
+      blk1 = pl.q * pl.G + i;
+      e0 = (int)((long long)pp * pl.nst / pl.parts);
+      e1 = (int)((long long)(pp + 1) * pl.nst / pl.parts);
+      slot1 = pp; cnt1 = pl.parts;
+    }
+  }
+}
+
+template <int WAVES, int TPS, int NSTAGE>
+__global__ __launch_bounds__(WAVES * 64, 2) void aff_rowcol_blocks_kernel(const bf16_t* __restrict__ Eb, const bf16_t* __restrict__ Pb,
+                                                                      int N, int P, BlockPlan pl, float* __restrict__ stats,
+                                                                      int32_t* __restrict__ part_base, int32_t* __restrict__ part_cnt,
+                                                                      int32_t* __restrict__ flag_count, unsigned long long* __restrict__ dbg) {
+  int nstamp = 2;
+  auto stamp = [&]() {
+    if (dbg && threadIdx.x == 0 && nstamp < 62) dbg[blockIdx.x * 64 + nstamp++] = __builtin_amdgcn_s_memrealtime();
+  };
+  if (dbg && threadIdx.x == 0) dbg[blockIdx.x * 64] = __builtin_amdgcn_s_memrealtime();
+  if (blockIdx.x == 0 && threadIdx.x == 0) *flag_count = 0;
+  const unsigned long long clk0 = dbg ? __builtin_amdgcn_s_memtime() : 0;
+  constexpr int STAGE_BYTES = TPS * TILE_BYTES;
+  constexpr int DMA_PER_STAGE = STAGE_BYTES / 1024;
+  static_assert(DMA_PER_STAGE % WAVES == 0 && WAVES == 8, "stage must split evenly over the 8 waves");
+  constexpr int DPW = DMA_PER_STAGE / WAVES;
+  extern __shared__ __attribute__((aligned(16))) char sP[];
+  const int tid = threadIdx.x, lane = tid & 63, wid = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int col = lane & 31, h = lane >> 5;
+  const int nst = pl.nst;
+  const int ntiles = (P + PT - 1) / PT;
+  const int g = blockIdx.x;
+
+  // this wave's blocks: slot 0 is always a main block (q >= 8); slot 1 a main block, a leftover item, or nothing
+  int blk0, blk1, e0, e1, slot1, cnt1;
+  block_slots(pl, g, wid, blk0, blk1, e0, e1, slot1, cnt1);
+  const bool has1 = blk1 >= 0;
+
+  int drow[DPW], dsrc[DPW];
+#pragma unroll
+  for (int i = 0; i < DPW; ++i) {
+    const int id = (wid * DPW + i) * 64 + lane;
+    drow[i] = id / 24;
+    const int pos = id - drow[i] * 24;
+    dsrc[i] = ((pos & ~7) | ((pos & 7) ^ ((drow[i] >> 1) & 7))) * 8;
+  }
+  int s_issue = 0, k_issue = 0;
+  auto issue = [&]() {
+    char* st = sP + (k_issue % NSTAGE) * STAGE_BYTES;
+#pragma unroll
+    for (int i = 0; i < DPW; ++i) {
+      int pr = s_issue * (TPS * PT) + drow[i];
+      pr = pr < P ? pr : P - 1;
+      __builtin_amdgcn_global_load_lds((const void __attribute__((address_space(1)))*)(Pb + (int64_t)pr * D + dsrc[i]),
+                                       (void __attribute__((address_space(3)))*)(st + (wid * DPW + i) * 1024), 16, 0, 0);
+    }
+    ++k_issue;
+    ++s_issue;
+  };
+
+  bf16x8 bfrag[2][KS];
+  float C[2][16], tl[2][4];
+#pragma unroll
+  for (int sb = 0; sb < 2; ++sb) {
+    const int blk = sb == 0 ? blk0 : (has1 ? blk1 : blk0);        // (no second block: a valid address, never used)
+    const int seg = blk * 32 + col;
+    const int seg_c = seg < N ? seg : N - 1;
+#pragma unroll
+    for (int ks = 0; ks < KS; ++ks) bfrag[sb][ks] = *reinterpret_cast<const bf16x8*>(Eb + (int64_t)seg_c * D + ks * 16 + h * 8);
+#pragma unroll
+    for (int r = 0; r < 16; ++r) C[sb][r] = EMPTY;
+#pragma unroll
+    for (int q = 0; q < 4; ++q) tl[sb][q] = EMPTY;
+  }
+  if (lane == 0) {
+    part_base[blk0 * MAXP] = 0;
+    part_cnt[blk0] = 1;
+    if (has1) {
+      part_base[blk1 * MAXP + slot1] = e0 * TPS;
+      part_cnt[blk1] = cnt1;                                       // (every part of a leftover block writes the same count)
+    }
+  }
+  if (pl.prio == 1) { if (wid >= WAVES / 2) __builtin_amdgcn_s_setprio(2); }
+  constexpr int AHEAD = NSTAGE - 1;
+#pragma unroll
+  for (int a = 0; a < AHEAD; ++a)
+    if (a < nst) issue();
+  const int rsw = (col >> 1) & 7;
+  int aoff[4];
+#pragma unroll
+  for (int q = 0; q < 4; ++q) aoff[q] = col * PROWB + (((2 * q + h) ^ rsw) << 4);
+  auto reduce1 = [&](const f32x16& a, int sb, int tag) {
+    const float m0 = max3(a[0], a[1], a[2]), m1 = max3(a[3], a[4], a[5]), m2 = max3(a[6], a[7], a[8]);
+    const float m3 = max3(a[9], a[10], a[11]), m4 = max3(a[12], a[13], a[14]);
+    const float T = fmaxf(max3(m0, m1, m2), max3(m3, m4, a[15]));
+#pragma unroll
+    for (int r = 0; r < 16; ++r) C[sb][r] = fmaxf(C[sb][r], a[r]);
+    insert_sorted<4>(__uint_as_float((__float_as_uint(T) & ~TMASK) | (uint32_t)tag), tl[sb]);
+  };
+  auto mask1 = [&](int tile, f32x16& acc) {
+    if ((tile + 1) * PT > P) {
+#pragma unroll
+      for (int r = 0; r < 16; ++r)
+        if (tile * PT + (r & 3) + 8 * (r >> 2) + 4 * h >= P) acc[r] = MASKED;
+    }
+  };
+  stamp();
+  const char* sq[4];
+  for (int s = 0; s < nst; ++s) {
+    const int after = nst - 1 - s < AHEAD - 1 ? nst - 1 - s : AHEAD - 1;
+    if (after >= 2) {
+      if constexpr (DPW == 3) asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
+      else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    } else if (after == 1) {
+      if constexpr (DPW == 3) asm volatile("s_waitcnt vmcnt(3)" ::: "memory");
+      else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    } else {
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    }
+    __builtin_amdgcn_s_barrier();
+    stamp();
+    if (s + AHEAD < nst) issue();
+#pragma unroll
+    for (int q = 0; q < 4; ++q) sq[q] = sP + (s % NSTAGE) * STAGE_BYTES + aoff[q];
+    const bool two = has1 && s >= e0 && s < e1;                   // wave-uniform
+#pragma unroll
+    for (int tt = 0; tt < TPS; ++tt) {
+      const int tile = s * TPS + tt;
+      if (tile < ntiles) {
+        if (two) {
+          f32x16 a0, a1;
+#pragma unroll
+          for (int r = 0; r < 16; ++r) { a0[r] = 0.f; a1[r] = 0.f; }
+#pragma unroll
+          for (int ks = 0; ks < KS; ++ks) {
+            const bf16x8 a = *reinterpret_cast<const bf16x8*>(sq[ks & 3] + tt * TILE_BYTES + (ks >> 2) * 128);
+            a0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, bfrag[0][ks], a0, 0, 0, 0);
+            a1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, bfrag[1][ks], a1, 0, 0, 0);
+          }
+          mask1(tile, a0);
+          mask1(tile, a1);
+          reduce1(a0, 0, tile);
+          reduce1(a1, 1, tile - e0 * TPS);
+        } else {
+          f32x16 a0;
+#pragma unroll
+          for (int r = 0; r < 16; ++r) a0[r] = 0.f;
+#pragma unroll
+          for (int ks = 0; ks < KS; ++ks) {
+            const bf16x8 a = *reinterpret_cast<const bf16x8*>(sq[ks & 3] + tt * TILE_BYTES + (ks >> 2) * 128);
+            a0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, bfrag[0][ks], a0, 0, 0, 0);
+          }
+          mask1(tile, a0);
+          reduce1(a0, 0, tile);
+        }
+      }
+    }
+  }
+  stamp();
+#pragma unroll
+  for (int sb = 0; sb < 2; ++sb) {
+    if (sb == 1 && !has1) break;
+    float cl[4] = {EMPTY, EMPTY, EMPTY, EMPTY};
+#pragma unroll
+    for (int r = 0; r < 16; ++r) insert_sorted<4>(__uint_as_float((__float_as_uint(C[sb][r]) & ~CMASK) | (uint32_t)r), cl);
+    const int seg = (sb == 0 ? blk0 : blk1) * 32 + col;
+    const int slot = sb == 0 ? 0 : slot1;
+    if (seg < N) {
+      float* dst = stats + (((int64_t)seg * MAXP + slot) * 2 + h) * 8;
+      f32x4 tv, cv;
+#pragma unroll
+      for (int q = 0; q < 4; ++q) { tv[q] = tl[sb][q]; cv[q] = cl[q]; }
+      *reinterpret_cast<f32x4*>(dst) = tv;
+      *reinterpret_cast<f32x4*>(dst + 4) = cv;
+    }
+  }
+  stamp();
+  if (dbg && threadIdx.x == 0) {
+    dbg[blockIdx.x * 64 + 1] = nstamp;
+    dbg[blockIdx.x * 64 + 63] = __builtin_amdgcn_s_memtime() - clk0;
+  }
+}
+
+// Host side of the block plan.  Returns false when the shape does not fit it (too few / too many blocks per workgroup, no free slots for the
+// leftover items) or when the range plan is estimated cheaper (long sweeps: config #4's shape - the range plan balances to the stage, the block
+// plan only to the block).  Costs in block-stages on the busiest SIMD; the range plan pays ~3.5 stages of fragment reload / refill per workgroup.
+bool plan_blocks(int N, int P, int tps, int num_cu, BlockPlan* out, bool force) {
+  const int NB = ceil_div(N, 32), G = num_cu;
+  const int nst = ceil_div(ceil_div(P, PT), tps);
+  if (G <= 0 || NB < 8 * G || nst < 3) return false;
+  int q = NB / G;
+  q = q >= 12 ? 12 : 8;
+  const long long r = (long long)NB - (long long)q * G, free_slots = (long long)(16 - q) * G;
+  int parts = 0;
+  for (int pp = 3; pp >= 1; --pp)
+    if (pp <= MAXP && r * pp <= free_slots) { parts = pp; break; }
+  if (r > 0 && parts == 0) return false;
+  if (r == 0) parts = 1;
+  const long long items = r * parts;
+  out->q = q; out->G = G; out->nst = nst; out->parts = parts; out->items = (int)items; out->prio = 0;
+  const long long per_wg = (items + G - 1) / G;                                   // leftover items in the fullest workgroup
+  const double cost_blocks = (double)nst * (q / 4) + (double)((per_wg + 3) / 4) * ceil_div(nst, parts);
+  const int ngroups = ceil_div(N, 512);
+  const double cost_ranges = ((double)ngroups * nst / (double)(G < 2 * ngroups ? G : 2 * ngroups) + 3.5) * 4.0;
+  return force || cost_blocks < cost_ranges;
+}
+
 // ---- exact pass ------------------------------------------------------------------------------------------------------
 // 8 lanes per segment row.  Lane j looks after half (j >> 2) of every part and, of that half's 3 x 3 intersections
 // (i, j) = (c / 3, c % 3), the combinations c = (j & 3), (j & 3) + 4, (j & 3) + 8.  The live ones are gathered into one
@@ -711,7 +945,7 @@ inline size_t al256(size_t v) { return (v + 255) & ~(size_t)255; }
 size_t ws_layout(int N, int P, char* base, Ws* w) {
   size_t off = 0;
   auto take = [&](size_t bytes) { char* p = base ? base + off : nullptr; off += al256(bytes); return p; };
-  const size_t ngroups_max = (size_t)(N + 255) / 256;          // the smallest group any variant uses
+  const size_t ngroups_max = (size_t)(N + 31) / 32;            // the smallest group any variant uses (the block plan: 32 segments)
   char* a = take((size_t)N * MAXP * 2 * 8 * 4);
   char* b = take(ngroups_max * MAXP * 4);
   char* c = take(ngroups_max * 4);
@@ -791,6 +1025,25 @@ extern "C" int sdk_affinity_plan_range(int N, int P, int num_cu, int wg, int64_t
   *first_slot = a < b ? (int32_t)(wg - geom_first_wg(gm, a / gm.nst)) : -1;
   return 0;
 }
+// Host-only: the block plan of a shape (tests).  out6 = {1 if the plan is taken / 0 if the range plan stays, q, workgroups, stages, parts per leftover block, items}
+extern "C" int sdk_affinity_block_plan(int N, int P, int num_cu, int force, int32_t* out6) {
+  SDK_REQUIRE(N > 0 && P > 0 && num_cu > 0 && out6, "sdk_affinity_block_plan: bad argument");
+  BlockPlan bp = {0, 0, 0, 0, 0, 0};
+  const bool ok = plan_blocks(N, P, 2, num_cu, &bp, force != 0);
+  out6[0] = ok ? 1 : 0; out6[1] = bp.q; out6[2] = bp.G; out6[3] = bp.nst; out6[4] = bp.parts; out6[5] = bp.items;
+  return 0;
+}
+// Host-only: the blocks of wave `wave` (0..7) of workgroup `wg` under that plan: out7 = {block of slot 0, block of slot 1 or -1, first stage, end stage,
+// record slot, parts of that block}
+extern "C" int sdk_affinity_block_plan_wave(int N, int P, int num_cu, int wg, int wave, int32_t* out6) {
+  SDK_REQUIRE(N > 0 && P > 0 && num_cu > 0 && out6 && wave >= 0 && wave < 8, "sdk_affinity_block_plan_wave: bad argument");
+  BlockPlan bp = {0, 0, 0, 0, 0, 0};
+  SDK_REQUIRE(plan_blocks(N, P, 2, num_cu, &bp, true) && wg >= 0 && wg < bp.G, "sdk_affinity_block_plan_wave: the shape has no block plan, or workgroup %d out of range", wg);
+  int b0, b1, e0, e1, s1, c1;
+  block_slots(bp, wg, wave, b0, b1, e0, e1, s1, c1);
+  out6[0] = b0; out6[1] = b1; out6[2] = e0; out6[3] = e1; out6[4] = s1; out6[5] = c1;
+  return 0;
+}
 bool aff_rowcol_supported(int P) { return P <= 32768; }
 
 // k = 1.  Same contract as sdk_affinity_topk (which dispatches here).
@@ -805,6 +1058,19 @@ int aff_rowcol_top1(sdk_ctx* ctx, const float* E, const uint16_t* Eb, const floa
   {
     ProfScope ps(ctx, stream, SDK_K_AFF_COARSE, 2.0 * N * (double)Pn * D, 2.0 * ((double)N + Pn) * D + 64.0 * N);
     int rc;
+    BlockPlan bp;
+    // `affinity_variant` 7 = never the block plan (A/B, tests), 8 = always when the shape fits
+    if (ctx->aff_variant != 7 && (ctx->aff_variant == 0 || ctx->aff_variant == 5 || ctx->aff_variant == 8) &&
+        plan_blocks(N, Pn, 2, ctx->num_cu, &bp, ctx->aff_variant == 8)) {
+      auto kern = aff_rowcol_blocks_kernel<8, 2, 4>;
+      constexpr int LDSB = 4 * 2 * TILE_BYTES;
+      if (sdk_lds_optin(ctx, (const void*)kern, LDSB)) return 1;
+      bp.prio = ctx->aff_variant == 5 ? 1 : 0;
+      hipLaunchKernelGGL(kern, dim3(bp.G), dim3(512), LDSB, s, (const bf16_t*)Eb, (const bf16_t*)Pb, N, Pn, bp, w.stats, w.part_base, w.part_cnt, w.flag_count,
+                         (unsigned long long*)ctx->dbg_ptr);
+      segs = 32;
+      rc = 0;
+    } else
     switch (ctx->aff_variant) {
       case 1: rc = launch_coarse<8, 2, 4, 3>(ctx, (const bf16_t*)Eb, (const bf16_t*)Pb, N, Pn, w, s, 1, &segs); break;
       case 2: rc = launch_coarse<4, 2, 2, 3>(ctx, (const bf16_t*)Eb, (const bf16_t*)Pb, N, Pn, w, s, 2, &segs); break;

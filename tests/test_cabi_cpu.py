@@ -343,3 +343,44 @@ def test_bias_correction_host_side():
         o = f["off"][WP.bias_slot(n, small)]
         nb = w[f"{n}.conv.b"].shape[0]
         assert np.array_equal(blob[o:o + 4 * nb].view(np.float32), w[f"{n}.conv.b"]), n
+
+
+def test_affinity_block_plan_covers_every_block_and_stage_exactly_once():
+    """Round 4, k4 at short sweeps: the block plan (csrc/affinity_rowcol.hip plan_blocks / block_slots, shared by host and kernel).  Replayed here for
+    every wave of every workgroup: each block of 32 segments is swept over every profile stage exactly once - a main block by one wave for the
+    whole sweep, a leftover block by `parts` waves whose stage ranges tile [0, stages) - record slots 0..parts-1 each written once, and no
+    SIMD (waves w and w + 4) carries more than q / 4 + 1 blocks.  Config #3 takes the plan, config #4's long sweeps keep the range plan."""
+    lib = LIB.load_library()
+    out = (C.c_int32 * 6)()
+    assert lib.sdk_affinity_block_plan(100_000, 1000, 256, 0, out) == 0 and list(out) == [1, 12, 256, 16, 3, 159]
+    assert lib.sdk_affinity_block_plan(125_000, 10_000, 256, 0, out) == 0 and out[0] == 0          # long sweeps: the range plan balances to the stage
+    assert lib.sdk_affinity_block_plan(125_000, 10_000, 256, 1, out) == 0 and out[0] == 1 and out[1] == 12 and out[4] == 1
+    assert lib.sdk_affinity_block_plan(50_000, 1000, 256, 1, out) == 0 and out[0] == 0            # fewer than 8 blocks per workgroup: no block plan
+    assert lib.sdk_affinity_block_plan(140_000, 1000, 256, 1, out) == 0 and out[0] == 0           # more leftover blocks than free slots
+    w = (C.c_int32 * 6)()
+    for N, P, cu in ((100_000, 1000, 256), (70_001, 333, 256), (98_303, 4100, 256), (131_000, 197, 256), (109_215, 1000, 256), (114_000, 640, 256), (26_000, 500, 64)):
+        assert lib.sdk_affinity_block_plan(N, P, cu, 1, out) == 0 and out[0] == 1, (N, P, cu)
+        _, q, G, nst, parts, items = list(out)
+        NB = (N + 31) // 32
+        assert q in (8, 12) and G == cu and nst == -(-(-(-P // 32)) // 2) and items == (NB - q * G) * parts and 1 <= parts <= 3
+        cover = np.zeros((NB, nst), np.int32)
+        slots = [set() for _ in range(NB)]
+        for g in range(G):
+            per_simd = [0, 0, 0, 0]
+            for wave in range(8):
+                assert lib.sdk_affinity_block_plan_wave(N, P, cu, g, wave, w) == 0
+                b0, b1, e0, e1, s1, c1 = list(w)
+                assert b0 == g * q + wave
+                cover[b0, :] += 1
+                slots[b0].add(0)
+                per_simd[wave % 4] += 1
+                if b1 >= 0:
+                    assert 0 <= e0 < e1 <= nst and 0 <= s1 < c1 <= 3 and b1 < NB
+                    cover[b1, e0:e1] += 1
+                    assert s1 not in slots[b1]
+                    slots[b1].add(s1)
+                    per_simd[wave % 4] += 1
+            assert max(per_simd) <= q // 4 + 1
+        assert (cover == 1).all(), (N, P, np.argwhere(cover != 1)[:5])
+        assert all(sl == set(range(len(sl))) for sl in slots)
+        assert all(len(slots[b]) == (1 if b < q * G else parts) for b in range(NB))

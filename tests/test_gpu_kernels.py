@@ -444,6 +444,33 @@ def test_affinity_pipelined_variant_is_bit_identical(engine, N, P):
     assert np.array_equal(got[0], ref[0]) and np.array_equal(got[1], ref[1]) and got[2] == ref[2]
 
 
+@pytest.mark.parametrize("N,P", [(100_000, 1000), (70_001, 333), (109_215, 1000), (131_000, 197), (98_303, 2049)])
+def test_affinity_block_plan_equals_the_range_plan(engine, N, P):
+    """Round 4: the coarse pass's BLOCK plan (every workgroup sweeps all stages once; blocks of 32 segments dealt to waves, leftover blocks swept in
+    parts; csrc/affinity_rowcol.hip) against the range plan on the same inputs: the exact pass certifies or rescans every row, so indices and
+    scores must agree bit for bit whatever the decomposition - near-duplicate profiles, exact ties and a partial last tile included - and both
+    equal the fp64 scan of the GPU's own embeddings (IDs identical, scores within 1e-5)."""
+    E, Pm = _unit(N, 192, N + P), _unit(P, 192, 7 * P + 1)
+    Pm[1] = Pm[0]                                                   # an exact tie: the lower index must win under both plans
+    Pm[5] = oecapa.l2_normalise((Pm[4] + 1e-4 * Pm[6])[None])[0]    # a near-duplicate pair
+    E[:64] = oecapa.l2_normalise(Pm[np.arange(64) % 8] + 0.05 * _unit(64, 192, 3))
+    out = {}
+    for name, var in (("ranges", 7), ("blocks", 8)):
+        engine.set_option("affinity_variant", var)
+        try:
+            out[name] = _score_gpu(engine, E, Pm, 1)
+        finally:
+            engine.set_option("affinity_variant", 0)
+    a, b = out["ranges"], out["blocks"]
+    assert np.array_equal(a[0], b[0]) and np.array_equal(a[1], b[1])
+    En, Pn = a[3], a[4]
+    step = 20_000
+    for lo in range(0, N, step):
+        oidx, osc = oscoring.affinity_topk(En[lo:lo + step], Pn, 1)
+        assert np.array_equal(b[0][lo:lo + step], oidx) and np.abs(b[1][lo:lo + step] - osc).max() <= 1e-5
+    assert b[2] <= a[2] + 50                                        # whole sweeps give full certificates: no more rescans than the split sweeps (+ slack for the leftover parts)
+
+
 def test_affinity_threshold_assignment(engine):
     """Config #2 shape: 1000 segments x 100 profiles, threshold 0.354 (the ABC default)."""
     E, Pm = _unit(1000, 192, 0), _unit(100, 192, 1)
