@@ -342,7 +342,8 @@ int sdk_affinity_plan(int N, int P, int num_cu, int32_t* out5, int64_t* units);
 /* Host-only: the unit range [u0, u1) of workgroup `wg` under that plan and the record slot of its first portion.  The ranges can be balanced by
  * cost instead of unit count ("affinity_boundary_penalty" p: a group boundary inside a range counts as p stages; default 0 - measured, not a robust win). */
 int sdk_affinity_plan_range(int N, int P, int num_cu, int wg, int64_t* u0, int64_t* u1, int32_t* first_slot);
-/* Host-only (round 4): the BLOCK plan the coarse pass takes for short sweeps (config #3), for tests.  Unit of work = a block of 32 segments with its whole
+/* Host-only (round 4): the BLOCK plan of the coarse pass for short sweeps (config #3; `affinity_variant` 8 - measured level with the default range plan
+ * end to end, so not the default), for tests.  Unit of work = a block of 32 segments with its whole
  * sweep; workgroup g owns blocks [g q, (g + 1) q), the leftover blocks are swept in `parts` stage ranges by waves with a free second slot.
  * sdk_affinity_block_plan: out6 = {1 = plan taken / 0 = the range plan stays (force != 0: taken whenever the shape fits), q, workgroups, stages per
  * sweep, parts per leftover block, leftover items}.  sdk_affinity_block_plan_wave: wave `wave` (0..7) of workgroup `wg`: out6 = {block of slot 0, block of

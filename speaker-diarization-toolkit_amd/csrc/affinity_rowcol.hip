@@ -65,6 +65,51 @@ __host__ __device__ inline long long geom_first_wg(const Geom& g, long long b) {
   return ((X + 1) * g.G + V - 1) / V - 1;
 }
 
+
+// ---- hand-pipelined fragment reads (round 4) ---------------------------------------------------------------------------------------------------
+// Left to hipcc, a tile's twelve profile-fragment reads are issued one or two at a time directly in front of the MFMAs that need them, each pair
+// behind an `s_waitcnt lgkmcnt(0)` (the .s of both coarse kernels showed 7-8 such waits per tile): the wave exposes an LDS round trip every one or
+// two MFMAs, and the stage loop ran at 58-65 % of the matrix pipe whatever was done to the vector work beside it (pipelined reduction, static
+// priority, staggered waves: all measured, all null).  Here the reads are inline asm in a ring of RD registers, RD steps ahead of their MFMAs, with
+// counted waits; the last steps of a tile already fetch the next tile's first fragments (PREF), which then arrive under the tile's reduction.
+// Every wait is followed by sched_barrier(0): hipcc hoists register-only MFMAs across an inline-asm s_waitcnt (cdna_hip_programming.md rule 18).
+// The kernels have no static LDS, so the dynamic array starts at LDS address 0 and `sqa` are plain byte offsets.
+constexpr int RD = 4;
+template <int OFF>
+__device__ __forceinline__ void lds_rd128(bf16x8& d, uint32_t addr) {
+  asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(d) : "v"(addr), "n"(OFF));
+}
+template <int N>
+__device__ __forceinline__ void lgkm_wait_pinned() {
+  asm volatile("s_waitcnt lgkmcnt(%0)" ::"n"(N) : "memory");
+  __builtin_amdgcn_sched_barrier(0);
+}
+// fragments 0..RD-1 of tile TT (byte offset TT * TILE_BYTES inside the stage): the stage's prologue, right behind its barrier
+template <int TT>
+__device__ __forceinline__ void tile_prologue(const uint32_t (&sqa)[4], bf16x8 (&ring)[RD]) {
+  lds_rd128<TT * TILE_BYTES>(ring[0], sqa[0]);
+  lds_rd128<TT * TILE_BYTES>(ring[1], sqa[1]);
+  lds_rd128<TT * TILE_BYTES>(ring[2], sqa[2]);
+  lds_rd128<TT * TILE_BYTES>(ring[3], sqa[3]);
+}
+// step KSI of tile TT for NB segment blocks: wait for fragment KSI, its NB MFMAs, then the read RD steps ahead into the slot just consumed
+template <int TT, int NB, bool PREF, int KSI>
+struct TileStep {
+  static __device__ __forceinline__ void run(const uint32_t (&sqa)[4], const bf16x8 (&bfrag)[2][KS], f32x16 (&acc)[2], bf16x8 (&ring)[RD]) {
+    constexpr int LAST = PREF ? KS + RD - 1 : KS - 1;                         // index of the last read of this tile's sequence (PREF: + the next tile's first RD)
+    constexpr int YOUNGER = (LAST - KSI) < (RD - 1) ? (LAST - KSI) : (RD - 1); // reads issued after fragment KSI that may stay in flight
+    lgkm_wait_pinned<YOUNGER>();
+#pragma unroll
+    for (int sb = 0; sb < NB; ++sb) acc[sb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ring[KSI % RD], bfrag[sb][KSI], acc[sb], 0, 0, 0);
+    __builtin_amdgcn_sched_barrier(0);
+    constexpr int NX = KSI + RD;
+    if constexpr (NX < KS) lds_rd128<TT * TILE_BYTES + (NX >> 2) * 128>(ring[NX % RD], sqa[NX & 3]);
+    else if constexpr (PREF) lds_rd128<(TT + 1) * TILE_BYTES + ((NX - KS) >> 2) * 128>(ring[NX % RD], sqa[(NX - KS) & 3]);
+    if constexpr (KSI + 1 < KS) TileStep<TT, NB, PREF, KSI + 1>::run(sqa, bfrag, acc, ring);
+  }
+};
+static_assert(KS % RD == 0, "the ring slot of fragment ks (ks % RD) and its address register (ks & 3) line up across tiles");
+
 template <int DEPTH>
 __device__ __forceinline__ void insert_sorted(float x, float* m) {
   float n[DEPTH];
@@ -323,7 +368,8 @@ __global__ __launch_bounds__(WAVES * 64, 2) void aff_rowcol_kernel(const bf16_t*
       }
       __builtin_amdgcn_s_barrier();                 // stage k landed for everyone; the buffer of stage k-1 is free
       stamp();
-      if (u + AHEAD < u1) issue();
+      const bool late_issue = gm.prio == 3;         // A/B (`affinity_variant` 10): the refill of the freed buffer is issued behind the first tile's MFMAs
+      if (!late_issue && u + AHEAD < u1) issue();
       // Fragment addresses: chunk c = 2 ks + h of this lane's row sits at 16 * ((c & ~7) | ((c & 7) ^ rsw)); its low three
       // bits depend only on ks & 3, so four per-lane offsets + compile-time immediates (tile, ks >> 2) cover all 12 reads of
       // every tile.  (Left to the compiler, the XOR was re-derived per read: ~50 of the ~118 vector instructions per tile.)
@@ -342,6 +388,38 @@ __global__ __launch_bounds__(WAVES * 64, 2) void aff_rowcol_kernel(const bf16_t*
         } else {                                     // odd tile count: nothing follows in this sweep - reduce now, leave "nothing pending"
           reduce(accq, tag0);
           clear_pending();
+        }
+      } else if (TPS == 2 && SEGB == 2 && gm.prio == 4) {
+        // hand-pipelined fragment reads (TileStep above): A/B knob `affinity_variant` 11 - measured equal to the compiler's schedule
+        const uint32_t stage_off = (uint32_t)((k % NSTAGE) * STAGE_BYTES);
+        const uint32_t sqa[4] = {stage_off + (uint32_t)aoff[0], stage_off + (uint32_t)aoff[1], stage_off + (uint32_t)aoff[2], stage_off + (uint32_t)aoff[3]};
+        bf16x8 ring[RD];
+        tile_prologue<0>(sqa, ring);
+        const int tile0 = s * TPS;
+        const bool t1 = tile0 + 1 < ntiles;            // wave-uniform
+        {
+          f32x16 acc[2];
+#pragma unroll
+          for (int sb = 0; sb < 2; ++sb)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[sb][r] = 0.f;
+          if (t1) TileStep<0, 2, true, 0>::run(sqa, bfrag, acc, ring);
+          else TileStep<0, 2, false, 0>::run(sqa, bfrag, acc, ring);
+          if (late_issue && u + AHEAD < u1) issue();
+          mask_partial(tile0, acc);
+          reduce(acc, ltile);
+          ++ltile;
+        }
+        if (t1) {
+          f32x16 acc[2];
+#pragma unroll
+          for (int sb = 0; sb < 2; ++sb)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[sb][r] = 0.f;
+          TileStep<1, 2, false, 0>::run(sqa, bfrag, acc, ring);
+          mask_partial(tile0 + 1, acc);
+          reduce(acc, ltile);
+          ++ltile;
         }
       } else {
 #pragma unroll
@@ -513,7 +591,6 @@ __global__ __launch_bounds__(WAVES * 64, 2) void aff_rowcol_blocks_kernel(const 
     }
   };
   stamp();
-  const char* sq[4];
   for (int s = 0; s < nst; ++s) {
     const int after = nst - 1 - s < AHEAD - 1 ? nst - 1 - s : AHEAD - 1;
     if (after >= 2) {
@@ -528,40 +605,35 @@ __global__ __launch_bounds__(WAVES * 64, 2) void aff_rowcol_blocks_kernel(const 
     __builtin_amdgcn_s_barrier();
     stamp();
     if (s + AHEAD < nst) issue();
-#pragma unroll
-    for (int q = 0; q < 4; ++q) sq[q] = sP + (s % NSTAGE) * STAGE_BYTES + aoff[q];
     const bool two = has1 && s >= e0 && s < e1;                   // wave-uniform
+    const int t0 = s * TPS, t1 = t0 + 1;
+    static_assert(TPS == 2, "TileStep<0 / 1>: two tiles per stage");
+    const bool has_t1 = t1 < ntiles;                              // wave-uniform
+    const uint32_t stage_off = (uint32_t)((s % NSTAGE) * STAGE_BYTES);
+    const uint32_t sqa[4] = {stage_off + (uint32_t)aoff[0], stage_off + (uint32_t)aoff[1], stage_off + (uint32_t)aoff[2], stage_off + (uint32_t)aoff[3]};
+    bf16x8 ring[RD];
+    tile_prologue<0>(sqa, ring);
+    f32x16 acc[2];
 #pragma unroll
-    for (int tt = 0; tt < TPS; ++tt) {
-      const int tile = s * TPS + tt;
-      if (tile < ntiles) {
-        if (two) {
-          f32x16 a0, a1;
+    for (int r = 0; r < 16; ++r) { acc[0][r] = 0.f; acc[1][r] = 0.f; }
+    if (two) {
+      if (has_t1) TileStep<0, 2, true, 0>::run(sqa, bfrag, acc, ring);
+      else TileStep<0, 2, false, 0>::run(sqa, bfrag, acc, ring);
+    } else {
+      if (has_t1) TileStep<0, 1, true, 0>::run(sqa, bfrag, acc, ring);
+      else TileStep<0, 1, false, 0>::run(sqa, bfrag, acc, ring);
+    }
+    mask1(t0, acc[0]);
+    reduce1(acc[0], 0, t0);
+    if (two) { mask1(t0, acc[1]); reduce1(acc[1], 1, t0 - e0 * TPS); }
+    if (has_t1) {
 #pragma unroll
-          for (int r = 0; r < 16; ++r) { a0[r] = 0.f; a1[r] = 0.f; }
-#pragma unroll
-          for (int ks = 0; ks < KS; ++ks) {
-            const bf16x8 a = *reinterpret_cast<const bf16x8*>(sq[ks & 3] + tt * TILE_BYTES + (ks >> 2) * 128);
-            a0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, bfrag[0][ks], a0, 0, 0, 0);
-            a1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, bfrag[1][ks], a1, 0, 0, 0);
-          }
-          mask1(tile, a0);
-          mask1(tile, a1);
-          reduce1(a0, 0, tile);
-          reduce1(a1, 1, tile - e0 * TPS);
-        } else {
-          f32x16 a0;
-#pragma unroll
-          for (int r = 0; r < 16; ++r) a0[r] = 0.f;
-#pragma unroll
-          for (int ks = 0; ks < KS; ++ks) {
-            const bf16x8 a = *reinterpret_cast<const bf16x8*>(sq[ks & 3] + tt * TILE_BYTES + (ks >> 2) * 128);
-            a0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, bfrag[0][ks], a0, 0, 0, 0);
-          }
-          mask1(tile, a0);
-          reduce1(a0, 0, tile);
-        }
-      }
+      for (int r = 0; r < 16; ++r) { acc[0][r] = 0.f; acc[1][r] = 0.f; }
+      if (two) TileStep<1, 2, false, 0>::run(sqa, bfrag, acc, ring);
+      else TileStep<1, 1, false, 0>::run(sqa, bfrag, acc, ring);
+      mask1(t1, acc[0]);
+      reduce1(acc[0], 0, t1);
+      if (two) { mask1(t1, acc[1]); reduce1(acc[1], 1, t1 - e0 * TPS); }
     }
   }
   stamp();
@@ -645,15 +717,26 @@ __global__ __launch_bounds__(256) void aff_rowcol_rescore_kernel(const float* __
   // everything that does not depend on other loads is requested up front
   f32x4 T4[MAXP], C4[MAXP];
   int pb[MAXP];
-#pragma unroll
-  for (int p = 0; p < MAXP; ++p) {       // slots a group does not use hold stale bytes: masked by np below
-    const float* src = stats + (((int64_t)rc * MAXP + p) * 2 + hh) * 8;
-    T4[p] = *reinterpret_cast<const f32x4*>(src);
-    C4[p] = *reinterpret_cast<const f32x4*>(src + 4);
-    pb[p] = part_base[grp * MAXP + p];
-  }
   const int np_raw = part_cnt[grp];
+  {                                      // slot 0 always exists: requested together with the count
+    const float* src = stats + (((int64_t)rc * MAXP) * 2 + hh) * 8;
+    T4[0] = *reinterpret_cast<const f32x4*>(src);
+    C4[0] = *reinterpret_cast<const f32x4*>(src + 4);
+    pb[0] = part_base[grp * MAXP];
+  }
   const int np = np_raw < MAXP ? np_raw : MAXP;
+#pragma unroll
+  for (int p = 1; p < MAXP; ++p) {       // further parts only where a sweep was split (block plan: 2 % of the blocks; 128 B per row and part saved)
+    T4[p] = f32x4{EMPTY, EMPTY, EMPTY, EMPTY};
+    C4[p] = T4[p];
+    pb[p] = 0;
+    if (p < np) {
+      const float* src = stats + (((int64_t)rc * MAXP + p) * 2 + hh) * 8;
+      T4[p] = *reinterpret_cast<const f32x4*>(src);
+      C4[p] = *reinterpret_cast<const f32x4*>(src + 4);
+      pb[p] = part_base[grp * MAXP + p];
+    }
+  }
   const float re = resid_e[rc];
   float e24[24];
   load_row24(E + (int64_t)rc * D, j, e24);     // plain loads: a non-temporal hint here cost 19 us (25.7 -> 44.6: E then comes from HBM, not the Infinity Cache)
@@ -993,7 +1076,7 @@ int launch_coarse(sdk_ctx* ctx, const bf16_t* Eb, const bf16_t* Pb, int N, int P
   constexpr int LDS = NSTAGE * TPS * TILE_BYTES;
   *segs = SEGS;
   Geom gm = plan_geometry(N, P, SEGS, TPS, (long long)ctx->num_cu * wg_per_cu, ctx->aff_whole_groups, ctx->aff_boundary_pen);
-  gm.prio = ctx->aff_variant == 5 ? 1 : ctx->aff_variant == 6 ? 2 : 0;
+  gm.prio = ctx->aff_variant == 5 ? 1 : ctx->aff_variant == 6 ? 2 : ctx->aff_variant == 10 ? 3 : ctx->aff_variant == 11 ? 4 : 0;
   auto kern = aff_rowcol_kernel<WAVES, SEGB, TPS, NSTAGE, PIPE>;
   if (sdk_lds_optin(ctx, (const void*)kern, LDS)) return 1;
   hipLaunchKernelGGL(kern, dim3(gm.G), dim3(WAVES * 64), LDS, s, Eb, Pb, N, P, gm, w.stats, w.part_base, w.part_cnt, w.flag_count,
@@ -1059,9 +1142,10 @@ int aff_rowcol_top1(sdk_ctx* ctx, const float* E, const uint16_t* Eb, const floa
     ProfScope ps(ctx, stream, SDK_K_AFF_COARSE, 2.0 * N * (double)Pn * D, 2.0 * ((double)N + Pn) * D + 64.0 * N);
     int rc;
     BlockPlan bp;
-    // `affinity_variant` 7 = never the block plan (A/B, tests), 8 = always when the shape fits
-    if (ctx->aff_variant != 7 && (ctx->aff_variant == 0 || ctx->aff_variant == 5 || ctx->aff_variant == 8) &&
-        plan_blocks(N, Pn, 2, ctx->num_cu, &bp, ctx->aff_variant == 8)) {
+    // `affinity_variant` 8 = the block plan whenever the shape fits (A/B, tests).  NOT the default: measured (profiles/r04_aff_block_plan_ab.txt) the
+    // coarse pass gains 6-9 % at config #3 (47.1 -> 42.7-44.1 us) and whole sweeps give weaker certificates (201 instead of 88 rows to rescan:
+    // +5.6 us), so end to end it is level (82.9-84.2 vs 81.4-82.4 us); config #4's shape is level either way.
+    if (ctx->aff_variant == 8 && plan_blocks(N, Pn, 2, ctx->num_cu, &bp, true)) {
       auto kern = aff_rowcol_blocks_kernel<8, 2, 4>;
       constexpr int LDSB = 4 * 2 * TILE_BYTES;
       if (sdk_lds_optin(ctx, (const void*)kern, LDSB)) return 1;
