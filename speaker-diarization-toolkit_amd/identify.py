@@ -17,14 +17,43 @@ def db_dir() -> Path:
 
 
 def list_all_speakers() -> List[Dict[str, Any]]:
-    out = []
+    """Every db/*.json profile, sorted by file name (speaker_detection:206-220 reads them one by one, per CLI call).  At BASELINE's profile counts
+    (1 000 / 10 000 speakers) that is 10^3-10^4 small-file reads per process, so the parsed list is kept as ONE file, db/.profiles-pack.json, keyed by
+    a digest of the directory listing (name, size, mtime_ns of every db/*.json: one scandir, no file is opened): any edit, addition or deletion
+    changes the digest and the pack is rebuilt from the files.  SDK_PROFILE_PACK=0 disables it.  Warnings for unreadable files are repeated on a
+    pack hit (they are stored with it)."""
+    import hashlib
     d = db_dir()
-    if d.exists():
-        for p in sorted(d.glob("*.json")):
-            try:
-                out.append(json.loads(p.read_text()))
-            except (json.JSONDecodeError, OSError) as exc:
-                print(f"Warning: Failed to load {p}: {exc}", file=sys.stderr)
+    if not d.exists():
+        return []
+    entries = sorted((e.name, e.stat().st_size, e.stat().st_mtime_ns) for e in os.scandir(d) if e.name.endswith(".json") and not e.name.startswith(".") and e.is_file())
+    use_pack = os.environ.get("SDK_PROFILE_PACK", "1") != "0" and len(entries) >= 64
+    digest = hashlib.sha256(repr(entries).encode()).hexdigest()
+    pack = d / ".profiles-pack.json"
+    if use_pack:
+        try:
+            t = json.loads(pack.read_text())
+            if t.get("digest") == digest and t.get("format") == 1:
+                for w in t.get("warnings", []):
+                    print(w, file=sys.stderr)
+                return t["profiles"]
+        except (OSError, ValueError, KeyError):
+            pass
+    out, warns = [], []
+    for name, _, _ in entries:
+        p = d / name
+        try:
+            out.append(json.loads(p.read_text()))
+        except (json.JSONDecodeError, OSError) as exc:
+            warns.append(f"Warning: Failed to load {p}: {exc}")
+            print(warns[-1], file=sys.stderr)
+    if use_pack:
+        try:                                     # atomic publish; concurrent CLI processes write identical content
+            tmp = d / f".profiles-pack.{os.getpid()}.tmp"
+            tmp.write_text(json.dumps({"format": 1, "digest": digest, "profiles": out, "warnings": warns}))
+            os.replace(tmp, pack)
+        except OSError:
+            pass
     return out
 
 

@@ -218,6 +218,7 @@ class LiteEngine:
         return out
 
     def forward(self, feats: DevBuf, B: int, T: int) -> DevBuf:
+        check(self.lib.sdk_set_option(self.ctx, b"precision", 0), "sdk_set_option")      # this path serves the default contract only: never inherit the context's last setting
         emb = self._buf("emb", B * self.cfg.embed_dim * 4)
         if self._xv is not None:
             blob, d = self._xv

@@ -379,6 +379,11 @@ class Engine:
         B = pcm.shape[0]
         if nsplit <= 1 or B < 2 * nsplit:
             return self.embed_pcm(pcm)
+        # lazy state first, on THIS stream and complete: the weight upload, the calibration pass and the 29 bias patches of a first load must not
+        # race with the side streams that read the same blob
+        self.desc
+        self.fbank_tables()
+        torch.cuda.current_stream().synchronize()
         if len(self._streams) < nsplit:
             self._streams += [torch.cuda.Stream(device=self.device) for _ in range(nsplit - len(self._streams))]
         cur = torch.cuda.current_stream()

@@ -491,3 +491,35 @@ def test_vectors_remember_their_numerical_setting(tmp_path, monkeypatch):
     be = backend.Backend()
     monkeypatch.setenv("SDK_PRECISION", "1")
     assert be.numerics() == {"precision": 1, "bias_correction": False}
+
+
+def test_db_listing_pack_follows_every_change(tmp_path, monkeypatch, capsys):
+    """a7 at BASELINE's profile counts: the in-process counterpart of `speaker_detection identify` (which reads every db/*.json per call,
+    speaker_detection:206-220) keeps the parsed list as one file keyed by the directory listing; an edit, an addition and a deletion each
+    invalidate it; a broken file warns on a miss AND on a hit; dot-files and the pack itself are not profiles."""
+    ident = sub("identify")
+    monkeypatch.setenv("SPEAKERS_EMBEDDINGS_DIR", str(tmp_path))
+    db = tmp_path / "db"
+    db.mkdir()
+    for i in range(70):
+        (db / f"s{i:03d}.json").write_text(json.dumps({"id": f"s{i:03d}", "tags": ["a"] if i % 2 else [], "embeddings": {"mi355x": [{"id": f"e{i}"}]}}))
+    (db / "broken.json").write_text("{not json")
+    first = ident.list_all_speakers()
+    assert [p["id"] for p in first] == [f"s{i:03d}" for i in range(70)] and (db / ".profiles-pack.json").exists()
+    assert "broken.json" in capsys.readouterr().err
+    reads = []
+    real = Path.read_text
+    monkeypatch.setattr(Path, "read_text", lambda self, *a, **k: (reads.append(self.name), real(self, *a, **k))[1])
+    again = ident.list_all_speakers()
+    assert again == first and reads == [".profiles-pack.json"]                     # ONE file opened, whatever the number of speakers
+    assert "broken.json" in capsys.readouterr().err
+    (db / "s005.json").write_text(json.dumps({"id": "s005", "tags": ["edited"], "embeddings": {}}))       # edit (size and mtime change)
+    assert ident.list_all_speakers()[5]["tags"] == ["edited"]
+    (db / "s070.json").write_text(json.dumps({"id": "s070", "embeddings": {}}))                           # addition
+    assert len(ident.list_all_speakers()) == 71
+    (db / "s000.json").unlink()                                                                           # deletion
+    assert ident.list_all_speakers()[0]["id"] == "s001" and len(ident.list_all_speakers()) == 70
+    assert len(ident.candidates_for("mi355x", tags=["a"])) == 34
+    monkeypatch.setenv("SDK_PROFILE_PACK", "0")
+    reads.clear()
+    assert len(ident.list_all_speakers()) == 70 and ".profiles-pack.json" not in reads and len(reads) == 71
