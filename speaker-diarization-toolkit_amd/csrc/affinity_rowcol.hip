@@ -134,7 +134,7 @@ __device__ __forceinline__ float max3(float a, float b, float c) { return fmaxf(
 // budget forces (DMA source offsets re-derived per stage instead of kept in 6 registers).  A 4-wave form with 128 segments per wave and 512 registers
 // (one wave per SIMD, each fragment read feeding 4 MFMAs) was built too: hipcc keeps the segment fragments in AGPRs and copies them out before every MFMA
 // (4 v_accvgpr_read per MFMA, 18 registers spilled): 63 us / 582 us, removed.
-template <int WAVES, int SEGB, int TPS, int NSTAGE, bool PIPE>
+template <int WAVES, int SEGB, int TPS, int NSTAGE, bool PIPE, bool HANDRD>
 __global__ __launch_bounds__(WAVES * 64, 2) void aff_rowcol_kernel(const bf16_t* __restrict__ Eb, const bf16_t* __restrict__ Pb,
                                                                int N, int P, Geom gm, float* __restrict__ stats,
                                                                int32_t* __restrict__ part_base, int32_t* __restrict__ part_cnt,
@@ -368,8 +368,8 @@ __global__ __launch_bounds__(WAVES * 64, 2) void aff_rowcol_kernel(const bf16_t*
       }
       __builtin_amdgcn_s_barrier();                 // stage k landed for everyone; the buffer of stage k-1 is free
       stamp();
-      const bool late_issue = gm.prio == 3;         // A/B (`affinity_variant` 10): the refill of the freed buffer is issued behind the first tile's MFMAs
-      if (!late_issue && u + AHEAD < u1) issue();
+      constexpr bool late_issue = false;            // (round 4 A/B, `affinity_variant` 10 then: the refill issued behind the first tile's MFMAs - 47.0 vs 47.1 us: no change, removed)
+      if (u + AHEAD < u1) issue();
       // Fragment addresses: chunk c = 2 ks + h of this lane's row sits at 16 * ((c & ~7) | ((c & 7) ^ rsw)); its low three
       // bits depend only on ks & 3, so four per-lane offsets + compile-time immediates (tile, ks >> 2) cover all 12 reads of
       // every tile.  (Left to the compiler, the XOR was re-derived per read: ~50 of the ~118 vector instructions per tile.)
@@ -389,8 +389,10 @@ __global__ __launch_bounds__(WAVES * 64, 2) void aff_rowcol_kernel(const bf16_t*
           reduce(accq, tag0);
           clear_pending();
         }
-      } else if (TPS == 2 && SEGB == 2 && gm.prio == 4) {
-        // hand-pipelined fragment reads (TileStep above): A/B knob `affinity_variant` 11 - measured equal to the compiler's schedule
+      } else if constexpr (HANDRD) {
+        static_assert(!HANDRD || (TPS == 2 && SEGB == 2), "TileStep<0 / 1> with two blocks");
+        // hand-pipelined fragment reads (TileStep above): A/B knob `affinity_variant` 11, its own instantiation - measured equal to the compiler's
+        // schedule (as a run-time branch inside the default instantiation it cost the DEFAULT path 30 %: 47 -> 61-66 us at config #3)
         const uint32_t stage_off = (uint32_t)((k % NSTAGE) * STAGE_BYTES);
         const uint32_t sqa[4] = {stage_off + (uint32_t)aoff[0], stage_off + (uint32_t)aoff[1], stage_off + (uint32_t)aoff[2], stage_off + (uint32_t)aoff[3]};
         bf16x8 ring[RD];
@@ -1069,15 +1071,15 @@ Geom plan_geometry(int N, int P, int segs, int tps, long long max_wg, int whole_
   return gm;
 }
 
-template <int WAVES, int SEGB, int TPS, int NSTAGE, bool PIPE = false>
+template <int WAVES, int SEGB, int TPS, int NSTAGE, bool PIPE = false, bool HANDRD = false>
 int launch_coarse(sdk_ctx* ctx, const bf16_t* Eb, const bf16_t* Pb, int N, int P, const Ws& w, hipStream_t s, int wg_per_cu,
                   int* segs) {
   constexpr int SEGS = WAVES * SEGB * 32;
   constexpr int LDS = NSTAGE * TPS * TILE_BYTES;
   *segs = SEGS;
   Geom gm = plan_geometry(N, P, SEGS, TPS, (long long)ctx->num_cu * wg_per_cu, ctx->aff_whole_groups, ctx->aff_boundary_pen);
-  gm.prio = ctx->aff_variant == 5 ? 1 : ctx->aff_variant == 6 ? 2 : ctx->aff_variant == 10 ? 3 : ctx->aff_variant == 11 ? 4 : 0;
-  auto kern = aff_rowcol_kernel<WAVES, SEGB, TPS, NSTAGE, PIPE>;
+  gm.prio = ctx->aff_variant == 5 ? 1 : ctx->aff_variant == 6 ? 2 : 0;
+  auto kern = aff_rowcol_kernel<WAVES, SEGB, TPS, NSTAGE, PIPE, HANDRD>;
   if (sdk_lds_optin(ctx, (const void*)kern, LDS)) return 1;
   hipLaunchKernelGGL(kern, dim3(gm.G), dim3(WAVES * 64), LDS, s, Eb, Pb, N, P, gm, w.stats, w.part_base, w.part_cnt, w.flag_count,
                      (unsigned long long*)ctx->dbg_ptr);
@@ -1159,6 +1161,7 @@ int aff_rowcol_top1(sdk_ctx* ctx, const float* E, const uint16_t* Eb, const floa
       case 1: rc = launch_coarse<8, 2, 4, 3>(ctx, (const bf16_t*)Eb, (const bf16_t*)Pb, N, Pn, w, s, 1, &segs); break;
       case 2: rc = launch_coarse<4, 2, 2, 3>(ctx, (const bf16_t*)Eb, (const bf16_t*)Pb, N, Pn, w, s, 2, &segs); break;
       case 3: rc = launch_coarse<8, 2, 2, 4, true>(ctx, (const bf16_t*)Eb, (const bf16_t*)Pb, N, Pn, w, s, 1, &segs); break;
+      case 11: rc = launch_coarse<8, 2, 2, 4, false, true>(ctx, (const bf16_t*)Eb, (const bf16_t*)Pb, N, Pn, w, s, 1, &segs); break;
       default: rc = launch_coarse<8, 2, 2, 4>(ctx, (const bf16_t*)Eb, (const bf16_t*)Pb, N, Pn, w, s, 1, &segs); break;
     }
     if (rc) return rc;

@@ -360,24 +360,18 @@ __global__ __launch_bounds__(NT2, 2) void conv_gemm256_kernel(Params p) {
       const int mm = min(tm0 + row, p.M - 1);
       aseg0 = (mm / p.T) * p.T;
       atl0 = mm - aseg0;                             // rows past M fetch some valid row; their results are dropped
-    } else if (p.tune & 512) {
-      // TIMING PROBE ONLY (gemm_variant 8194, tools/gemm_kblock_probe.py; results are wrong): source addresses as if A were stored K-blocked
-      // [K/64][M][64] - a wave's piece of 8 rows x 128 B is then ONE contiguous KiB and a tile's K-step 32 contiguous KiB
-#pragma unroll
-      for (int i = 0; i < 4; ++i) aoff[i] = ((uint32_t)min(tm0 + row + 8 * i, p.M - 1) * 64u + (uint32_t)gch) * 2u;
     } else {
 #pragma unroll
       for (int i = 0; i < 4; ++i) aoff[i] = ((uint32_t)min(tm0 + row + 8 * i, p.M - 1) * (uint32_t)p.lda + (uint32_t)gch) * 2u;
     }
-    woff = (p.tune & 1024) ? ((uint32_t)(tn0 + row) * 64u + (uint32_t)gch) * 2u       // probe: W as [K/64][N][64] too (gemm_variant 24578)
-                           : ((uint32_t)(tn0 + row) * (uint32_t)Ktot + (uint32_t)gch) * 2u;
+    woff = ((uint32_t)(tn0 + row) * (uint32_t)Ktot + (uint32_t)gch) * 2u;
   };
   auto issue = [&](int t, int stage) {
     const int j = t / ksteps_per_tap;
     const int kc = (t - j * ksteps_per_tap) * BK;
     char* sA = smem + stage * STAGE2 + (32 * wu) * 128;
     char* sB = sA + BM2 * BK * 2;
-    const char* abase = reinterpret_cast<const char*>(p.A + ((p.tune & 512) ? (size_t)(kc >> 6) * (size_t)p.M * 64 : (size_t)kc));
+    const char* abase = reinterpret_cast<const char*>(p.A + kc);
     if constexpr (TAPS) {
       int off = (j - half) * p.dil;
       uint32_t acol = (uint32_t)gch;
@@ -410,20 +404,16 @@ __global__ __launch_bounds__(NT2, 2) void conv_gemm256_kernel(Params p) {
       for (int i = 0; i < 4; ++i)
         __builtin_amdgcn_global_load_lds((gptr_t)(abase + (size_t)aoff[i]), (lptr_t)(sA + i * 1024), 16, 0, 0);
     }
-    const bool wkb = (p.tune & 1024) != 0;
-    const char* wbase = reinterpret_cast<const char*>(p.W + (wkb ? (size_t)((j * cin_w + kc) >> 6) * (size_t)p.N * 64 : (size_t)(j * cin_w + kc)));
-    const size_t wstep = wkb ? (size_t)16 * 64 : (size_t)16 * Ktot;
+    const char* wbase = reinterpret_cast<const char*>(p.W + (j * cin_w + kc));
 #pragma unroll
     for (int i = 0; i < 4; ++i)
-      __builtin_amdgcn_global_load_lds((gptr_t)(wbase + (size_t)i * wstep + (size_t)woff), (lptr_t)(sB + i * 1024), 16, 0, 0);
+      __builtin_amdgcn_global_load_lds((gptr_t)(wbase + (size_t)i * 16 * Ktot + (size_t)woff), (lptr_t)(sB + i * 1024), 16, 0, 0);
   };
 
   const int fr = lane & 15, fq = lane >> 4, sw = lane & 7;
   const uint32_t a_base = (wm * 128 + fr) * 128;
   const uint32_t b_base = BM2 * BK * 2 + (wn * 64 + fr) * 128;
   const uint32_t c0 = ((0 * 4 + fq) ^ sw) << 4, c1 = ((1 * 4 + fq) ^ sw) << 4;
-  const int prio_mode = (p.tune >> 11) & 3;
-  if (prio_mode == 2 && wu >= 4) __builtin_amdgcn_s_setprio(1);
   const int pol = p.tune & 3;   // 0: waves 0-3 early / 4-7 late (default), 1: all early, 2: all late, 3: odd/even
   const bool dma_early = pol == 1 ? true : pol == 2 ? false : pol == 3 ? (wu & 1) == 0 : wu < 4;
   const bool relu = p.flags & SDK_GEMM_RELU;
@@ -466,18 +456,14 @@ __global__ __launch_bounds__(NT2, 2) void conv_gemm256_kernel(Params p) {
     // the halves, so they complete under the second half instead of being waited for right after issue.
     // The WEIGHT fragment is the MFMA's row operand: a lane then holds 4 CONSECUTIVE output columns
     // (fq*4 + r) of one output row (fr), which the epilogue packs into one 8-byte LDS write.
-    // Priority experiments (A/B knobs, MI355X_MICROARCH.md "Two waves per SIMD" items 2-4): default = every wave raises its priority around an MFMA
-    // cluster.  prio_mode 1 (gemm_variant 32770): waves 4-7 - the younger half, the arbitration loser - use level 2 there, waves 0-3 level 1.
-    // prio_mode 2 (gemm_variant 65538): no flips at all; waves 4-7 run at level 1 for the whole kernel (set once before the tile loop).
     auto mma_half = [&](const bf16x8* af, const bf16x8* bf, int mh, int part) {
-      if (prio_mode == 0) __builtin_amdgcn_s_setprio(1);
-      else if (prio_mode == 1) { if (wu >= 4) __builtin_amdgcn_s_setprio(2); else __builtin_amdgcn_s_setprio(1); }
+      __builtin_amdgcn_s_setprio(1);
 #pragma unroll
       for (int mi = 2 * part; mi < 2 * part + 2; ++mi)
 #pragma unroll
         for (int ni = 0; ni < 4; ++ni)
           acc[mh * 4 + mi][ni] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(bf[ni], af[mi], acc[mh * 4 + mi][ni], 0, 0, 0);
-      if (prio_mode != 2) __builtin_amdgcn_s_setprio(0);
+      __builtin_amdgcn_s_setprio(0);
     };
 
     // Software pipeline over the K-tiles, one barrier per K-tile placed BEFORE the last MFMA sub-phase:
