@@ -156,12 +156,15 @@ def precision_modes(eng, pcm, pcm_host, P_host, Pn, Pb, rpm, default_value, defa
             return E, eng.affinity_topk(E, Eb, re, Pn, Pb, rpm, k=1)
         step()
         torch.cuda.synchronize()
-        t0 = time.perf_counter()
         reps = 4
-        for _ in range(reps):
-            E, (gi, gs) = step()
-        torch.cuda.synchronize()
-        ms = (time.perf_counter() - t0) / reps * 1e3
+        batches = []
+        for _ in range(3):                      # median of three batches of `reps` steps (a one-off platform stall inside a 100-ms window would halve the figure)
+            t0 = time.perf_counter()
+            for _ in range(reps):
+                E, (gi, gs) = step()
+            torch.cuda.synchronize()
+            batches.append((time.perf_counter() - t0) / reps * 1e3)
+        ms = sorted(batches)[1]
         eng.profile_begin()
         step()
         prof = eng.profile_end()
@@ -177,7 +180,7 @@ def precision_modes(eng, pcm, pcm_host, P_host, Pn, Pb, rpm, default_value, defa
                         "id_mismatches": default_parity["id_mismatches"] if default_parity else None,
                         "parity_sample": f"{default_parity['segments']} segments x {default_parity['profiles']} profiles vs the fp32 oracle" if default_parity else None},
             "precise": {"precision": 1, "operands": "fp16 hi+lo planes, 3 MFMAs per product, fp32 accumulate (sdk_set_option precision 1)",
-                        "value": round(B / ms * 1e3, 1), "unit": "segment-embeddings/sec", "ms_per_step": round(ms, 3), "steps_timed": reps,
+                        "value": round(B / ms * 1e3, 1), "unit": "segment-embeddings/sec", "ms_per_step": round(ms, 3), "steps_timed": reps, "batches_ms": [round(b, 3) for b in batches],
                         "max_abs_dscore_all_pairs": par["max_abs_dscore_all_pairs"], "max_abs_dscore_top1": par["max_abs_dscore_top1"],
                         "id_mismatches": par["id_mismatches"], "min_cos_embedding": par["min_cos_embedding"],
                         "parity_sample": f"{m} segments x {P_host.shape[0]} profiles vs the un-rounded oracle (float64 accumulation)",
@@ -207,11 +210,14 @@ def xvector_object(eng, pcm, pcm_host, P_host, Pn, Pb, rpm, n_par=16):
         for _ in range(2):
             step()
         torch.cuda.synchronize()
-        t0 = time.perf_counter()
-        for _ in range(reps):
-            E, (gi, gs) = step()
-        torch.cuda.synchronize()
-        ms = (time.perf_counter() - t0) / reps * 1e3
+        batches = []
+        for _ in range(3):                      # median of three batches: a 20-100 ms window is easily hit by a one-off platform stall (section 6)
+            t0 = time.perf_counter()
+            for _ in range(reps):
+                E, (gi, gs) = step()
+            torch.cuda.synchronize()
+            batches.append((time.perf_counter() - t0) / reps * 1e3)
+        ms = sorted(batches)[1]
         eng.profile_begin()
         step()
         return ms, eng.profile_end(), E[:m].cpu().numpy(), gi[:m, 0].cpu().numpy(), gs[:m, 0].cpu().numpy()

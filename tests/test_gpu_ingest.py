@@ -127,3 +127,27 @@ def test_backend_ingest_path_equals_host_cut_windows(tmp_path, monkeypatch):
     for w, (_, S, row, _, _) in enumerate(wins):
         want = be.embed_windows(pcm_by_len[S])[0][row]
         assert torch.equal(ra[0][w], want)
+
+
+def test_ingest_edge_cases(engine, tmp_path, monkeypatch):
+    """Empty tables, a recording shorter than a window (one zero-padded window), a recording too short to analyse (the error the CLI prints), and a
+    window table far larger than the staging slots' first size (they grow)."""
+    assert engine.embed_from_host(_recording(1.0, 2), {}) == {}
+    with pytest.raises(SdkError, match="empty batch"):
+        engine.fbank_windows(1, 100, 1, 0, 32000)
+    short = _recording(1.2, 4)                                     # 19 200 samples < one 2-s window
+    st, spans, W = wav.window_starts(len(short), None)
+    assert st.tolist() == [0] and W == 32000
+    got = engine.embed_from_host(short, {W: st})[W][0]
+    want = engine.embed_pcm(torch.from_numpy(wav.materialise_windows(short, st, W)).cuda())[0]
+    torch.cuda.synchronize()
+    assert torch.equal(got, want)
+    monkeypatch.setenv("SPEAKERS_EMBEDDINGS_DIR", str(tmp_path / "store"))
+    be = sub("backend").Backend()
+    wav.write_wav_s16(tmp_path / "tiny.wav", _recording(0.3, 5))
+    with pytest.raises(ValueError, match="no analysable audio"):
+        be.enroll_speaker(tmp_path / "tiny.wav")
+    long = _recording(40.0, 6)
+    dense = np.arange(0, len(long) - 8000, 100, dtype=np.int32)     # 6320 windows of 0.5 s: more than the slots' initial 4096-entry table
+    out = engine.embed_from_host(long, {8000: dense}, step=4096)[8000]
+    assert out[0].shape == (len(dense), 192) and bool(torch.isfinite(out[0]).all())
