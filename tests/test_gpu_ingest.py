@@ -133,7 +133,7 @@ def test_ingest_edge_cases(engine, tmp_path, monkeypatch):
     """Empty tables, a recording shorter than a window (one zero-padded window), a recording too short to analyse (the error the CLI prints), and a
     window table far larger than the staging slots' first size (they grow)."""
     assert engine.embed_from_host(_recording(1.0, 2), {}) == {}
-    with pytest.raises(SdkError, match="empty batch"):
+    with pytest.raises(SdkError, match="empty batch|null argument"):
         engine.fbank_windows(1, 100, 1, 0, 32000)
     short = _recording(1.2, 4)                                     # 19 200 samples < one 2-s window
     st, spans, W = wav.window_starts(len(short), None)
