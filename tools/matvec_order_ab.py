@@ -1,6 +1,7 @@
 #!/usr/bin/env python3
 """Round 4: the mat-vec's range order (ranges sorted by start stage, 32 neighbours per XCD: matvec_variant 0) against the plain map blockIdx -> range
-(matvec_variant 2), interleaved, HIP events; Y must be bit-identical (the work of a range does not depend on who runs it)."""
+(matvec_variant 2), interleaved, HIP events; Y must be bit-identical (the work of a range does not depend on who runs it).
+The kernel change it measured is NOT in the tree (no effect: DESIGN 5.17): apply tools/probe/matvec_range_order.patch to reproduce."""
 import importlib, sys
 from pathlib import Path
 import torch
