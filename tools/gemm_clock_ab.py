@@ -17,7 +17,8 @@ for name, N, Cin in (("tdnn 1024x1024", 1024, 1024), ("mfa 3072x3072", 3072, 307
     A0, W0 = torch.zeros_like(A), torch.zeros_like(W)
     Ap = torch.relu(A.float()).bfloat16()                       # post-ReLU-like: half the elements exactly zero, the rest positive
     bias = torch.randn(N, device="cuda"); sc = torch.rand(N, device="cuda") + 0.5; sh = torch.randn(N, device="cuda")
-    arms = [("v2 random", 2, A, W), ("v3 random", 258, A, W), ("v2 zeros", 2, A0, W0), ("v2 relu-like A", 2, Ap, W)]
+    arms = [("v2 random", 2, A, W), ("v3 random", 258, A, W), ("v2 zeros", 2, A0, W0), ("v2 relu-like A", 2, Ap, W),
+            ("v2 A random, W zero", 2, A, W0), ("v2 A zero, W random", 2, A0, W)]     # all products zero either way: what is left is the cost of MOVING one random operand
     res = {a[0]: {"us": [], "mhz": []} for a in arms}
     for rnd in range(7):
         for label, var, a, w in arms:
