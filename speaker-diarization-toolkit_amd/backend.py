@@ -395,6 +395,37 @@ class Backend(EmbeddingBackend):
             idx, sc = self.score_windows(E, Eb, re, batch)
         return aggregate_matches(idx[:, 0], sc[:, 0], spans, batch, threshold)
 
+    def identify_many(self, audio_paths: List[Path], candidates: List[Dict[str, Any]], threshold: float = 0.354) -> List[List[Dict[str, Any]]]:
+        """identify_speaker over SEVERAL recordings against one candidate set, as one pipelined pass (an extension: the reference's contract is one
+        recording per call, base.py:130-151, and gets its concurrency from up to four CLI processes, speaker-process:627-629).  The profiles are
+        loaded and uploaded once; every recording is decoded, handed to the staging slots and its kernels enqueued WITHOUT waiting for the previous
+        one - the upload of recording i + 1 runs under the forward pass of recording i (csrc/ingest.hip) - and the host synchronises once, at the end.
+        Row lists equal identify_speaker's, recording by recording (tests/test_gpu_ingest.py)."""
+        batch = self.last_batch = load_profile_batch(candidates, self.name, model_prefix=f"{self.name}-", model_version=self.model_version,
+                                                     settings=self.numerics())
+        for why in batch.skipped:
+            print(f"mi355x backend: skipped embedding {why}", file=sys.stderr)
+        if batch.all_skipped_message():
+            raise ValueError(batch.all_skipped_message())
+        if len(batch) == 0:
+            return [[] for _ in audio_paths]
+        if self.lite:                       # the torch-free path downloads per recording (everything on the null stream): sequential
+            out = []
+            for path in audio_paths:
+                samples, starts, W, spans = self._windows(path, None)
+                _, idx, sc = self.embed_tables_host(samples, {W: starts}, batch)[W]
+                out.append(aggregate_matches(idx[:, 0], sc[:, 0], spans, batch, threshold))
+            return out
+        eng = self.engine()
+        Pn, Pb, rpm = self.profile_tensors(batch)
+        pending = []
+        for path in audio_paths:
+            samples, starts, W, spans = self._windows(path, None)
+            E, Eb, re = self.embed_tables(samples, {W: starts})[W]
+            idx, sc = eng.affinity_topk(E, Eb, re, Pn, Pb, rpm, k=1)      # enqueued; nothing waits here
+            pending.append((idx, sc, spans))
+        return [aggregate_matches(idx.cpu().numpy()[:, 0], sc.cpu().numpy()[:, 0], spans, batch, threshold) for idx, sc, spans in pending]
+
     # ---- a3: verify - the CLI reads result['confidence'] (speaker_detection:1173-1174) ---------
     def verify_speaker(self, audio_path: Path, speaker_profile: Dict[str, Any], threshold: float = 0.354) -> Dict[str, Any]:
         hits = self.identify_speaker(audio_path, [speaker_profile], threshold)

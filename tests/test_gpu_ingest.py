@@ -151,3 +151,27 @@ def test_ingest_edge_cases(engine, tmp_path, monkeypatch):
     dense = np.arange(0, len(long) - 8000, 100, dtype=np.int32)     # 6320 windows of 0.5 s: more than the slots' initial 4096-entry table
     out = engine.embed_from_host(long, {8000: dense}, step=4096)[8000]
     assert out[0].shape == (len(dense), 192) and bool(torch.isfinite(out[0]).all())
+
+
+def test_identify_many_equals_identify_speaker_per_recording(tmp_path, monkeypatch):
+    """Backend.identify_many: several recordings against one candidate set in one pipelined pass (profiles uploaded once, recording i + 1 uploaded
+    under recording i's forward, one host synchronisation): the row lists must equal identify_speaker's, recording by recording."""
+    from test_gpu_backend_e2e import _voice
+    monkeypatch.setenv("SPEAKERS_EMBEDDINGS_DIR", str(tmp_path / "store"))
+    be = sub("backend").Backend()
+    profiles = []
+    for i, (sid, f0) in enumerate((("alice", 140.0), ("bob", 95.0), ("carol", 210.0))):
+        p = tmp_path / f"enroll_{sid}.wav"
+        wav.write_wav_s16(p, _voice(10 + i, 6.0, f0))
+        rec = be.enroll_speaker(p)
+        profiles.append({"id": sid, "embeddings": {"mi355x": [{"id": f"emb-{sid}", "external_id": rec["external_id"], "model_version": rec["model_version"]}]}})
+    paths = []
+    for i, parts in enumerate(([(95.0, 4.0), (140.0, 4.0)], [(210.0, 7.5)], [(140.0, 3.0), (210.0, 3.0), (95.0, 3.0)], [(95.0, 2.2)], [(140.0, 9.0), (95.0, 5.0)])):
+        rec = np.concatenate([_voice(50 + 7 * i + j, sec, f0) for j, (f0, sec) in enumerate(parts)])
+        paths.append(tmp_path / f"meeting{i}.wav")
+        wav.write_wav_s16(paths[-1], rec)
+    many = be.identify_many(paths, profiles, threshold=-1.0)
+    one_by_one = [be.identify_speaker(p, profiles, threshold=-1.0) for p in paths]
+    assert many == one_by_one and len(many) == 5 and all(len(r) >= 1 for r in many)
+    assert many[1][0]["speaker_id"] == "carol" and many[3][0]["speaker_id"] == "bob"
+    assert be.identify_many([], profiles) == []
