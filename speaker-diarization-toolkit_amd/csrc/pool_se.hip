@@ -244,59 +244,71 @@ __global__ __launch_bounds__(KW * 64) void rows_fc_mfma_kernel(const float* __re
   const int kw = Cin / KW;                                 // K range of this wave (multiple of 8)
   const float* ap = in + (int64_t)row * ldin + wid * kw + 4 * hh;
   const float* bp = wt + (int64_t)(wid * kw + 4 * hh) * Nout + colw;
-  const float* sp = isc ? isc + wid * kw + 4 * hh : nullptr;
-  const float* tp = isc ? ish + wid * kw + 4 * hh : nullptr;
+  // the input affine (the final FC's folded ASP batch-norm), when given: staged once per workgroup in dynamic LDS [2][Cin] - it depends on k only,
+  // and carrying it in the fetch ring would cost 8 registers per slot
+  extern __shared__ __attribute__((aligned(16))) float aff[];
+  if (isc) {
+    for (int e = tid; e < Cin; e += KW * 64) { aff[e] = isc[e]; aff[Cin + e] = ish[e]; }
+    __syncthreads();
+  }
+  const float* sp = isc ? aff + wid * kw + 4 * hh : nullptr;
   f32x16 acc;
 #pragma unroll
   for (int r = 0; r < 16; ++r) acc[r] = 0.f;
-  // software pipeline: the operands of group g+1 (8 k) are in flight while group g feeds the matrix pipe
-  auto fetch = [&](int g, f32x4& a, float* b) {
-    a = *reinterpret_cast<const f32x4*>(ap + g);
+  // software pipeline: a ring of D register slots, the operands of groups g+1 .. g+D-1 (8 k each) in flight while group g feeds the matrix pipe
+  // (rounds 1-3 ran one group ahead).  The input affine is applied when a slot is consumed (from LDS), so a fetch is loads only.  What bounds the
+  // 6144-long FCs is the fp32 matrix pipe, not latency: 192 `32x32x2` MFMAs x 64 cycles x 4 waves per SIMD = 23 us on the 128-192 workgroups
+  // (32 x 32 output tiles of a 1000-row problem) of a 45-55 us launch; the deeper ring buys 5-15 % (`tools/rows_fc_bench.py`: 55 -> 50, 14 -> 12 us).
+  constexpr int D = WLDS ? 8 : 4;
+  const int ng = kw >> 3;
+  f32x4 ra[D], rw[D];
+  const float* wq = WLDS ? wt + (int64_t)(wid * kw + (lane >> 3)) * Nout + n0 + (lane & 7) * 4 : nullptr;
+  auto fetch = [&](int g, int d) {
+    ra[d] = *reinterpret_cast<const f32x4*>(ap + 8 * g);
+    if (WLDS) {
+      // A group's weights [8 k][32 outputs] = 1 KiB = ONE 16-byte load per lane (lane -> k = lane >> 3, 4 outputs) instead of
+      // four 4-byte column loads per lane: the long-K FCs are bound by L2 request rate.
+      rw[d] = *reinterpret_cast<const f32x4*>(wq + (int64_t)(8 * g) * Nout);
+    } else {
+#pragma unroll
+      for (int u = 0; u < 4; ++u) rw[d][u] = bp[(int64_t)(8 * g + u) * Nout];
+    }
+  };
+  // Every fetch is UNCONDITIONAL (the group index is clamped, the tail re-fetches the last group into slots nobody reads): a fetch under a branch
+  // makes hipcc's wait-count pass join two different load histories and fall back to vmcnt(0) after every load - the ring then pipelines nothing.
+#pragma unroll
+  for (int d = 0; d < D; ++d) fetch(min(d, ng - 1), d);
+  // (WLDS) the weight tile is private to the wave (same-wave LDS operations execute in order), so no barrier is involved.
+  float* tw = &wtile[WLDS ? wid : 0][(lane >> 3) * 32 + (lane & 7) * 4];
+  const float* tr = &wtile[WLDS ? wid : 0][(4 * hh) * 32 + i];
+  auto consume = [&](int g, int d) {
+    f32x4 a = ra[d];
+    const f32x4 w4 = rw[d];
     if (sp) {
-      const f32x4 s4 = *reinterpret_cast<const f32x4*>(sp + g), t4 = *reinterpret_cast<const f32x4*>(tp + g);
+      const f32x4 s4 = *reinterpret_cast<const f32x4*>(sp + 8 * g), t4 = *reinterpret_cast<const f32x4*>(sp + Cin + 8 * g);
 #pragma unroll
       for (int u = 0; u < 4; ++u) a[u] = a[u] * s4[u] + t4[u];
     }
-    if (!WLDS) {
+    if (WLDS) {
+      *reinterpret_cast<f32x4*>(tw) = w4;
 #pragma unroll
-      for (int u = 0; u < 4; ++u) b[u] = bp[(int64_t)(g + u) * Nout];
+      for (int u = 0; u < 4; ++u) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a[u], tr[u * 32], acc, 0, 0, 0);
+    } else {
+#pragma unroll
+      for (int u = 0; u < 4; ++u) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a[u], w4[u], acc, 0, 0, 0);
     }
   };
-  f32x4 fa0, fa1;
-  float fb0[4], fb1[4];
-  if (WLDS) {
-    // A group's weights [8 k][32 outputs] = 1 KiB = ONE 16-byte load per lane (lane -> k = lane >> 3, 4 outputs) instead of
-    // four 4-byte column loads per lane: the long-K FCs are bound by L2 request rate.  The tile is private to the wave
-    // (same-wave LDS operations execute in order), so no barrier is involved.
-    const float* wq = wt + (int64_t)(wid * kw + (lane >> 3)) * Nout + n0 + (lane & 7) * 4;
-    float* tw = &wtile[wid][(lane >> 3) * 32 + (lane & 7) * 4];
-    const float* tr = &wtile[wid][(4 * hh) * 32 + i];
-    f32x4 wcur = *reinterpret_cast<const f32x4*>(wq), wnxt = wcur;
-    fetch(0, fa0, fb0);
-    for (int g = 0; g < kw; g += 8) {
-      if (g + 8 < kw) {
-        wnxt = *reinterpret_cast<const f32x4*>(wq + (int64_t)(g + 8) * Nout);
-        fetch(g + 8, fa1, fb1);
-      }
-      *reinterpret_cast<f32x4*>(tw) = wcur;
+  const int nfull = ng / D * D;
+  for (int g0 = 0; g0 < nfull; g0 += D) {
 #pragma unroll
-      for (int u = 0; u < 4; ++u) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(fa0[u], tr[u * 32], acc, 0, 0, 0);
-      wcur = wnxt;
-      fa0 = fa1;
-    }
-  } else {
-  fetch(0, fa0, fb0);
-  for (int g = 0; g < kw; g += 16) {
-    if (g + 8 < kw) fetch(g + 8, fa1, fb1);
-#pragma unroll
-    for (int u = 0; u < 4; ++u) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(fa0[u], fb0[u], acc, 0, 0, 0);
-    if (g + 8 < kw) {
-      if (g + 16 < kw) fetch(g + 16, fa0, fb0);
-#pragma unroll
-      for (int u = 0; u < 4; ++u) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(fa1[u], fb1[u], acc, 0, 0, 0);
+    for (int d = 0; d < D; ++d) {
+      consume(g0 + d, d);
+      fetch(min(g0 + d + D, ng - 1), d);
     }
   }
-  }
+#pragma unroll
+  for (int d = 0; d < D; ++d)
+    if (nfull + d < ng) consume(nfull + d, d);
 #pragma unroll
   for (int r = 0; r < 16; ++r) red[wid][((r & 3) + 8 * (r >> 2) + 4 * hh) * 33 + i] = acc[r];
   __syncthreads();
@@ -867,16 +879,23 @@ extern "C" int sdk_rows_fc(sdk_ctx* ctx, const float* in, int64_t ldin, const fl
   SDK_REQUIRE((in_scale == nullptr) == (in_shift == nullptr), "sdk_rows_fc: in_scale and in_shift go together");
   SDK_REQUIRE(act >= 0 && act <= 2, "sdk_rows_fc: act=%d", act);
   ProfScope ps(ctx, stream, SDK_K_ROWS_FC, 2.0 * B * Cin * Nout, 4.0 * ((double)B * Cin + (double)Cin * Nout + (double)B * Nout));
-  const bool mfma_ok = ldin % 4 == 0 && ((uintptr_t)in % 16) == 0 && (!in_scale || (((uintptr_t)in_scale | (uintptr_t)in_shift) % 16) == 0);
+  constexpr int kAffMax = 64 * 1024;                         // dynamic LDS of the MFMA kernels (beside up to 84 KB static): an input affine of Cin <= 8192
+  const bool mfma_ok = ldin % 4 == 0 && ((uintptr_t)in % 16) == 0 && (!in_scale || (size_t)Cin * 8 <= (size_t)kAffMax);
+  if (in_scale && mfma_ok) {
+    if (sdk_lds_optin(ctx, (const void*)rows_fc_mfma_kernel<16, true>, kAffMax)) return 1;
+    if (sdk_lds_optin(ctx, (const void*)rows_fc_mfma_kernel<16, false>, kAffMax)) return 1;
+    if (sdk_lds_optin(ctx, (const void*)rows_fc_mfma_kernel<4, false>, kAffMax)) return 1;
+  }
   const bool wlds_ok = Nout % 32 == 0 && ((uintptr_t)wt % 16) == 0;
+  const size_t aff_bytes = in_scale ? (size_t)Cin * 8 : 0;      // the MFMA kernels stage the input affine in dynamic LDS ([2][Cin] fp32)
   if (mfma_ok && Cin % 128 == 0 && Cin >= 2048 && wlds_ok)   // long K (context bias, final FC): 16 K-slices, weights as 16-byte rows via LDS
-    hipLaunchKernelGGL((rows_fc_mfma_kernel<16, true>), dim3(ceil_div(B, 32), ceil_div(Nout, 32)), dim3(1024), 0, (hipStream_t)stream,
+    hipLaunchKernelGGL((rows_fc_mfma_kernel<16, true>), dim3(ceil_div(B, 32), ceil_div(Nout, 32)), dim3(1024), aff_bytes, (hipStream_t)stream,
                        in, ldin, in_scale, in_shift, wt, bias, out, ldout, B, Cin, Nout, act);
   else if (mfma_ok && Cin % 128 == 0 && Cin >= 2048)
-    hipLaunchKernelGGL(rows_fc_mfma_kernel<16>, dim3(ceil_div(B, 32), ceil_div(Nout, 32)), dim3(1024), 0, (hipStream_t)stream,
+    hipLaunchKernelGGL(rows_fc_mfma_kernel<16>, dim3(ceil_div(B, 32), ceil_div(Nout, 32)), dim3(1024), aff_bytes, (hipStream_t)stream,
                        in, ldin, in_scale, in_shift, wt, bias, out, ldout, B, Cin, Nout, act);
   else if (mfma_ok && Cin % 32 == 0)
-    hipLaunchKernelGGL(rows_fc_mfma_kernel<4>, dim3(ceil_div(B, 32), ceil_div(Nout, 32)), dim3(NT), 0, (hipStream_t)stream,
+    hipLaunchKernelGGL(rows_fc_mfma_kernel<4>, dim3(ceil_div(B, 32), ceil_div(Nout, 32)), dim3(NT), aff_bytes, (hipStream_t)stream,
                        in, ldin, in_scale, in_shift, wt, bias, out, ldout, B, Cin, Nout, act);
   else
     hipLaunchKernelGGL(rows_fc_kernel, dim3(ceil_div(B, FC_ROWS), ceil_div(Nout, FC_OUT)), dim3(NT), 0, (hipStream_t)stream,
