@@ -137,7 +137,8 @@ int sdk_fbank_windows(sdk_ctx* ctx, const int16_t* samples, int64_t n_samples, c
  *      upload of recording i + 1 runs under the forward pass of recording i.  A slot = pinned host buffers for max_samples int16 and
  *      max_windows int32 window starts + their device twins.
  *   sdk_ingest_acquire : next slot (ring order); *pinned_samples / *pinned_starts are HOST pointers the caller fills (a file reader can
- *                        read straight into them: no second host copy).  Fails if that slot was committed and never released.
+ *                        read straight into them: no second host copy).  Fails if that slot was committed and never released; a slot
+ *                        acquired and never committed (its filler gave up) is handed out again when the ring comes round.
  *   sdk_ingest_commit  : validates the start table (every start inside [0, n_samples)), enqueues the uploads on the copy stream - behind the
  *                        slot's previous consumer, without blocking the host - and makes `compute_stream` wait for them;
  *                        *dev_samples / *dev_starts are DEVICE pointers for sdk_fbank_windows (any sub-range of the table may be launched)

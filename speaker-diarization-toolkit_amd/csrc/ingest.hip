@@ -102,7 +102,8 @@ extern "C" int sdk_ingest_create(sdk_ctx* ctx, int64_t max_samples, int max_wind
 extern "C" int sdk_ingest_acquire(sdk_ingest* g, int* ticket, int16_t** pinned_samples, int32_t** pinned_starts) {
   SDK_REQUIRE(g && ticket && pinned_samples && pinned_starts, "sdk_ingest_acquire: null argument");
   auto& s = g->slot[g->next];
-  SDK_REQUIRE(s.state == 0 || s.state == 3, "sdk_ingest_acquire: all %d slots are in flight (slot %d was committed but never released: call sdk_ingest_release "
+  // (a slot that was acquired but never committed - its filler failed - has nothing enqueued and is simply handed out again)
+  SDK_REQUIRE(s.state != 2, "sdk_ingest_acquire: all %d slots are in flight (slot %d was committed but never released: call sdk_ingest_release "
               "after the last kernel that reads it has been enqueued)", g->depth, g->next);
   if (s.ever_copied) SDK_HIP_OK(hipEventSynchronize(s.copied));     // the previous upload has left the pinned buffers (it finished long ago unless depth == 1)
   s.state = 1;

@@ -103,6 +103,11 @@ def test_ingest_refuses_bad_tables_and_unreleased_slots(engine):
     engine.lib.sdk_memcpy(engine.ctx, back.data_ptr(), ds, len(rec) * 2, 3, st)
     ing.release(t, st)
     assert np.array_equal(back.cpu().numpy(), rec)
+    # a filler that gives up between acquire and commit does not wedge the ring: the slot comes round again
+    seen = [ing.pinned(len(rec), 1)[0] for _ in range(5)]
+    assert seen == [seen[0], 1 - seen[0]] * 2 + [seen[0]]
+    t3, _, _ = ing.submit(rec, np.array([0], np.int32), 8000, st)
+    ing.release(t3, st)
     ing.close()
 
 
