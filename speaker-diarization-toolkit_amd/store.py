@@ -272,6 +272,7 @@ def load_profile_batch(candidates: List[Dict[str, Any]], backend_name: str, mode
         if hit is not None:
             return hit
     rows, sids, eids, trusts, skipped, warns = [], [], [], [], [], []
+    unreadable = 0
     for prof in candidates:
         sid = prof.get("id")
         for rec in prof.get("embeddings", {}).get(backend_name, []) or []:
@@ -287,6 +288,7 @@ def load_profile_batch(candidates: List[Dict[str, Any]], backend_name: str, mode
                 vec = load_vector(ext, root)
             except (ValueError, OSError) as exc:
                 skipped.append(f"{tag}: {exc}")
+                unreadable += 1
                 continue
             if link and sid and rec.get("id"):
                 adopt(ext, sid, rec["id"], root)
@@ -301,7 +303,9 @@ def load_profile_batch(candidates: List[Dict[str, Any]], backend_name: str, mode
             trusts.append(rec.get("trust_level", "unknown"))
     mat = np.stack(rows).astype(np.float32) if rows else np.zeros((0, EMBED_DIM), np.float32)
     batch = ProfileBatch(mat, sids, eids, trusts, skipped, warns)
-    if use_pack and len(batch) >= pack_min_rows():
+    # a set with an unreadable / missing vector file is not packed: the digest is over the records' keys, so the file turning up later (a store
+    # copied after its database) would not invalidate a pack that had recorded it as skipped
+    if use_pack and len(batch) >= pack_min_rows() and not unreadable:
         digest = candidate_digest(candidates, backend_name, model_prefix, model_version, settings)
         batch.pack_ref = _pack_paths(root, model_version, digest) + (digest,)
     return batch

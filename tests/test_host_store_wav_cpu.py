@@ -403,6 +403,26 @@ def test_profile_pack_goes_stale_with_the_candidate_set(tmp_path, monkeypatch):
     assert not store.load_profile_batch(cands, "mi355x", **kw).from_pack
 
 
+def test_profile_pack_is_not_built_over_an_unreadable_vector(tmp_path, monkeypatch):
+    """The digest is over the records' keys: a set with a missing vector file must not be packed, or the file turning up later (a store copied
+    after its database) would stay "skipped" for ever."""
+    monkeypatch.setenv("SPEAKERS_EMBEDDINGS_DIR", str(tmp_path))
+    vecs, cands = _enrol(20)
+    kw = dict(model_prefix="mi355x-", model_version="mi355x-ecapa1024-x")
+    victim = next(f for f in (tmp_path / "embeddings" / "by-hash").glob("*.npy")
+                  if np.array_equal(np.load(f, allow_pickle=False).astype(np.float32).reshape(-1), vecs[7]))
+    raw = victim.read_bytes()
+    victim.unlink()
+    b = store.load_profile_batch(cands, "mi355x", **kw)
+    assert len(b) == 19 and len(b.skipped) == 1 and b.pack_ref is None and not b.from_pack
+    assert store.publish_pack(b, *_fake_norm(b.matrix)) is None
+    victim.write_bytes(raw)
+    b = store.load_profile_batch(cands, "mi355x", **kw)
+    assert len(b) == 20 and not b.skipped and b.pack_ref is not None
+    store.publish_pack(b, *_fake_norm(b.matrix))
+    assert store.load_profile_batch(cands, "mi355x", **kw).from_pack
+
+
 def test_profile_pack_is_bounded(tmp_path, monkeypatch):
     monkeypatch.setenv("SPEAKERS_EMBEDDINGS_DIR", str(tmp_path))
     _, cands = _enrol(60)
