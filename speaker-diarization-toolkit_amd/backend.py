@@ -372,7 +372,8 @@ class Backend(EmbeddingBackend):
         idx, sc = eng.affinity_topk(E, Eb, re, Pn, Pb, rpm, k=min(k, len(batch)))
         return idx.cpu().numpy(), sc.cpu().numpy()
 
-    def identify_speaker(self, audio_path: Path, candidates: List[Dict[str, Any]], threshold: float = 0.354) -> List[Dict[str, Any]]:
+    def _load_candidates(self, candidates: List[Dict[str, Any]]):
+        """The candidate set as one ProfileBatch (pack hit or file by file), with everything a user must hear about it on stderr."""
         batch = self.last_batch = load_profile_batch(candidates, self.name, model_prefix=f"{self.name}-", model_version=self.model_version,
                                                      settings=self.numerics())
         for why in batch.skipped:
@@ -385,6 +386,10 @@ class Backend(EmbeddingBackend):
             # candidates exist but none is comparable: "no match" would be a lie.  The CLI prints "Error during identification: ..."
             # and exits 1 (speaker_detection:1072-1074); speaker-assign then records no embedding signal (speaker-assign:296)
             raise ValueError(batch.all_skipped_message())
+        return batch
+
+    def identify_speaker(self, audio_path: Path, candidates: List[Dict[str, Any]], threshold: float = 0.354) -> List[Dict[str, Any]]:
+        batch = self._load_candidates(candidates)
         if len(batch) == 0:
             return []
         samples, starts, W, spans = self._windows(audio_path, None)
@@ -401,12 +406,7 @@ class Backend(EmbeddingBackend):
         loaded and uploaded once; every recording is decoded, handed to the staging slots and its kernels enqueued WITHOUT waiting for the previous
         one - the upload of recording i + 1 runs under the forward pass of recording i (csrc/ingest.hip) - and the host synchronises once, at the end.
         Row lists equal identify_speaker's, recording by recording (tests/test_gpu_ingest.py)."""
-        batch = self.last_batch = load_profile_batch(candidates, self.name, model_prefix=f"{self.name}-", model_version=self.model_version,
-                                                     settings=self.numerics())
-        for why in batch.skipped:
-            print(f"mi355x backend: skipped embedding {why}", file=sys.stderr)
-        if batch.all_skipped_message():
-            raise ValueError(batch.all_skipped_message())
+        batch = self._load_candidates(candidates)
         if len(batch) == 0:
             return [[] for _ in audio_paths]
         if self.lite:                       # the torch-free path downloads per recording (everything on the null stream): sequential
