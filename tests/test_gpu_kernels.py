@@ -213,7 +213,8 @@ def test_asp_fused_matches_unfused_oracle(engine, B, T):
 
 def test_rows_fc(engine):
     g = torch.Generator().manual_seed(3)
-    for B, Cin, Nout, act in [(7, 6144, 192, 0), (5, 6144, 128, 0), (9, 1000, 70, 1), (1, 33, 200, 2), (1000, 1024, 128, 1), (77, 128, 1024, 2), (33, 96, 40, 0)]:
+    for B, Cin, Nout, act in [(7, 6144, 192, 0), (5, 6144, 128, 0), (9, 1000, 70, 1), (1, 33, 200, 2), (1000, 1024, 128, 1), (77, 128, 1024, 2), (33, 96, 40, 0),
+                               (3, 8192, 64, 0), (3, 8320, 64, 0)]:      # input affine in LDS at its 64-KB limit / past it (plain kernel)
         x = torch.randn(B, Cin, generator=g)
         wt = torch.randn(Cin, Nout, generator=g) / Cin ** 0.5
         bias, isc, ish = torch.randn(Nout, generator=g), torch.rand(Cin, generator=g) + 0.5, torch.randn(Cin, generator=g)
