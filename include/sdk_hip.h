@@ -80,7 +80,8 @@ int sdk_stream_synchronize(sdk_ctx* ctx, void* stream);
  * 0 = the chain ignores the blob's optional fragment-ordered weight copies, ecapa_layout.h EL_CHAINPACK), "res2net_two_per_cu" (1 default /
  * 0 = 8-wave workgroups, one segment per CU), "asp_packed_weights"
  * (likewise for the ASP logit weights, EL_ASP_W2PACK), "asp_per_segment"
- * (1 default / 0 = one workgroup per (segment, 128 channels)), "affinity_fast_path" / "affinity_variant" /
+ * (1 default / 0 = one workgroup per (segment, 128 channels)), "h_kblocked" (1 default / 0 = sdk_ecapa_forward keeps the MFA output row-major
+ * instead of K-blocked, SDK_GEMM_C_KBLOCKED below), "affinity_fast_path" / "affinity_variant" /
  * "affinity_whole_groups" / "affinity_boundary_penalty" (k = 1 affinity kernel selection and work split), "chol_pivot_rtol_ppb" / "chol_shift_ppb"
  * (sdk_chol_inverse, below), "matvec_variant" (0 default: persistent row-group kernel / 1 = round 1's
  * kernel; sums differ in the last bits only), "gemm_variant" (see sdk_set_gemm_variant).  Results do not depend on them.
@@ -161,6 +162,12 @@ int sdk_ingest_copy_ms(sdk_ingest* ing, int ticket, float* ms, double* bytes);
 
 #define SDK_GEMM_RELU 1u
 #define SDK_GEMM_TANH 2u
+/* K-BLOCKED activation layout (round 4): a [M, cols] bf16 matrix stored as [cols / 64][M][64] - element (m, c) at (c / 64) * M * 64 + m * 64 + c % 64 -
+ * so that the 128-byte row piece a GEMM K-step (or an ASP channel block) takes from a row lies next to its neighbours' instead of `ld` apart.  Made for
+ * the widest activation of the forward, the MFA output h [B*T, 3072]: written once (C_KBLOCKED: plain-layer shape of the 256^2 kernel only, ldc ignored),
+ * read by the skinny attention-hidden GEMM (A_KBLOCKED: taps == 1, lda ignored; runs on the 128^2 kernel) and by sdk_asp_fused_kblocked. */
+#define SDK_GEMM_A_KBLOCKED 4u
+#define SDK_GEMM_C_KBLOCKED 8u
 
 /* Dilated 1-D convolution over frames as one MFMA GEMM:
  *   pre[m, n] = bias[n] + ubias[m / T, n] + sum_{j<taps} sum_{c<Cin}
@@ -242,6 +249,12 @@ int sdk_asp_pool(sdk_ctx* ctx, const float* logits, int64_t ldl, const uint16_t*
 int sdk_asp_fused_max_frames(void);
 int sdk_asp_fused(sdk_ctx* ctx, const uint16_t* ah, int64_t ldah, const uint16_t* w2, const float* b2,
                   const uint16_t* h, int64_t ldh, int B, int T, int C, int A, float* pooled, void* stream);
+/* The same with h in the K-blocked layout [C / 64][B*T][64] (SDK_GEMM_C_KBLOCKED above).  Only the per-segment form reads it: where
+ * sdk_asp_kblocked_ok(ctx, T, C) is 0 (short or long windows, option asp_per_segment off) the call is an error and the caller keeps h row-major.
+ * Bit-identical to sdk_asp_fused on the same values. */
+int sdk_asp_kblocked_ok(sdk_ctx* ctx, int T, int C);
+int sdk_asp_fused_kblocked(sdk_ctx* ctx, const uint16_t* ah, int64_t ldah, const uint16_t* w2, const float* b2,
+                           const uint16_t* h, int B, int T, int C, int A, float* pooled, void* stream);
 
 /* ---- PRECISE MODE (sdk_set_option "precision" 1; north_star: cosine scores within 1e-5 of the fp32 model, which bf16 operands miss
  *      by 4e-3 - profiles/r03_error_budget.md).  Tensors the default mode rounds to bf16 travel as fp16 hi + lo PLANES: a [rows, C]

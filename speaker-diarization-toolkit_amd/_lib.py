@@ -68,6 +68,8 @@ KERNEL_FAMILIES = ["conv_gemm", "se_gate", "asp_stats", "rows_fc", "asp_pool", "
 ABI_VERSION = 3
 GEMM_RELU = 1
 GEMM_TANH = 2
+GEMM_A_KBLOCKED = 4      # A read / C written as [cols / 64][M][64] (include/sdk_hip.h)
+GEMM_C_KBLOCKED = 8
 
 _vp, _i, _i64, _sz = C.c_void_p, C.c_int, C.c_int64, C.c_size_t
 
@@ -109,6 +111,8 @@ SIGNATURES = {
     "sdk_asp_pool": (_i, [_vp, _vp, _i64, _vp, _i64, _i, _i, _i, _vp, _vp]),
     "sdk_asp_fused_max_frames": (_i, []),
     "sdk_asp_fused": (_i, [_vp, _vp, _i64, _vp, _vp, _vp, _i64, _i, _i, _i, _i, _vp, _vp]),
+    "sdk_asp_kblocked_ok": (_i, [_vp, _i, _i]),
+    "sdk_asp_fused_kblocked": (_i, [_vp, _vp, _i64, _vp, _vp, _vp, _i, _i, _i, _i, _vp, _vp]),
     "sdk_ecapa_workspace_bytes": (_sz, [C.POINTER(EcapaDesc), _i, _i]),
     "sdk_ecapa_forward": (_i, [_vp, _vp, C.POINTER(EcapaDesc), _vp, _i, _i, _i, _vp, _sz, _vp, _vp]),
     "sdk_ecapa_calib_floats": (_sz, [C.POINTER(EcapaDesc), _i]),

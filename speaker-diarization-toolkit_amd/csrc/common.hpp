@@ -33,6 +33,7 @@ struct sdk_ctx {
   bool no_chain_packed = false;   // A/B + test knob: ignore the fragment-ordered copies of the Res2Net chain weights (EL_CHAINPACK)
   bool no_asp_packed = false;     // A/B + test knob: ignore the fragment-ordered copy of the ASP logit weights (EL_ASP_W2PACK)
   bool no_asp_seg = false;        // A/B + test knob: ASP by (segment, 128-channel) workgroups instead of one per segment
+  bool no_h_kblocked = false;     // A/B + test knob: keep the MFA output h row-major (default: K-blocked [C / 64][M][64] where the per-segment ASP reads it)
   int precision = 0;              // 0: bf16 operands (default); 1: fp16 hi+lo planes, 3 MFMAs per product ("precision": hp.hip)
   int aff_fast = 1;               // k = 1 affinity: 1 = row/column-maxima kernel (affinity_rowcol.hip), 0 = general sorted-list kernel
   void* dbg_ptr = nullptr;         // diagnostics only: device buffer for the affinity kernel's time stamps (sdk_debug_set_ptr "stamps")
@@ -57,7 +58,7 @@ int sdk_lds_optin(sdk_ctx* ctx, const void* func, int bytes);
 
 // pool_se.hip: sdk_asp_fused with the optional fragment-ordered copy of w2 (internal; sdk_ecapa_forward)
 int asp_fused_launch(sdk_ctx* ctx, const uint16_t* ah, int64_t ldah, const uint16_t* w2, const uint16_t* w2p, const float* b2,
-                     const uint16_t* h, int64_t ldh, int B, int T, int C, int A, float* pooled, void* stream);
+                     const uint16_t* h, int64_t ldh, int B, int T, int C, int A, float* pooled, void* stream, bool kblocked = false);
 
 // res2net.hip: sdk_res2net_chain with the optional fragment-ordered weight copies (internal; sdk_ecapa_forward)
 int res2net_chain_launch(sdk_ctx* ctx, const uint16_t* U, int64_t ldu, uint16_t* R, int64_t ldr, const uint16_t* const* W,

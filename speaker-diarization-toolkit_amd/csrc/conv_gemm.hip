@@ -43,6 +43,8 @@ struct Params {
   int tune;
   float* stats_part; int stats_mode;   // fused per-segment column statistics (256^2 kernel only)
   const bf16_t* A2; int64_t lda2;      // optional addend of the A operand (128^2 kernel only): A := bf16(A + A2)
+  int64_t ablk, cblk;                  // K-BLOCKED operands (elements between 64-column blocks, = M * 64; 0 = row-major): A read (128^2 kernel, taps == 1) /
+                                       // C written (256^2 kernel) as [cols / 64][M][64]: every 128-byte row piece of a 64-column block is contiguous with its neighbours
   int tap_pack;                        // > 0: the taps are packed along K (W is [N][round64(taps * tap_pack)], a 16-byte chunk of 8 channels
                                        // belongs to tap chunk / (tap_pack / 8)): blk0's 5 x 80 mel channels in 7 K-steps instead of 5 x 128 in 10
   unsigned long long* clk;             // diagnostics (256^2 kernel): per workgroup {shader cycles, 100 MHz ticks} of its lifetime, or null
@@ -115,7 +117,7 @@ __global__ __launch_bounds__(NT, 2) void conv_gemm_kernel(Params p) {
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
       const int src = p.taps > 1 ? segbase[i] + reflect_idx(tloc[i] + off, p.T) : segbase[i];
-      ra[i] = *reinterpret_cast<const u32x4*>(p.A + (int64_t)src * p.lda + acol);
+      ra[i] = *reinterpret_cast<const u32x4*>(p.ablk ? p.A + (int64_t)(acol >> 6) * p.ablk + (int64_t)src * 64 + (acol & 63) : p.A + (int64_t)src * p.lda + acol);
       rb[i] = *reinterpret_cast<const u32x4*>(wrow[i] + j * cin_w + kc);
       if (p.A2) ra2[i] = *reinterpret_cast<const u32x4*>(p.A2 + (int64_t)src * p.lda2 + acol);
     }
@@ -254,7 +256,7 @@ static_assert(BM2 * BN2 * 2 <= LDS2, "the bf16 image of a finished tile must fit
 typedef const void __attribute__((address_space(1)))* gptr_t;
 typedef void __attribute__((address_space(3)))* lptr_t;
 
-template <bool TAPS>
+template <bool TAPS, bool CKB = false>   // CKB: the output is written K-blocked (Params::cblk) - its own instantiation, so the default kernel's code is untouched
 __global__ __launch_bounds__(NT2, 2) void conv_gemm256_kernel(Params p) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
@@ -568,13 +570,15 @@ __global__ __launch_bounds__(NT2, 2) void conv_gemm256_kernel(Params p) {
       // not depend on i, so every read is base + i * 8 KiB
       const int r0 = tid >> 5, cc = tid & 31;
       const char* src = smem + r0 * (BN2 * 2) + ((cc ^ (r0 & 15)) << 4);
-      bf16_t* dst = p.C + (int64_t)(m0 + r0) * p.ldc + n0 + cc * 8;
+      bf16_t* dst = CKB ? p.C + (int64_t)((n0 >> 6) + (cc >> 3)) * p.cblk + (int64_t)(m0 + r0) * 64 + (cc & 7) * 8
+                        : p.C + (int64_t)(m0 + r0) * p.ldc + n0 + cc * 8;
+      const int64_t ldc = CKB ? 64 : p.ldc;
       const int rows_left = p.M - m0 - r0;               // rows r0 + 16 i < rows_left are inside the matrix
 #pragma unroll
       for (int i = 0; i < 16; ++i) {
         if (16 * i < rows_left) {
           const u32x4 v = *reinterpret_cast<const u32x4*>(src + i * 16 * (BN2 * 2));
-          __builtin_nontemporal_store(v, reinterpret_cast<u32x4*>(dst + (int64_t)(16 * i) * p.ldc));
+          __builtin_nontemporal_store(v, reinterpret_cast<u32x4*>(dst + (int64_t)(16 * i) * ldc));
         }
       }
     }
@@ -1005,10 +1009,14 @@ extern "C" int sdk_conv_gemm(sdk_ctx* ctx, const sdk_conv_gemm_args* a, void* st
   SDK_REQUIRE(a->T > 0 && a->M % a->T == 0, "sdk_conv_gemm: M=%d must be a multiple of T=%d", a->M, a->T);
   SDK_REQUIRE((int64_t)a->N * a->taps * a->Cin < (1ll << 31), "sdk_conv_gemm: weight matrix of %d x %d elements exceeds 2^31", a->N, a->taps * a->Cin);
   SDK_REQUIRE(a->taps == 1 || (a->taps / 2) * a->dil < a->T, "sdk_conv_gemm: segment of T=%d frames shorter than the conv halo %d", a->T, (a->taps / 2) * a->dil);
+  const bool a_kb = (a->flags & SDK_GEMM_A_KBLOCKED) != 0, c_kb = (a->flags & SDK_GEMM_C_KBLOCKED) != 0;
+  if (a_kb) SDK_REQUIRE(a->taps == 1 && !pack && !a->A2, "sdk_conv_gemm: a K-blocked A operand needs taps == 1, no tap packing and no A2");
+  else
   SDK_REQUIRE(a->lda % 8 == 0 && a->lda >= a->Cin, "sdk_conv_gemm: lda=%lld must be >= Cin and a multiple of 8", (long long)a->lda);
   SDK_REQUIRE(((uintptr_t)a->A % 16) == 0 && ((uintptr_t)a->W % 16) == 0, "sdk_conv_gemm: A/W must be 16-byte aligned");
   SDK_REQUIRE(a->C || a->C32 || a->S, "sdk_conv_gemm: no output requested");
-  if (a->C) SDK_REQUIRE(a->ldc % 8 == 0 && a->ldc >= a->N && ((uintptr_t)a->C % 16) == 0, "sdk_conv_gemm: bad C/ldc");
+  if (a->C && !c_kb) SDK_REQUIRE(a->ldc % 8 == 0 && a->ldc >= a->N && ((uintptr_t)a->C % 16) == 0, "sdk_conv_gemm: bad C/ldc");
+  if (c_kb) SDK_REQUIRE(a->C && ((uintptr_t)a->C % 16) == 0, "sdk_conv_gemm: a K-blocked output needs C (16-byte aligned)");
   if (a->S) SDK_REQUIRE(a->X2 && a->lds % 8 == 0 && a->ldx2 % 8 == 0 && ((uintptr_t)a->S % 16) == 0 && ((uintptr_t)a->X2 % 16) == 0, "sdk_conv_gemm: S needs X2 and 16-byte aligned rows");
   if (a->C32) SDK_REQUIRE(a->ldc32 >= a->N, "sdk_conv_gemm: bad ldc32");
   if (a->ubias) SDK_REQUIRE(a->ldub >= a->N, "sdk_conv_gemm: bad ldub");
@@ -1019,6 +1027,7 @@ extern "C" int sdk_conv_gemm(sdk_ctx* ctx, const sdk_conv_gemm_args* a, void* st
   }
   if (sdk_lds_optin(ctx, (const void*)conv_gemm256_kernel<false>, LDS2_TOTAL)) return 1;
   if (sdk_lds_optin(ctx, (const void*)conv_gemm256_kernel<true>, LDS2_TOTAL)) return 1;
+  if (sdk_lds_optin(ctx, (const void*)conv_gemm256_kernel<false, true>, LDS2_TOTAL)) return 1;
   if (sdk_lds_optin(ctx, (const void*)conv_gemm256_v3_kernel<false, false>, LDS3_TOTAL)) return 1;
   if (sdk_lds_optin(ctx, (const void*)conv_gemm256_v3_kernel<true, false>, LDS3_TOTAL)) return 1;
   if (sdk_lds_optin(ctx, (const void*)conv_gemm256_v3_kernel<false, true>, LDS3_TOTAL)) return 1;
@@ -1033,6 +1042,8 @@ extern "C" int sdk_conv_gemm(sdk_ctx* ctx, const sdk_conv_gemm_args* a, void* st
   p.stats_part = nullptr; p.stats_mode = 0;
   p.A2 = (const bf16_t*)a->A2; p.lda2 = a->lda2;
   p.tap_pack = pack;
+  p.ablk = a_kb ? (int64_t)a->M * 64 : 0;
+  p.cblk = c_kb ? (int64_t)a->M * 64 : 0;
   p.clk = (unsigned long long*)ctx->gemm_clk_ptr;
   p.stamps = (unsigned long long*)ctx->gemm_stamps_ptr;
   if (a->A2) SDK_REQUIRE(a->lda2 % 8 == 0 && a->lda2 >= a->Cin && ((uintptr_t)a->A2 % 16) == 0, "sdk_conv_gemm: bad A2/lda2");
@@ -1040,12 +1051,15 @@ extern "C" int sdk_conv_gemm(sdk_ctx* ctx, const sdk_conv_gemm_args* a, void* st
   const double kk = pack ? (double)(((a->taps * pack + BK - 1) / BK) * BK) : (double)a->taps * a->Cin;      // K as launched
   // the 256^2 kernel covers the plain layer shape (bias / ReLU / BN affine -> bf16, optional column statistics);
   // fp32 output, residual sum, per-segment bias, tanh and the A2 addend stay with the 128^2 kernel
-  const bool use256 = (g_gemm_variant & 15) != 1 && a->N % BN2 == 0 && a->M >= BM2 && !a->A2 && a->C && !a->C32 && !a->S &&
+  const bool use256 = !a_kb && ((g_gemm_variant & 15) != 1 || c_kb) && a->N % BN2 == 0 && a->M >= BM2 && !a->A2 && a->C && !a->C32 && !a->S &&
                       !a->ubias && !(a->flags & SDK_GEMM_TANH) && (a->taps == 1 || a->T >= 64) &&
                       (uint64_t)a->M * (uint64_t)a->lda * 2u < (1ull << 32);   // the 256^2 kernel addresses A by 32-bit byte offsets
   ProfScope ps(ctx, stream, use256 ? SDK_K_CONV_GEMM256 : SDK_K_CONV_GEMM, 2.0 * a->M * a->N * kk,
                2.0 * a->M * a->Cin + 2.0 * a->N * kk + (a->C ? 2.0 : 0.0) * a->M * a->N + (a->C32 ? 4.0 : 0.0) * a->M * a->N +
                    (a->S ? 4.0 : 0.0) * a->M * a->N);
+  // K-blocked forms ([cols / 64][M][64], SDK_GEMM_*_KBLOCKED): the A read is the 128^2 kernel's (register-staged: any address form), the C write the
+  // 256^2 kernel's copy-out sweep of its LDS image
+  if (c_kb) SDK_REQUIRE(use256 && a->taps == 1, "sdk_conv_gemm: a K-blocked output needs the plain-layer shape of the 256^2 kernel (taps == 1, N %% 256 == 0, M >= 256, bf16 output only)");
   if (a->stats_mode) {
     SDK_REQUIRE(a->stats_mode == 1 || a->stats_mode == 2, "sdk_conv_gemm: stats_mode=%d", a->stats_mode);
     SDK_REQUIRE(use256 && a->T >= 128 && a->stats_part && a->C, "sdk_conv_gemm: fused column statistics need the 256^2 kernel (N %% 256 == 0, M >= 256), T >= 128 and a bf16 output");
@@ -1059,7 +1073,9 @@ extern "C" int sdk_conv_gemm(sdk_ctx* ctx, const sdk_conv_gemm_args* a, void* st
     // tune bit 4 (gemm_variant 258) selects v3, the overlapped tile boundary: bit-identical output, 6-7 % fewer cycles per
     // K = 1024 tile in the in-kernel timeline, and the same wall time in interleaved A/B (0.97-1.01x) - the chip returns the
     // saved cycles as a lower clock (DVFS give-back), so the simpler v2 stays the default
-    if ((p.tune & 16) && par_ok && !pack)
+    if (c_kb)
+      hipLaunchKernelGGL((conv_gemm256_kernel<false, true>), dim3(grid), dim3(NT2), LDS2_TOTAL, (hipStream_t)stream, p);
+    else if ((p.tune & 16) && par_ok && !pack)
     {
       const bool st = p.stats_part != nullptr, tp = p.taps > 1;
       auto kern = st ? (tp ? conv_gemm256_v3_kernel<true, true> : conv_gemm256_v3_kernel<true, false>)

@@ -659,6 +659,7 @@ extern "C" int sdk_conv_gemm_hp(sdk_ctx* ctx, const sdk_conv_gemm_hp_args* a, vo
   SDK_REQUIRE(a->lda % 8 == 0 && a->a_lo % 8 == 0 && a->a_lo >= a->Cin && a->lda >= a->a_lo + a->Cin, "sdk_conv_gemm_hp: bad lda / a_lo");
   SDK_REQUIRE(((uintptr_t)a->A % 16) == 0 && ((uintptr_t)a->W % 16) == 0, "sdk_conv_gemm_hp: A/W must be 16-byte aligned");
   SDK_REQUIRE(((int64_t)a->N * a->taps * a->Cin) % 8 == 0, "sdk_conv_gemm_hp: weight planes must be 16-byte multiples");
+  SDK_REQUIRE(!(a->flags & (SDK_GEMM_A_KBLOCKED | SDK_GEMM_C_KBLOCKED)), "sdk_conv_gemm_hp: the K-blocked layouts belong to the bf16 kernels (sdk_conv_gemm)");
   SDK_REQUIRE(a->C || a->C32 || a->S, "sdk_conv_gemm_hp: no output requested");
   if (a->C) SDK_REQUIRE(a->ldc % 8 == 0 && a->c_lo % 8 == 0 && a->c_lo >= a->N && ((uintptr_t)a->C % 16) == 0, "sdk_conv_gemm_hp: bad C planes");
   if (a->S) SDK_REQUIRE(a->X2 && a->lds % 8 == 0 && a->s_lo % 8 == 0 && a->ldx2 % 8 == 0 && a->x2_lo % 8 == 0 && ((uintptr_t)a->S % 16) == 0 && ((uintptr_t)a->X2 % 16) == 0, "sdk_conv_gemm_hp: S needs X2 planes, 16-byte aligned");

@@ -588,7 +588,9 @@ typedef void __attribute__((address_space(3)))* seg_lptr_t;
 template <bool PACKED>
 __global__ __launch_bounds__(SEG_NT, 2) void asp_seg_kernel(const bf16_t* __restrict__ ah, int64_t ldah,
                                                            const bf16_t* __restrict__ w2, const bf16_t* __restrict__ h,
-                                                           int64_t ldh, int T, int C, float* __restrict__ pooled) {
+                                                           int64_t ldh, int T, int C, float* __restrict__ pooled, int64_t hblk) {
+  // hblk != 0: h is K-BLOCKED, [C / 64][rows][64] with hblk = rows * 64 elements between 64-channel blocks and ldh = 64 (sdk_hip.h
+  // SDK_GEMM_C_KBLOCKED): a slab piece's 64-byte rows are 128 bytes apart instead of 2 ldh (-12 % on this kernel: DESIGN 5.3)
   extern __shared__ __attribute__((aligned(16))) char lds[];
   constexpr int NTILES = 7;
   const int tid = threadIdx.x, lane = tid & 63;
@@ -616,7 +618,7 @@ __global__ __launch_bounds__(SEG_NT, 2) void asp_seg_kernel(const bf16_t* __rest
   const uint32_t chunk_off = (uint32_t)((lch ^ ((lrow >> 2) & 3)) << 4);
   uint32_t voff0 = (uint32_t)lrow * (uint32_t)ldh * 2u + chunk_off;       // the per-lane part of every FULL piece's address
   auto fetch_piece = [&](int blk, int rt) {
-    const char* hb = reinterpret_cast<const char*>(h + base * ldh + blk * 32);     // wave-uniform
+    const char* hb = reinterpret_cast<const char*>(h + base * ldh + (hblk ? (int64_t)(blk >> 1) * hblk + (blk & 1) * 32 : (int64_t)blk * 32));     // wave-uniform
 #pragma unroll
     for (int i = 2 * rt; i < 2 * rt + 2 && i < SEG_ROWS / 16; ++i) {
       // address = scalar base + 32-bit lane offset; the row part of a full piece moves into the scalar base
@@ -918,22 +920,30 @@ extern "C" int sdk_asp_pool(sdk_ctx* ctx, const float* logits, int64_t ldl, cons
 extern "C" int sdk_asp_fused_max_frames(void) { return 224; }
 
 // Internal entry (sdk_ecapa_forward): w2p may be null, or the fragment-ordered copy of w2 (ecapa_layout.h EL_ASP_W2PACK).
+static bool asp_seg_ok(const sdk_ctx* ctx, int T, int C) { return T > 96 && T <= SEG_ROWS && C % 256 == 0 && !ctx->no_asp_seg; }
+
 int asp_fused_launch(sdk_ctx* ctx, const uint16_t* ah, int64_t ldah, const uint16_t* w2, const uint16_t* w2p, const float* b2,
-                     const uint16_t* h, int64_t ldh, int B, int T, int C, int A, float* pooled, void* stream) {
+                     const uint16_t* h, int64_t ldh, int B, int T, int C, int A, float* pooled, void* stream, bool kblocked) {
   SDK_REQUIRE(ctx && ah && w2 && b2 && h && pooled, "sdk_asp_fused: null argument");
+  const int64_t hblk = kblocked ? (int64_t)B * T * 64 : 0;
+  if (kblocked) {
+    SDK_REQUIRE(asp_seg_ok(ctx, T, C), "sdk_asp_fused_kblocked: only the per-segment form reads the K-blocked layout (96 < T <= %d, C %% 256 == 0, "
+                "option asp_per_segment on); keep h row-major for T=%d, C=%d", SEG_ROWS, T, C);
+    ldh = 64;
+  }
   SDK_REQUIRE(A == 128, "sdk_asp_fused: attention width %d, this build is specialised for 128", A);
   SDK_REQUIRE(B > 0 && T > 0 && T <= 224, "sdk_asp_fused: T=%d frames unsupported (1..224); use sdk_conv_gemm + sdk_asp_pool", T);
   SDK_REQUIRE(C % 128 == 0 && ldah % 8 == 0 && ldh % 8 == 0, "sdk_asp_fused: C=%d must be a multiple of 128", C);
   ProfScope ps(ctx, stream, SDK_K_ASP_FUSED, 2.0 * B * T * (double)A * C, 2.0 * B * T * ((double)C + A) + 8.0 * B * C);
-  if (T > 96 && T <= SEG_ROWS && C % 256 == 0 && !ctx->no_asp_seg) {     // one workgroup per segment (hidden tile read once)
+  if (asp_seg_ok(ctx, T, C)) {     // one workgroup per segment (hidden tile read once)
     if (sdk_lds_optin(ctx, (const void*)asp_seg_kernel<false>, SEG_LDS)) return 1;
     if (sdk_lds_optin(ctx, (const void*)asp_seg_kernel<true>, SEG_LDS)) return 1;
     if (w2p && !ctx->no_asp_packed)
       hipLaunchKernelGGL(asp_seg_kernel<true>, dim3(B), dim3(SEG_NT), SEG_LDS, (hipStream_t)stream, (const bf16_t*)ah, ldah, (const bf16_t*)w2p,
-                         (const bf16_t*)h, ldh, T, C, pooled);
+                         (const bf16_t*)h, ldh, T, C, pooled, hblk);
     else
       hipLaunchKernelGGL(asp_seg_kernel<false>, dim3(B), dim3(SEG_NT), SEG_LDS, (hipStream_t)stream, (const bf16_t*)ah, ldah, (const bf16_t*)w2,
-                         (const bf16_t*)h, ldh, T, C, pooled);
+                         (const bf16_t*)h, ldh, T, C, pooled, hblk);
     SDK_LAUNCH_CHECK();
     return 0;
   }
@@ -946,7 +956,14 @@ int asp_fused_launch(sdk_ctx* ctx, const uint16_t* ah, int64_t ldah, const uint1
 
 extern "C" int sdk_asp_fused(sdk_ctx* ctx, const uint16_t* ah, int64_t ldah, const uint16_t* w2, const float* b2,
                              const uint16_t* h, int64_t ldh, int B, int T, int C, int A, float* pooled, void* stream) {
-  return asp_fused_launch(ctx, ah, ldah, w2, nullptr, b2, h, ldh, B, T, C, A, pooled, stream);
+  return asp_fused_launch(ctx, ah, ldah, w2, nullptr, b2, h, ldh, B, T, C, A, pooled, stream, false);
+}
+
+extern "C" int sdk_asp_kblocked_ok(sdk_ctx* ctx, int T, int C) { return ctx && asp_seg_ok(ctx, T, C) ? 1 : 0; }
+
+extern "C" int sdk_asp_fused_kblocked(sdk_ctx* ctx, const uint16_t* ah, int64_t ldah, const uint16_t* w2, const float* b2, const uint16_t* h,
+                                      int B, int T, int C, int A, float* pooled, void* stream) {
+  return asp_fused_launch(ctx, ah, ldah, w2, nullptr, b2, h, 64, B, T, C, A, pooled, stream, true);
 }
 
 extern "C" int sdk_l2norm(sdk_ctx* ctx, const float* X, int N, int d, float* E, uint16_t* Eb, float* resid,

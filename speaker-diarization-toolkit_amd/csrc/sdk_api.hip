@@ -113,6 +113,7 @@ extern "C" int sdk_set_option(sdk_ctx* ctx, const char* name, int value) {
   if (strcmp(name, "res2net_two_per_cu") == 0) { ctx->no_chain_two_per_cu = value == 0; return 0; }
   if (strcmp(name, "asp_packed_weights") == 0) { ctx->no_asp_packed = value == 0; return 0; }
   if (strcmp(name, "asp_per_segment") == 0) { ctx->no_asp_seg = value == 0; return 0; }
+  if (strcmp(name, "h_kblocked") == 0) { ctx->no_h_kblocked = value == 0; return 0; }
   if (strcmp(name, "precision") == 0) {
     SDK_REQUIRE(value == 0 || value == 1, "sdk_set_option: precision must be 0 (bf16 operands) or 1 (fp16 hi+lo planes), got %d", value);
     ctx->precision = value;
@@ -408,13 +409,13 @@ static int ecapa_forward_impl(sdk_ctx* ctx, const void* wblob, const sdk_ecapa_d
   hipStream_t st = (hipStream_t)stream;
 
   auto tdnn = [&](const uint16_t* Ain, int64_t lda, int Cin, int taps, int dil, int slot, int N, uint16_t* Cout, int64_t ldc,
-                  const uint16_t* X2, int64_t ldx2, uint16_t* Sout, int64_t lds, int stats_mode = 0) -> int {
+                  const uint16_t* X2, int64_t ldx2, uint16_t* Sout, int64_t lds, int stats_mode = 0, uint32_t layout = 0) -> int {
     sdk_conv_gemm_args g;
     memset(&g, 0, sizeof(g));
     g.A = Ain; g.lda = lda; g.W = P16(slot + EL_W); g.C = Cout; g.ldc = ldc;
     g.bias = P32(slot + EL_B); g.scale = P32(slot + EL_SCALE); g.shift = P32(slot + EL_SHIFT);
     g.X2 = X2; g.ldx2 = ldx2; g.S = Sout; g.lds = lds;
-    g.M = M; g.N = N; g.Cin = Cin; g.taps = taps; g.dil = dil; g.T = T; g.flags = SDK_GEMM_RELU;
+    g.M = M; g.N = N; g.Cin = Cin; g.taps = taps; g.dil = dil; g.T = T; g.flags = SDK_GEMM_RELU | layout;
     g.stats_mode = stats_mode; g.stats_part = stats_mode ? w.stats : nullptr;
     SDK_REQUIRE(g.W && g.bias && g.scale && g.shift, "sdk_ecapa_forward: weight slot %d missing", slot);
     return sdk_conv_gemm(ctx, &g, stream);
@@ -491,7 +492,10 @@ static int ecapa_forward_impl(sdk_ctx* ctx, const void* wblob, const sdk_ecapa_d
   const bool fuse_ctx = sdk_conv_gemm_stats_fusable(M, Cm, T) != 0;
   if (calib)
     if (int rc = sdk_asp_stats(ctx, w.CAT, Cm, B, T, Cm, calib + calib_offset(d, B, d->n_blocks, 0), stream)) return rc;
-  if (int rc = tdnn(w.CAT, Cm, Cm, 1, 1, tb + EL_MFA, Cm, w.H, Cm, nullptr, 0, nullptr, 0, fuse_ctx ? 2 : 0)) return rc;
+  // h [M, Cm] is the widest activation and is read twice, both times in 64- / 32-channel pieces of its 6-KB rows (the skinny attention-hidden GEMM,
+  // the per-segment ASP slabs): where those two are its only readers it is written K-BLOCKED, [Cm / 64][M][64] (sdk_hip.h SDK_GEMM_C_KBLOCKED)
+  const bool h_kb = !ctx->no_h_kblocked && !calib && fuse_ctx && A == 128 && sdk_asp_kblocked_ok(ctx, T, Cm) != 0;
+  if (int rc = tdnn(w.CAT, Cm, Cm, 1, 1, tb + EL_MFA, Cm, w.H, Cm, nullptr, 0, nullptr, 0, fuse_ctx ? 2 : 0, h_kb ? SDK_GEMM_C_KBLOCKED : 0)) return rc;
   if (calib)
     if (int rc = sdk_asp_stats(ctx, w.H, Cm, B, T, Cm, calib + calib_offset(d, B, d->n_blocks, 1), stream)) return rc;
   if (fuse_ctx) {
@@ -505,11 +509,11 @@ static int ecapa_forward_impl(sdk_ctx* ctx, const void* wblob, const sdk_ecapa_d
     memset(&g, 0, sizeof(g));
     g.A = w.H; g.lda = Cm; g.W = P16(tb + EL_ASP_WH); g.C = w.AH; g.ldc = A;
     g.ubias = w.ubias; g.ldub = A; g.scale = P32(tb + EL_ASP_SCALE); g.shift = P32(tb + EL_ASP_SHIFT);
-    g.M = M; g.N = A; g.Cin = Cm; g.taps = 1; g.dil = 1; g.T = T; g.flags = SDK_GEMM_RELU | SDK_GEMM_TANH;
+    g.M = M; g.N = A; g.Cin = Cm; g.taps = 1; g.dil = 1; g.T = T; g.flags = SDK_GEMM_RELU | SDK_GEMM_TANH | (h_kb ? SDK_GEMM_A_KBLOCKED : 0);
     if (int rc = sdk_conv_gemm(ctx, &g, stream)) return rc;
     if (A == 128 && T <= sdk_asp_fused_max_frames()) {
       // logits GEMM + softmax pooling fused: no [M, Cm] fp32 logits round trip through HBM
-      if (int rc = asp_fused_launch(ctx, w.AH, A, P16(tb + EL_ASP_W2), P16(tb + EL_ASP_W2PACK), P32(tb + EL_ASP_B2), w.H, Cm, B, T, Cm, A, w.pooled, stream)) return rc;
+      if (int rc = asp_fused_launch(ctx, w.AH, A, P16(tb + EL_ASP_W2), P16(tb + EL_ASP_W2PACK), P32(tb + EL_ASP_B2), w.H, Cm, B, T, Cm, A, w.pooled, stream, h_kb)) return rc;
     } else {
       memset(&g, 0, sizeof(g));
       g.A = w.AH; g.lda = A; g.W = P16(tb + EL_ASP_W2); g.C32 = w.logits; g.ldc32 = Cm; g.bias = P32(tb + EL_ASP_B2);

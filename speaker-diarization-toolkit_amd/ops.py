@@ -421,17 +421,22 @@ class Engine:
 
     # ------------------------------------------------------------------ building blocks (tests / tuning)
     def conv_gemm(self, A, W, N, Cin, taps=1, dil=1, T=None, bias=None, scale=None, shift=None, ubias=None,
-                  relu=False, tanh=False, out_bf16=True, out_f32=False, X2=None, stats_mode=0, A2=None, tap_pack=0):
+                  relu=False, tanh=False, out_bf16=True, out_f32=False, X2=None, stats_mode=0, A2=None, tap_pack=0,
+                  a_kblocked=False, c_kblocked=False):
         """stats_mode 1/2 additionally returns the fused per-segment column statistics as a 4th value
-        ([B, N] means, or [B, 2N] mean | std)."""
+        ([B, N] means, or [B, 2N] mean | std).
+        a_kblocked: A is a K-blocked tensor [Cin / 64, M, 64] (to_kblocked); c_kblocked: the bf16 output comes back as [N / 64, M, 64]
+        (include/sdk_hip.h SDK_GEMM_A_KBLOCKED / SDK_GEMM_C_KBLOCKED)."""
         _need(A, torch.bfloat16, "A"); _need(W, torch.bfloat16, "W")
-        M = A.shape[0]
+        if a_kblocked and (A.dim() != 3 or A.shape[2] != 64 or A.shape[0] * 64 != Cin or not A.is_contiguous()):
+            raise ValueError(f"conv_gemm: a K-blocked A must be a contiguous [Cin / 64, M, 64] tensor, got {tuple(A.shape)} for Cin={Cin}")
+        M = A.shape[1] if a_kblocked else A.shape[0]
         T = T or M
         g = ConvGemmArgs()
-        g.A, g.lda, g.W = A.data_ptr(), A.stride(0), W.data_ptr()
+        g.A, g.lda, g.W = A.data_ptr(), (64 if a_kblocked else A.stride(0)), W.data_ptr()
         if A2 is not None:
             g.A2, g.lda2 = A2.data_ptr(), A2.stride(0)
-        Cout = torch.empty((M, N), dtype=torch.bfloat16, device=self.device) if out_bf16 else None
+        Cout = torch.empty((N // 64, M, 64) if c_kblocked else (M, N), dtype=torch.bfloat16, device=self.device) if out_bf16 else None
         C32 = torch.empty((M, N), dtype=torch.float32, device=self.device) if out_f32 else None
         S = torch.empty((M, N), dtype=torch.bfloat16, device=self.device) if X2 is not None else None
         g.C, g.ldc, g.C32, g.ldc32 = _ptr(Cout), N, _ptr(C32), N
@@ -440,7 +445,8 @@ class Engine:
         g.X2, g.ldx2 = _ptr(X2), (X2.stride(0) if X2 is not None else 0)
         g.S, g.lds = _ptr(S), N
         g.M, g.N, g.Cin, g.taps, g.dil, g.T = M, N, Cin, taps, dil, T
-        g.flags = (_lib.GEMM_RELU if relu else 0) | (_lib.GEMM_TANH if tanh else 0)
+        g.flags = ((_lib.GEMM_RELU if relu else 0) | (_lib.GEMM_TANH if tanh else 0) | (_lib.GEMM_A_KBLOCKED if a_kblocked else 0)
+                   | (_lib.GEMM_C_KBLOCKED if c_kblocked else 0))
         g.tap_pack = tap_pack
         part = None
         if stats_mode:
@@ -452,6 +458,16 @@ class Engine:
             check(self.lib.sdk_colstats_finish(self.ctx, part.data_ptr(), M, N, T, stats_mode, st.data_ptr(), _stream()), "sdk_colstats_finish")
             return Cout, C32, S, st
         return Cout, C32, S
+
+    @staticmethod
+    def to_kblocked(x: torch.Tensor) -> torch.Tensor:
+        """[M, C] -> the K-blocked layout [C / 64, M, 64] (element (m, c) at (c // 64, m, c % 64)); for tests and tools."""
+        M, Cc = x.shape
+        return x.reshape(M, Cc // 64, 64).permute(1, 0, 2).contiguous()
+
+    @staticmethod
+    def from_kblocked(x: torch.Tensor) -> torch.Tensor:
+        return x.permute(1, 0, 2).reshape(x.shape[1], x.shape[0] * 64).contiguous()
 
     # ---- precise mode building blocks (csrc/hp.hip) ------------------------------------------------
     @staticmethod
@@ -599,7 +615,14 @@ class Engine:
                                          _ptr(ps), _ptr(pc), _stream()), "sdk_kmeans_assign")
         return lab, d2, ps, pc
 
-    def asp_fused(self, ah, w2, b2, h, B, T):
+    def asp_fused(self, ah, w2, b2, h, B, T, kblocked=False):
+        """kblocked: h is [Cm / 64, B*T, 64] (to_kblocked) - the per-segment form only (sdk_asp_kblocked_ok)."""
+        if kblocked:
+            Cm = h.shape[0] * 64
+            out = torch.empty((B, 2 * Cm), dtype=torch.float32, device=self.device)
+            check(self.lib.sdk_asp_fused_kblocked(self.ctx, ah.data_ptr(), ah.stride(0), w2.data_ptr(), b2.data_ptr(), h.data_ptr(),
+                                                  B, T, Cm, ah.shape[1], out.data_ptr(), _stream()), "sdk_asp_fused_kblocked")
+            return out
         Cm = h.shape[1]
         out = torch.empty((B, 2 * Cm), dtype=torch.float32, device=self.device)
         check(self.lib.sdk_asp_fused(self.ctx, ah.data_ptr(), ah.stride(0), w2.data_ptr(), b2.data_ptr(), h.data_ptr(), h.stride(0),

@@ -15,6 +15,7 @@ pytestmark = pytest.mark.gpu
 W = sub("weights")
 WP = sub("weights_pack")
 OPS = sub("ops")
+SdkError = sub("_lib").SdkError
 
 BF16_ULP = 2.0 ** -8          # relative spacing of bf16 (8 significand bits)
 
@@ -320,6 +321,76 @@ def test_ecapa_forward_full_config(engine):
     # and the bf16 model itself stays close to the unrounded fp32 model (reported, loose bound)
     ref32 = oecapa.EcapaOracle(weights, "fp32", torch.float64).embed(feats)
     assert (_cos(emb, ref32) > 0.999).all()
+
+
+def test_ecapa_forward_kblocked_h_is_bit_identical(engine):
+    """Round 4: the MFA output h is written K-blocked ([C / 64][M][64]) where the skinny attention-hidden GEMM and the per-segment ASP are its
+    only readers (T = 201: yes; T = 64: no - asp_stats and the short-window ASP read it row-major).  A layout, not arithmetic: the embeddings
+    equal the row-major schedule's bit for bit (option h_kblocked)."""
+    for B, T in [(6, 201), (3, 130), (2, 64)]:
+        feats = _feats(B, T, 40 + T)
+        f = torch.zeros(B * T, WP.N_MELS_PADDED, dtype=torch.bfloat16)
+        f[:, :80] = feats.reshape(-1, 80).to(torch.bfloat16)
+        f = f.cuda()
+        on = engine.ecapa_forward(f, B, T).clone()
+        engine.set_option("h_kblocked", 0)
+        try:
+            off = engine.ecapa_forward(f, B, T).clone()
+        finally:
+            engine.set_option("h_kblocked", 1)
+        assert torch.equal(on, off), (B, T, float((on - off).abs().max()))
+        assert engine.lib.sdk_asp_kblocked_ok(engine.ctx, T, 3072) == (1 if T > 96 else 0)
+
+
+@pytest.mark.parametrize("M,T,N,Cin", [(2010, 201, 3072, 128), (1000, 200, 256, 64), (2613, 201, 512, 192)])
+def test_conv_gemm_kblocked_output_and_input(engine, M, T, N, Cin):
+    """SDK_GEMM_C_KBLOCKED: the 256^2 kernel's copy-out writes [N / 64][M][64] - the same values (and the same fused column statistics) as the
+    row-major output, edge tiles included.  SDK_GEMM_A_KBLOCKED: the 128^2 kernel reads that layout - the same product as from row-major A."""
+    g = torch.Generator().manual_seed(M + N)
+    A = dev(bf16_round(torch.randn(M, Cin, generator=g)), torch.bfloat16)
+    Wt = dev(bf16_round(torch.randn(N, Cin, generator=g) * 0.2), torch.bfloat16)
+    bias, sc, sh = dev(torch.randn(N, generator=g)), dev(torch.rand(N, generator=g) + 0.5), dev(torch.randn(N, generator=g))
+    C0, _, _, st0 = engine.conv_gemm(A, Wt, N, Cin, T=T, bias=bias, scale=sc, shift=sh, relu=True, stats_mode=2)
+    C1, _, _, st1 = engine.conv_gemm(A, Wt, N, Cin, T=T, bias=bias, scale=sc, shift=sh, relu=True, stats_mode=2, c_kblocked=True)
+    assert torch.equal(st0, st1)
+    assert C1.shape == (N // 64, M, 64)
+    assert torch.equal(engine.from_kblocked(C1), C0)
+    assert torch.equal(engine.to_kblocked(C0), C1)
+    # the K-blocked tensor as the A operand of a skinny layer (N2 = 128: the attention-hidden shape)
+    W2 = dev(bf16_round(torch.randn(128, N, generator=g) * 0.05), torch.bfloat16)
+    ub = dev(torch.randn(M // T, 128, generator=g))
+    D0, _, _ = engine.conv_gemm(C0, W2, 128, N, T=T, ubias=ub, relu=True, tanh=True)
+    D1, _, _ = engine.conv_gemm(C1, W2, 128, N, T=T, ubias=ub, relu=True, tanh=True, a_kblocked=True)
+    torch.cuda.synchronize()
+    assert torch.equal(D0, D1)
+
+
+def test_conv_gemm_kblocked_refusals(engine):
+    A = torch.zeros(512, 64, dtype=torch.bfloat16, device="cuda")
+    Wt = torch.zeros(128, 64, dtype=torch.bfloat16, device="cuda")
+    with pytest.raises(SdkError, match="K-blocked output needs"):
+        engine.conv_gemm(A, Wt, 128, 64, c_kblocked=True)                       # N = 128: not the 256^2 kernel's shape
+    W3 = torch.zeros(256, 192, dtype=torch.bfloat16, device="cuda")
+    with pytest.raises(SdkError, match="K-blocked A operand needs taps == 1"):
+        engine.conv_gemm(engine.to_kblocked(A), W3, 256, 64, taps=3, T=128, a_kblocked=True)
+    with pytest.raises(ValueError, match="K-blocked A must be"):
+        engine.conv_gemm(A, Wt, 128, 64, a_kblocked=True)
+
+
+@pytest.mark.parametrize("B,T", [(3, 201), (2, 97), (2, 208)])
+def test_asp_fused_kblocked_is_bit_identical(engine, B, T):
+    C, A = 3072, 128
+    g = torch.Generator().manual_seed(T + 7)
+    h = dev(bf16_round(torch.randn(B * T, C, generator=g) * 20 + 5), torch.bfloat16)
+    ah = dev(bf16_round(torch.tanh(torch.randn(B * T, A, generator=g))), torch.bfloat16)
+    w2 = dev(bf16_round(torch.randn(C, A, generator=g) * 0.3), torch.bfloat16)
+    b2 = dev(torch.randn(C, generator=g))
+    p0 = engine.asp_fused(ah, w2, b2, h, B, T)
+    p1 = engine.asp_fused(ah, w2, b2, engine.to_kblocked(h), B, T, kblocked=True)
+    torch.cuda.synchronize()
+    assert torch.equal(p0, p1)
+    with pytest.raises(SdkError, match="only the per-segment form"):
+        engine.asp_fused(ah[:50], w2, b2, engine.to_kblocked(h[:50]), 1, 50, kblocked=True)
 
 
 @pytest.mark.parametrize("B,T", [(2, 301), (2, 501)])
