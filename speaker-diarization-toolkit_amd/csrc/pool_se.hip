@@ -259,6 +259,8 @@ __global__ __launch_bounds__(KW * 64) void rows_fc_mfma_kernel(const float* __re
   // (rounds 1-3 ran one group ahead).  The input affine is applied when a slot is consumed (from LDS), so a fetch is loads only.  What bounds the
   // 6144-long FCs is the fp32 matrix pipe, not latency: 192 `32x32x2` MFMAs x 64 cycles x 4 waves per SIMD = 23 us on the 128-192 workgroups
   // (32 x 32 output tiles of a 1000-row problem) of a 45-55 us launch; the deeper ring buys 5-15 % (`tools/rows_fc_bench.py`: 55 -> 50, 14 -> 12 us).
+  // A timing probe with perfectly coalesced (wrong) A addresses - each lane's 16-byte piece lies in a different row - reads 45 -> 39 / 50 -> 45 us:
+  // staging A through LDS would buy at most that; not built.
   constexpr int D = WLDS ? 8 : 4;
   const int ng = kw >> 3;
   f32x4 ra[D], rw[D];
