@@ -135,8 +135,8 @@ int sdk_fbank_windows(sdk_ctx* ctx, const int16_t* samples, int64_t n_samples, c
                       uint16_t* feats, int ldf, void* ws, size_t ws_bytes, void* stream);
 
 /* ---- ingest: host audio -> HBM, staged through pinned memory on a copy stream of its own, `depth`-deep (2 = double-buffered) so that the
- *      upload of recording i + 1 runs under the forward pass of recording i.  A slot = pinned host buffers for max_samples int16 and
- *      max_windows int32 window starts + their device twins.
+ *      upload of recording i + 1 runs under the forward pass of recording i.  A slot = pinned host buffers for int16 samples and
+ *      int32 window starts + their device twins, allocated on the slot's first use at the size of that upload (max_samples / max_windows bound it).
  *   sdk_ingest_acquire : next slot (ring order); *pinned_samples / *pinned_starts are HOST pointers the caller fills (a file reader can
  *                        read straight into them: no second host copy).  Fails if that slot was committed and never released; a slot
  *                        acquired and never committed (its filler gave up) is handed out again when the ring comes round.
@@ -149,7 +149,11 @@ int sdk_fbank_windows(sdk_ctx* ctx, const int16_t* samples, int64_t n_samples, c
 typedef struct sdk_ingest sdk_ingest;
 int sdk_ingest_create(sdk_ctx* ctx, int64_t max_samples, int max_windows, int depth, sdk_ingest** out);
 int sdk_ingest_destroy(sdk_ingest* ing);
-int sdk_ingest_acquire(sdk_ingest* ing, int* ticket, int16_t** pinned_samples, int32_t** pinned_starts);
+int sdk_ingest_acquire(sdk_ingest* ing, int* ticket, int16_t** pinned_samples, int32_t** pinned_starts);   /* = _sized(max_samples, max_windows) */
+/* a slot's buffers are allocated on its first use and sized to what it is asked to take (grown when a larger upload arrives; where the host
+ * refuses page-locked memory the slot stages through ordinary memory): max_samples / max_windows of sdk_ingest_create are upper bounds only */
+int sdk_ingest_acquire_sized(sdk_ingest* ing, int64_t n_samples, int n_windows, int* ticket, int16_t** pinned_samples, int32_t** pinned_starts);
+int sdk_ingest_slot_info(sdk_ingest* ing, int slot, int64_t* cap_samples, int* pinned);
 int sdk_ingest_commit(sdk_ingest* ing, int ticket, int64_t n_samples, int n_windows, int window_len, void* compute_stream,
                       const int16_t** dev_samples, const int32_t** dev_starts);
 int sdk_ingest_submit(sdk_ingest* ing, const int16_t* host_samples, int64_t n_samples, const int32_t* host_starts, int n_windows,

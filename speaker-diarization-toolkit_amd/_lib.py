@@ -92,6 +92,8 @@ SIGNATURES = {
     "sdk_ingest_create": (_i, [_vp, _i64, _i, _i, C.POINTER(_vp)]),
     "sdk_ingest_destroy": (_i, [_vp]),
     "sdk_ingest_acquire": (_i, [_vp, C.POINTER(_i), C.POINTER(_vp), C.POINTER(_vp)]),
+    "sdk_ingest_acquire_sized": (_i, [_vp, _i64, _i, C.POINTER(_i), C.POINTER(_vp), C.POINTER(_vp)]),
+    "sdk_ingest_slot_info": (_i, [_vp, _i, C.POINTER(_i64), C.POINTER(_i)]),
     "sdk_ingest_commit": (_i, [_vp, _i, _i64, _i, _i, _vp, C.POINTER(_vp), C.POINTER(_vp)]),
     "sdk_ingest_submit": (_i, [_vp, _vp, _i64, _vp, _i, _i, _vp, C.POINTER(_i), C.POINTER(_vp), C.POINTER(_vp)]),
     "sdk_ingest_release": (_i, [_vp, _i, _vp]),

@@ -5,7 +5,10 @@
 // int32 table of window starts; the windows are cut on the device by sdk_fbank_windows.  This file is the staging runtime around that:
 //
 //   sdk_ingest          `depth` slots, each = {pinned host buffers for samples and window starts, their device twins, two events};
-//                       one copy stream of its own
+//                       one copy stream of its own.  A slot's buffers are allocated on its FIRST use and sized to the upload it is asked to take
+//                       (rounded up, grown when a larger one arrives): a single-recording CLI call (base.py:130-151, one identify per process)
+//                       touches one slot of the recording's size, not `depth` slots of the largest size the ring may ever see.
+//                       Where the host refuses page-locked memory the slot stages through ordinary memory (slower upload, same results)
 //   acquire             next slot in ring order; waits (host side) only until the slot's PREVIOUS upload has left its pinned buffers
 //   [the caller fills the pinned buffers - a WAVE reader can readinto() them: no second host copy - or lets submit() memcpy]
 //   commit              H2D copies on the copy stream, issued behind the slot's previous consumer (stream wait on `consumed`, no host block);
@@ -14,6 +17,7 @@
 //
 // With depth >= 2 the upload of recording i + 1 (host memcpy into pinned memory + DMA) runs under the forward pass of recording i.
 // No kernel here: HIP runtime calls only; the library's other entry points take the returned device pointers as they take any others.
+#include <stdlib.h>
 #include <string.h>
 
 #include <thread>
@@ -45,6 +49,8 @@ struct sdk_ingest {
   struct Slot {
     int16_t* h_s = nullptr; int32_t* h_w = nullptr;
     int16_t* d_s = nullptr; int32_t* d_w = nullptr;
+    int64_t cap_s = 0; int cap_w = 0;   // what the buffers hold now (0: not allocated yet)
+    bool pinned = true;                 // false: hipHostMalloc was refused, h_s / h_w come from malloc
     hipEvent_t copy_begin = nullptr, copied = nullptr, consumed = nullptr;
     int state = 0;            // 0 free, 1 acquired (being filled), 2 committed (in use by the compute stream), 3 released (consumed event recorded)
     bool ever_copied = false, ever_consumed = false;
@@ -54,16 +60,57 @@ struct sdk_ingest {
   double bytes_total = 0.0;
 };
 
+static void slot_free(sdk_ingest::Slot& s) {
+  if (s.pinned) {
+    if (s.h_s) (void)hipHostFree(s.h_s);
+    if (s.h_w) (void)hipHostFree(s.h_w);
+  } else {
+    free(s.h_s);
+    free(s.h_w);
+  }
+  if (s.d_s) (void)hipFree(s.d_s);
+  if (s.d_w) (void)hipFree(s.d_w);
+  s.h_s = nullptr; s.h_w = nullptr; s.d_s = nullptr; s.d_w = nullptr;
+  s.cap_s = 0; s.cap_w = 0; s.pinned = true;
+}
+
+// Make the slot hold n_samples / n_windows.  Called with the slot idle on the host side (its previous upload has left the staging buffers);
+// its previous CONSUMER may still be running on the device, so growing waits for that one event - the other slots and both streams keep going.
+static int slot_reserve(sdk_ingest* g, sdk_ingest::Slot& s, int64_t n_samples, int n_windows) {
+  if (n_samples <= s.cap_s && n_windows <= s.cap_w) return 0;
+  if (s.ever_consumed) SDK_HIP_OK(hipEventSynchronize(s.consumed));
+  // sizes: at least what is asked, rounded up to 2^20 samples (2 MiB) / 4096 windows so that recordings of similar length reuse the buffers
+  int64_t cs = n_samples > s.cap_s ? n_samples : s.cap_s;
+  int cw = n_windows > s.cap_w ? n_windows : s.cap_w;
+  cs = (cs + (1 << 20) - 1) & ~(int64_t)((1 << 20) - 1);
+  cw = (cw + 4095) & ~4095;
+  if (cs > g->max_samples) cs = g->max_samples;
+  if (cw > g->max_windows) cw = g->max_windows;
+  slot_free(s);
+  const bool try_pinned = !getenv("SDK_INGEST_NO_PINNED");               // (tests: the pageable fallback without exhausting the host's lock limit)
+  if (!try_pinned || hipHostMalloc((void**)&s.h_s, (size_t)cs * 2, hipHostMallocDefault) != hipSuccess ||
+      hipHostMalloc((void**)&s.h_w, (size_t)cw * 4, hipHostMallocDefault) != hipSuccess) {
+    (void)hipGetLastError();
+    if (s.h_s) { (void)hipHostFree(s.h_s); s.h_s = nullptr; }
+    s.pinned = false;
+    s.h_s = (int16_t*)malloc((size_t)cs * 2);
+    s.h_w = (int32_t*)malloc((size_t)cw * 4);
+    if (!s.h_s || !s.h_w) { slot_free(s); SDK_REQUIRE(false, "sdk_ingest: no host memory for a staging slot of %lld samples", (long long)cs); }
+  }
+  hipError_t e = hipMalloc((void**)&s.d_s, (size_t)cs * 2);
+  if (e == hipSuccess) e = hipMalloc((void**)&s.d_w, (size_t)cw * 4);
+  if (e != hipSuccess) { slot_free(s); SDK_REQUIRE(false, "sdk_ingest: hipMalloc of a %lld-sample slot failed: %s", (long long)cs, hipGetErrorString(e)); }
+  s.cap_s = cs; s.cap_w = cw;
+  return 0;
+}
+
 extern "C" int sdk_ingest_destroy(sdk_ingest* g) {
   if (!g) return 0;
   if (g->copy) (void)hipStreamSynchronize(g->copy);
   for (int i = 0; i < g->depth; ++i) {
     auto& s = g->slot[i];
     if (s.consumed && s.ever_consumed) (void)hipEventSynchronize(s.consumed);
-    if (s.h_s) (void)hipHostFree(s.h_s);
-    if (s.h_w) (void)hipHostFree(s.h_w);
-    if (s.d_s) (void)hipFree(s.d_s);
-    if (s.d_w) (void)hipFree(s.d_w);
+    slot_free(s);
     if (s.copy_begin) (void)hipEventDestroy(s.copy_begin);
     if (s.copied) (void)hipEventDestroy(s.copied);
     if (s.consumed) (void)hipEventDestroy(s.consumed);
@@ -86,10 +133,6 @@ extern "C" int sdk_ingest_create(sdk_ctx* ctx, int64_t max_samples, int max_wind
   ING_OK(hipStreamCreateWithFlags(&g->copy, hipStreamNonBlocking));
   for (int i = 0; i < depth; ++i) {
     auto& s = g->slot[i];
-    ING_OK(hipHostMalloc((void**)&s.h_s, (size_t)max_samples * 2, hipHostMallocDefault));
-    ING_OK(hipHostMalloc((void**)&s.h_w, (size_t)max_windows * 4, hipHostMallocDefault));
-    ING_OK(hipMalloc((void**)&s.d_s, (size_t)max_samples * 2));
-    ING_OK(hipMalloc((void**)&s.d_w, (size_t)max_windows * 4));
     ING_OK(hipEventCreate(&s.copy_begin));
     ING_OK(hipEventCreate(&s.copied));
     ING_OK(hipEventCreateWithFlags(&s.consumed, hipEventDisableTiming));
@@ -100,12 +143,21 @@ extern "C" int sdk_ingest_create(sdk_ctx* ctx, int64_t max_samples, int max_wind
 }
 
 extern "C" int sdk_ingest_acquire(sdk_ingest* g, int* ticket, int16_t** pinned_samples, int32_t** pinned_starts) {
+  return sdk_ingest_acquire_sized(g, g ? g->max_samples : 0, g ? g->max_windows : 0, ticket, pinned_samples, pinned_starts);
+}
+
+extern "C" int sdk_ingest_acquire_sized(sdk_ingest* g, int64_t n_samples, int n_windows, int* ticket, int16_t** pinned_samples, int32_t** pinned_starts) {
   SDK_REQUIRE(g && ticket && pinned_samples && pinned_starts, "sdk_ingest_acquire: null argument");
+  SDK_REQUIRE(n_samples > 0 && n_samples <= g->max_samples && n_windows >= 0 && n_windows <= g->max_windows,
+              "sdk_ingest_acquire: %lld samples / %d windows do not fit the slots (%lld / %d)", (long long)n_samples, n_windows,
+              (long long)g->max_samples, g->max_windows);
   auto& s = g->slot[g->next];
   // (a slot that was acquired but never committed - its filler failed - has nothing enqueued and is simply handed out again)
   SDK_REQUIRE(s.state != 2, "sdk_ingest_acquire: all %d slots are in flight (slot %d was committed but never released: call sdk_ingest_release "
               "after the last kernel that reads it has been enqueued)", g->depth, g->next);
   if (s.ever_copied) SDK_HIP_OK(hipEventSynchronize(s.copied));     // the previous upload has left the pinned buffers (it finished long ago unless depth == 1)
+  SDK_HIP_OK(hipSetDevice(g->ctx->device));
+  if (int rc = slot_reserve(g, s, n_samples, n_windows > 0 ? n_windows : 1)) return rc;
   s.state = 1;
   *ticket = g->next;
   *pinned_samples = s.h_s;
@@ -119,10 +171,10 @@ extern "C" int sdk_ingest_commit(sdk_ingest* g, int ticket, int64_t n_samples, i
   SDK_REQUIRE(g && dev_samples && dev_starts, "sdk_ingest_commit: null argument");
   SDK_REQUIRE(ticket >= 0 && ticket < g->depth && g->slot[ticket].state == 1, "sdk_ingest_commit: ticket %d is not an acquired slot", ticket);
   auto& s = g->slot[ticket];
-  if (n_samples <= 0 || n_samples > g->max_samples || n_windows < 0 || n_windows > g->max_windows) {
+  if (n_samples <= 0 || n_samples > s.cap_s || n_windows < 0 || n_windows > s.cap_w) {
     s.state = 0;
-    SDK_REQUIRE(false, "sdk_ingest_commit: %lld samples / %d windows do not fit the slot (%lld / %d)", (long long)n_samples, n_windows,
-                (long long)g->max_samples, g->max_windows);
+    SDK_REQUIRE(false, "sdk_ingest_commit: %lld samples / %d windows do not fit the slot as acquired (%lld / %d)", (long long)n_samples, n_windows,
+                (long long)s.cap_s, s.cap_w);
   }
   // the start table is dereferenced on the device: every window must START inside the recording (window_len > 0: and end no further than one
   // window past it - what lies beyond the end reads as zero, sdk_fbank_windows)
@@ -157,7 +209,7 @@ extern "C" int sdk_ingest_submit(sdk_ingest* g, const int16_t* host_samples, int
               "sdk_ingest_submit: %lld samples / %d windows do not fit the slots (%lld / %d)", (long long)n_samples, n_windows,
               (long long)g->max_samples, g->max_windows);
   int16_t* ps; int32_t* pw;
-  if (int rc = sdk_ingest_acquire(g, ticket, &ps, &pw)) return rc;
+  if (int rc = sdk_ingest_acquire_sized(g, n_samples, n_windows, ticket, &ps, &pw)) return rc;
   staging_copy(ps, host_samples, (size_t)n_samples * 2);
   if (n_windows) memcpy(pw, host_starts, (size_t)n_windows * 4);
   return sdk_ingest_commit(g, *ticket, n_samples, n_windows, window_len, compute_stream, dev_samples, dev_starts);
@@ -179,5 +231,13 @@ extern "C" int sdk_ingest_copy_ms(sdk_ingest* g, int ticket, float* ms, double* 
   SDK_HIP_OK(hipEventSynchronize(s.copied));
   SDK_HIP_OK(hipEventElapsedTime(ms, s.copy_begin, s.copied));
   if (bytes) *bytes = (double)s.n * 2 + (double)s.B * 4;
+  return 0;
+}
+
+// What a slot holds right now: its capacity in samples (0 = never used: nothing allocated) and whether its staging memory is page-locked.
+extern "C" int sdk_ingest_slot_info(sdk_ingest* g, int slot, int64_t* cap_samples, int* pinned) {
+  SDK_REQUIRE(g && slot >= 0 && slot < g->depth, "sdk_ingest_slot_info: slot %d of %d", slot, g ? g->depth : 0);
+  if (cap_samples) *cap_samples = g->slot[slot].cap_s;
+  if (pinned) *pinned = g->slot[slot].pinned ? 1 : 0;
   return 0;
 }

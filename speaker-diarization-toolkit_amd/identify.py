@@ -16,31 +16,44 @@ def db_dir() -> Path:
     return Path(os.environ.get("SPEAKERS_EMBEDDINGS_DIR", os.path.expanduser("~/.config/speakers_embeddings"))) / "db"
 
 
+def listing_pack_path() -> Path:
+    """Where the parsed db listing is cached: $SPEAKERS_EMBEDDINGS_DIR/cache/profiles-pack.json - OUTSIDE db/, which this build shares with the
+    reference CLI: that lists profiles with pathlib `db_path.glob("*.json")` (speaker_detection:213), which matches dot-files too, so any *.json
+    kept inside db/ would be loaded there as a speaker profile without an 'id'."""
+    return db_dir().parent / "cache" / "profiles-pack.json"
+
+
 def list_all_speakers() -> List[Dict[str, Any]]:
     """Every db/*.json profile, sorted by file name (speaker_detection:206-220 reads them one by one, per CLI call).  At BASELINE's profile counts
-    (1 000 / 10 000 speakers) that is 10^3-10^4 small-file reads per process, so the parsed list is kept as ONE file, db/.profiles-pack.json, keyed by
-    a digest of the directory listing (name, size, mtime_ns of every db/*.json: one scandir, no file is opened): any edit, addition or deletion
-    changes the digest and the pack is rebuilt from the files.  SDK_PROFILE_PACK=0 disables it.  Warnings for unreadable files are repeated on a
-    pack hit (they are stored with it)."""
+    (1 000 / 10 000 speakers) that is 10^3-10^4 small-file reads per process, so the parsed list is kept as ONE file (listing_pack_path(), outside
+    db/), keyed by a digest of the directory listing (name, size, mtime_ns, ctime_ns and inode of every db/*.json: one scandir, no file is opened):
+    any edit, addition, deletion or replacement changes the digest - also a same-size rewrite inside the mtime granularity of a coarse file system,
+    or by a tool that restores mtime, because ctime cannot be set from user space - and the pack is rebuilt from the files.  SDK_PROFILE_PACK=0
+    disables it.  Warnings for unreadable files are repeated on a pack hit (they are stored with it)."""
     import hashlib
     d = db_dir()
     if not d.exists():
         return []
-    entries = sorted((e.name, e.stat().st_size, e.stat().st_mtime_ns) for e in os.scandir(d) if e.name.endswith(".json") and not e.name.startswith(".") and e.is_file())
+    entries = []
+    for e in os.scandir(d):
+        if e.name.endswith(".json") and e.is_file():                     # dot-files included: the reference's glob lists them too
+            st = e.stat()
+            entries.append((e.name, st.st_size, st.st_mtime_ns, st.st_ctime_ns, st.st_ino))
+    entries.sort()
     use_pack = os.environ.get("SDK_PROFILE_PACK", "1") != "0" and len(entries) >= 64
     digest = hashlib.sha256(repr(entries).encode()).hexdigest()
-    pack = d / ".profiles-pack.json"
+    pack = listing_pack_path()
     if use_pack:
         try:
             t = json.loads(pack.read_text())
-            if t.get("digest") == digest and t.get("format") == 1:
+            if t.get("digest") == digest and t.get("format") == 2:
                 for w in t.get("warnings", []):
                     print(w, file=sys.stderr)
                 return t["profiles"]
         except (OSError, ValueError, KeyError):
             pass
     out, warns = [], []
-    for name, _, _ in entries:
+    for name, *_ in entries:
         p = d / name
         try:
             out.append(json.loads(p.read_text()))
@@ -49,8 +62,9 @@ def list_all_speakers() -> List[Dict[str, Any]]:
             print(warns[-1], file=sys.stderr)
     if use_pack:
         try:                                     # atomic publish; concurrent CLI processes write identical content
-            tmp = d / f".profiles-pack.{os.getpid()}.tmp"
-            tmp.write_text(json.dumps({"format": 1, "digest": digest, "profiles": out, "warnings": warns}))
+            pack.parent.mkdir(parents=True, exist_ok=True)
+            tmp = pack.parent / f".profiles-pack.{os.getpid()}.tmp"
+            tmp.write_text(json.dumps({"format": 2, "digest": digest, "profiles": out, "warnings": warns}))
             os.replace(tmp, pack)
         except OSError:
             pass

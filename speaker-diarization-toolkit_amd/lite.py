@@ -194,27 +194,48 @@ class LiteEngine:
         """One recording (int16 [n], host) + window-start tables {S: int32 [B_S]} -> {S: (E [B_S, d] fp32 host, idx or None, score or None)}.
         The recording is uploaded ONCE (pinned staging slot); the windows are cut on the device, batch by batch; with `profiles` every batch is
         scored while its embeddings are resident (score_last).  Same results as embed_pcm on host-cut windows, bit for bit."""
-        order = sorted(tables)
-        flat = np.concatenate([np.ascontiguousarray(tables[S], dtype=np.int32) for S in order]) if order else np.zeros((0,), np.int32)
+        from .ingest import chunk_samples, plan_chunks
         ing = self.ingest()
-        ticket, ds, dw = ing.submit(samples, flat, max(order) if order else 0, None)
-        out, off = {}, 0
-        try:
-            for S in order:
-                Bs = len(tables[S])
-                Es, idxs, scs = [], [], []
-                for a in range(0, Bs, step):
-                    b = min(step, Bs - a)
-                    emb = self.forward(self.fbank_windows(ds, len(samples), dw + 4 * (off + a), b, S), b, num_frames(S))
-                    self._last = (self.l2norm(emb, b, self.cfg.embed_dim, "seg"), b)
-                    Es.append(self._last[0][0].download(np.float32, (b, self.cfg.embed_dim)))
-                    if profiles is not None:
-                        i, s_ = self.score_last(profiles, k, **(score_kw or {}))
-                        idxs.append(i); scs.append(s_)
-                out[S] = (np.concatenate(Es), np.concatenate(idxs) if idxs else None, np.concatenate(scs) if scs else None)
-                off += Bs
-        finally:
-            ing.release(ticket, None)
+        samples = np.ascontiguousarray(samples, dtype=np.int16).reshape(-1)
+        d = self.cfg.embed_dim
+        acc: Dict[int, list] = {}
+        for lo, hi, sub in plan_chunks(len(samples), tables, chunk_samples()):    # one piece unless the recording is longer than a staging slot may be
+            order = sorted(sub)
+            flat = np.concatenate([sub[S][1] for S in order]) if order else np.zeros((0,), np.int32)
+            ticket, ds, dw = ing.submit(samples[lo:hi], flat, max(order) if order else 0, None)
+            off = 0
+            try:
+                for S in order:
+                    rows, local = sub[S]
+                    Bs = len(local)
+                    Es, idxs, scs = [], [], []
+                    for a in range(0, Bs, step):
+                        b = min(step, Bs - a)
+                        emb = self.forward(self.fbank_windows(ds, hi - lo, dw + 4 * (off + a), b, S), b, num_frames(S))
+                        self._last = (self.l2norm(emb, b, d, "seg"), b)
+                        Es.append(self._last[0][0].download(np.float32, (b, d)))
+                        if profiles is not None:
+                            i, s_ = self.score_last(profiles, k, **(score_kw or {}))
+                            idxs.append(i); scs.append(s_)
+                    acc.setdefault(S, []).append((rows, np.concatenate(Es), np.concatenate(idxs) if idxs else None, np.concatenate(scs) if scs else None))
+                    off += Bs
+            finally:
+                ing.release(ticket, None)
+        out = {}
+        for S in tables:
+            got = acc.get(S, [])
+            if len(got) == 1 and got[0][0] is None:
+                out[S] = got[0][1:]
+                continue
+            n = len(tables[S])
+            E = np.empty((n, d), np.float32)
+            idx = np.empty((n, k), np.int32) if profiles is not None and n else None
+            sc = np.empty((n, k), np.float32) if profiles is not None and n else None
+            for rows, e, i, s_ in got:                                  # scatter every piece's windows to their rows of the table
+                E[rows] = e
+                if idx is not None:
+                    idx[rows] = i; sc[rows] = s_
+            out[S] = (E, idx, sc)
         return out
 
     def forward(self, feats: DevBuf, B: int, T: int) -> DevBuf:

@@ -295,27 +295,45 @@ class Engine:
         The recording is uploaded once through the pinned staging slots (the next call's upload overlaps this call's forward); the overlapping
         windows are never materialised.  Windows go through in batches of `step`; forward(feats, B, T) defaults to the ECAPA-TDNN forward
         (Backend passes the x-vector's).  Bit-identical to embed_pcm on the host-cut windows."""
+        from .ingest import chunk_samples, plan_chunks
         forward = forward or self.ecapa_forward
-        order = sorted(tables)
-        flat = np.concatenate([np.ascontiguousarray(tables[S], dtype=np.int32) for S in order]) if order else np.zeros((0,), np.int32)
         self.desc if forward == self.ecapa_forward else None          # lazy weight load (its uploads run on the current stream) before the fan-out
         st = _stream()
         ing = self.ingest()
-        ticket, ds, dw = ing.submit(samples, flat, max(order) if order else 0, st)
-        out, off = {}, 0
-        try:
-            for S in order:
-                Bs = len(tables[S])
-                parts = []
-                for a in range(0, Bs, step):
-                    b = min(step, Bs - a)
-                    feats = self.fbank_windows(ds, len(samples), dw + 4 * (off + a), b, S)
-                    parts.append(self.l2norm(forward(feats, b, num_frames(S))))
-                out[S] = parts[0] if len(parts) == 1 else tuple(torch.cat([p[i] for p in parts], dim=0) for i in range(3))
-                off += Bs
-        finally:
-            ing.release(ticket, st)
-        self.last_ingest_ticket = ticket
+        samples = np.ascontiguousarray(samples, dtype=np.int16).reshape(-1)
+        pieces = plan_chunks(len(samples), tables, chunk_samples())   # one piece unless the recording is longer than a staging slot may be
+        out: Dict[int, tuple] = {}
+        for lo, hi, sub in pieces:
+            order = sorted(sub)
+            flat = np.concatenate([sub[S][1] for S in order]) if order else np.zeros((0,), np.int32)
+            ticket, ds, dw = ing.submit(samples[lo:hi], flat, max(order) if order else 0, st)      # piece i + 1 uploads under piece i's forward
+            off = 0
+            try:
+                for S in order:
+                    rows, local = sub[S]
+                    Bs = len(local)
+                    parts = []
+                    for a in range(0, Bs, step):
+                        b = min(step, Bs - a)
+                        feats = self.fbank_windows(ds, hi - lo, dw + 4 * (off + a), b, S)
+                        parts.append(self.l2norm(forward(feats, b, num_frames(S))))
+                    res = parts[0] if len(parts) == 1 else tuple(torch.cat([p[i] for p in parts], dim=0) for i in range(3))
+                    if rows is None:
+                        out[S] = res
+                    else:                                              # scatter this piece's windows to their rows of the table
+                        if S not in out:
+                            out[S] = tuple(torch.empty((len(tables[S]),) + tuple(r.shape[1:]), dtype=r.dtype, device=r.device) for r in res)
+                        ridx = torch.from_numpy(rows).to(self.device)
+                        for dst, r in zip(out[S], res):
+                            dst[ridx] = r
+                    off += Bs
+            finally:
+                ing.release(ticket, st)
+            self.last_ingest_ticket = ticket
+        for S in tables:                                               # an empty table still has an (empty) result
+            if S not in out:
+                out[S] = (torch.empty((0, self.cfg.embed_dim), dtype=torch.float32, device=self.device),
+                          torch.empty((0, self.cfg.embed_dim), dtype=torch.bfloat16, device=self.device), torch.empty((0,), dtype=torch.float32, device=self.device))
         return out
 
     # ------------------------------------------------------------------ k2

@@ -134,6 +134,7 @@ class ProfileBatch:
     norm: Optional[tuple] = None
     pack_ref: Optional[tuple] = None
     from_pack: bool = False
+    linked: bool = False               # the loader that built this batch made the per-speaker hard links (recorded in the pack's side table)
     uid: int = field(default_factory=lambda: next(_BATCH_UID))      # process-unique identity (device-copy reuse across scoring calls of one batch)
 
     def __len__(self) -> int:
@@ -151,7 +152,7 @@ class ProfileBatch:
 
 
 # ---------------------------------------------------------------------------------------------------------------- packed profile matrix (k7)
-PACK_FORMAT = 1
+PACK_FORMAT = 2      # 2: the side table carries crc32 of the blob and whether the per-speaker links were made
 PACK_KEEP = 8          # packs kept per store (one per candidate set x model; the oldest are pruned at publish time)
 
 
@@ -184,10 +185,12 @@ def _pack_paths(root: Optional[Path], model_version: Optional[str], digest: str)
 
 
 def load_pack(candidates: List[Dict[str, Any]], backend_name: str, model_prefix: Optional[str] = None, root: Optional[Path] = None,
-              model_version: Optional[str] = None, settings: Optional[Dict[str, Any]] = None) -> Optional[ProfileBatch]:
-    """The packed matrix of exactly this candidate set, memory-mapped, or None (no pack, stale format, truncated file).  One JSON read +
-    one mmap whatever P is."""
+              model_version: Optional[str] = None, settings: Optional[Dict[str, Any]] = None, link: bool = False) -> Optional[ProfileBatch]:
+    """The packed matrix of exactly this candidate set, memory-mapped, or None (no pack, stale format, truncated or corrupted file: the side
+    table carries the blob's crc32).  One JSON read + one mmap + one checksum sweep whatever P is.  link: make the embeddings/<speaker_id>/<emb-id>.npy
+    hard links if the builder of the pack did not (it was called with link=False): once, recorded in the side table."""
     import json
+    import zlib
     digest = candidate_digest(candidates, backend_name, model_prefix, model_version, settings)
     npy, side = _pack_paths(root, model_version, digest)
     try:
@@ -201,6 +204,21 @@ def load_pack(candidates: List[Dict[str, Any]], backend_name: str, model_prefix:
     per_row = 2 * EMBED_DIM * 4 + EMBED_DIM * 2 + 4          # layout: [matrix fp32 P x 192][E fp32 P x 192][Eb bf16 bits P x 192][resid fp32 P]
     if blob.dtype != np.uint8 or blob.ndim != 1 or blob.size != P * per_row or any(len(t.get(k, ())) != P for k in ("speaker_ids", "embedding_ids", "trust_levels")):
         return None
+    if zlib.crc32(blob) != t.get("crc32"):
+        return None
+    if link and not t.get("linked"):
+        # the pack was built by a caller that did not link (or could not): the cheap pass the per-file loader runs per record, once per pack
+        ext_of = {(prof.get("id"), rec.get("id")): rec.get("external_id") for prof in candidates for rec in prof.get("embeddings", {}).get(backend_name, []) or []}
+        for sid, eid in zip(t["speaker_ids"], t["embedding_ids"]):
+            if sid and eid and ext_of.get((sid, eid)):
+                adopt(ext_of[(sid, eid)], sid, eid, root)
+        try:
+            t["linked"] = True
+            tmpj = side.parent / f".{side.stem}.{os.getpid()}.tmp.json"
+            tmpj.write_text(json.dumps(t))
+            os.replace(tmpj, side)
+        except OSError:
+            pass
     return _pack_batch(blob, P, t)
 
 
@@ -220,6 +238,7 @@ def publish_pack(batch: ProfileBatch, E: np.ndarray, Eb_bits: np.ndarray, resid:
     identical bytes and the last rename wins (speaker-process:627-629 runs up to 4 CLI processes at once).  Best effort: a read-only store
     must not break identify."""
     import json
+    import zlib
     if not batch.pack_ref:
         return None
     npy, side, digest = batch.pack_ref
@@ -239,9 +258,14 @@ def publish_pack(batch: ProfileBatch, E: np.ndarray, Eb_bits: np.ndarray, resid:
         tmpj = npy.parent / f".{side.stem}.{os.getpid()}.tmp.json"
         tmpj.write_text(json.dumps({"format": PACK_FORMAT, "digest": digest, "dim": EMBED_DIM, "rows": P, "speaker_ids": batch.speaker_ids,
                                     "embedding_ids": batch.embedding_ids, "trust_levels": batch.trust_levels, "skipped": batch.skipped,
-                                    "warnings": batch.warnings}))
+                                    "warnings": batch.warnings, "crc32": zlib.crc32(blob), "linked": bool(batch.linked)}))
         os.replace(tmpj, side)
-        packs = sorted(npy.parent.glob("pack-*.json"), key=lambda q: q.stat().st_mtime, reverse=True)
+        def age(q):                                                        # another CLI process may prune the same file between glob and stat
+            try:
+                return q.stat().st_mtime
+            except OSError:
+                return 0.0
+        packs = sorted(npy.parent.glob("pack-*.json"), key=age, reverse=True)
         for old in packs[PACK_KEEP:]:                                      # bounded: one pack per (candidate set, model)
             for q in (old, old.with_suffix(".npy")):
                 try:
@@ -268,7 +292,7 @@ def load_profile_batch(candidates: List[Dict[str, Any]], backend_name: str, mode
     different embedding space - its cosines against the current model's embeddings are noise, so it is skipped too."""
     use_pack = pack_enabled() if use_pack is None else use_pack
     if use_pack:
-        hit = load_pack(candidates, backend_name, model_prefix, root, model_version, settings)
+        hit = load_pack(candidates, backend_name, model_prefix, root, model_version, settings, link=link)
         if hit is not None:
             return hit
     rows, sids, eids, trusts, skipped, warns = [], [], [], [], [], []
@@ -308,4 +332,5 @@ def load_profile_batch(candidates: List[Dict[str, Any]], backend_name: str, mode
     if use_pack and len(batch) >= pack_min_rows() and not unreadable:
         digest = candidate_digest(candidates, backend_name, model_prefix, model_version, settings)
         batch.pack_ref = _pack_paths(root, model_version, digest) + (digest,)
+        batch.linked = bool(link)
     return batch

@@ -281,7 +281,10 @@ def calibration_tag() -> str:
     path = os.environ.get("SDK_CALIBRATION_WAV")
     if not path:
         return ""
-    st = os.stat(path)
+    try:
+        st = os.stat(path)
+    except OSError as exc:
+        raise ValueError(f"SDK_CALIBRATION_WAV={path}: cannot read the calibration recording ({exc.strerror or exc})") from exc
     return "-" + hashlib.sha256(f"{os.path.abspath(path)}|{st.st_size}|{st.st_mtime_ns}".encode()).hexdigest()[:8]
 
 

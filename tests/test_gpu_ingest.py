@@ -180,3 +180,65 @@ def test_identify_many_equals_identify_speaker_per_recording(tmp_path, monkeypat
     assert many == one_by_one and len(many) == 5 and all(len(r) >= 1 for r in many)
     assert many[1][0]["speaker_id"] == "carol" and many[3][0]["speaker_id"] == "bob"
     assert be.identify_many([], profiles) == []
+
+
+def test_ingest_slots_are_lazy_sized_and_fall_back_to_pageable_staging(engine, monkeypatch):
+    """a single-recording call (base.py:130-151: one identify per CLI process) touches ONE slot, sized to that recording -
+    not `depth` slots of the largest size; a longer recording grows the slot it lands in and nothing else; where page-locked memory is refused
+    the slot stages through ordinary memory with the same results."""
+    Ingest = sub("ingest").Ingest
+    st = torch.cuda.current_stream().cuda_stream
+    ing = Ingest(engine.lib, engine.ctx, depth=2)
+    assert ing.slot_info(0) == (0, True) and ing.slot_info(1) == (0, True)            # nothing allocated at creation
+    rec = _recording(70.0, 8)                                                         # 1 120 000 samples -> one 2^21-sample slot
+    t, _, _ = ing.submit(rec, np.array([0], np.int32), 32000, st)
+    ing.release(t, st)
+    assert ing.slot_info(t) == (1 << 21, True) and ing.slot_info(1 - t)[0] == 0
+    t2, _, _ = ing.submit(rec[:40000], np.array([0], np.int32), 32000, st)            # the other slot: sized to ITS upload
+    ing.release(t2, st)
+    assert t2 == 1 - t and ing.slot_info(t2)[0] == 1 << 20
+    t3, ds, _ = ing.submit(np.tile(rec, 2), np.array([0], np.int32), 32000, st)       # slot t again, now too small: grown in place
+    back = torch.empty(2 * len(rec), dtype=torch.int16, device="cuda")
+    engine.lib.sdk_memcpy(engine.ctx, back.data_ptr(), ds, 4 * len(rec), 3, st)
+    ing.release(t3, st)
+    assert t3 == t and ing.slot_info(t)[0] == 3 << 20 and np.array_equal(back.cpu().numpy(), np.tile(rec, 2))
+    ing.close()
+    monkeypatch.setenv("SDK_INGEST_NO_PINNED", "1")                                   # what a host at its lock limit answers
+    ing = Ingest(engine.lib, engine.ctx, depth=2)
+    t, ds, dw = ing.submit(rec, np.array([0, 16000], np.int32), 32000, st)
+    got = engine.fbank_windows(ds, len(rec), dw, 2, 32000)
+    ing.release(t, st)
+    want = engine.fbank(torch.from_numpy(wav.materialise_windows(rec, np.array([0, 16000], np.int32), 32000)).cuda())
+    torch.cuda.synchronize()
+    assert ing.slot_info(t) == (1 << 21, False) and torch.equal(got.view(torch.int16), want.view(torch.int16))
+    ing.close()
+
+
+def test_long_recording_goes_through_the_ring_in_pieces(engine, monkeypatch):
+    """A recording longer than a staging slot may be ($SDK_INGEST_CHUNK) is uploaded piece by piece (ingest.plan_chunks): every window is
+    computed from exactly the samples the one-piece form gives it - bit-identical per piece to embed_pcm on that piece's host-cut windows
+    (a piece is its own batch), and equal to the one-piece result within the batch-invariance tolerance - and no slot exceeds the bound."""
+    ingest = sub("ingest")
+    rec = _recording(31.3, 12)
+    s2, _, W = wav.window_starts(len(rec), None)
+    s1 = np.arange(0, len(rec) - 100, 7000, dtype=np.int32)[::-1].copy()               # unsorted table, its last windows run past the end
+    one = engine.embed_from_host(rec, {W: s2, 16000: s1})
+    monkeypatch.setenv("SDK_INGEST_CHUNK", str(1 << 17))                               # 8.2-s pieces
+    pieces = ingest.plan_chunks(len(rec), {W: s2, 16000: s1}, ingest.chunk_samples())
+    assert len(pieces) == 6 and all(hi - lo <= 1 << 17 for lo, hi, _ in pieces)
+    engine._ingest = None                                                              # fresh ring: its slots must stay at the bound
+    got = engine.embed_from_host(rec, {W: s2, 16000: s1})
+    torch.cuda.synchronize()
+    assert max(engine.ingest().slot_info(i)[0] for i in range(2)) == 1 << 20
+    for S, table in ((W, s2), (16000, s1)):
+        assert got[S][0].shape == one[S][0].shape and float((got[S][0] - one[S][0]).abs().max()) < 1e-3
+        for lo, hi, sub_ in pieces:
+            if S in sub_:
+                rows, local = sub_[S]
+                assert np.array_equal(table[rows], local + lo)
+                want = engine.embed_pcm(torch.from_numpy(wav.materialise_windows(rec, table[rows], S)).cuda())
+                assert torch.equal(got[S][0][torch.from_numpy(rows).cuda()], want[0])
+    # the torch-free host path plans the same pieces
+    lite = sub("lite").LiteEngine(0)
+    gl = lite.embed_from_host(rec, {W: s2, 16000: s1})
+    assert np.array_equal(gl[W][0], got[W][0].cpu().numpy()) and np.array_equal(gl[16000][0], got[16000][0].cpu().numpy())

@@ -516,7 +516,8 @@ def test_vectors_remember_their_numerical_setting(tmp_path, monkeypatch):
 def test_db_listing_pack_follows_every_change(tmp_path, monkeypatch, capsys):
     """a7 at BASELINE's profile counts: the in-process counterpart of `speaker_detection identify` (which reads every db/*.json per call,
     speaker_detection:206-220) keeps the parsed list as one file keyed by the directory listing; an edit, an addition and a deletion each
-    invalidate it; a broken file warns on a miss AND on a hit; dot-files and the pack itself are not profiles."""
+    invalidate it; a broken file warns on a miss AND on a hit.  The pack lives OUTSIDE db/ (ADVICE r4 high): db/ is shared with the reference
+    CLI, whose `db_path.glob("*.json")` matches dot-files - listed exactly that way below, db/ must hold the real profiles and nothing else."""
     ident = sub("identify")
     monkeypatch.setenv("SPEAKERS_EMBEDDINGS_DIR", str(tmp_path))
     db = tmp_path / "db"
@@ -525,21 +526,38 @@ def test_db_listing_pack_follows_every_change(tmp_path, monkeypatch, capsys):
         (db / f"s{i:03d}.json").write_text(json.dumps({"id": f"s{i:03d}", "tags": ["a"] if i % 2 else [], "embeddings": {"mi355x": [{"id": f"e{i}"}]}}))
     (db / "broken.json").write_text("{not json")
     first = ident.list_all_speakers()
-    assert [p["id"] for p in first] == [f"s{i:03d}" for i in range(70)] and (db / ".profiles-pack.json").exists()
+    pack = tmp_path / "cache" / "profiles-pack.json"
+    assert [p["id"] for p in first] == [f"s{i:03d}" for i in range(70)] and pack.exists() and ident.listing_pack_path() == pack
+    # the reference's own listing of db/ after the pack was built (speaker_detection:213): the 70 profiles + the broken file, every one with an 'id'
+    ref_listing = sorted(db.glob("*.json"))
+    assert [q.name for q in ref_listing] == ["broken.json"] + [f"s{i:03d}.json" for i in range(70)]
+    assert all("id" in json.loads(q.read_text()) for q in ref_listing if q.name != "broken.json")
+    assert [q.name for q in db.iterdir() if q.name.startswith(".")] == []          # no temp / cache files left inside db/ either
     assert "broken.json" in capsys.readouterr().err
     reads = []
     real = Path.read_text
     monkeypatch.setattr(Path, "read_text", lambda self, *a, **k: (reads.append(self.name), real(self, *a, **k))[1])
     again = ident.list_all_speakers()
-    assert again == first and reads == [".profiles-pack.json"]                     # ONE file opened, whatever the number of speakers
+    assert again == first and reads == ["profiles-pack.json"]                      # ONE file opened, whatever the number of speakers
     assert "broken.json" in capsys.readouterr().err
     (db / "s005.json").write_text(json.dumps({"id": "s005", "tags": ["edited"], "embeddings": {}}))       # edit (size and mtime change)
     assert ident.list_all_speakers()[5]["tags"] == ["edited"]
+    # a same-size rewrite with the old mtime restored (coarse-mtime file systems, mtime-preserving tools): ctime still moves
+    st = (db / "s006.json").stat()
+    body = (db / "s006.json").read_text()
+    (db / "s006.json").write_text(body.replace('"e6"', '"E6"'))
+    os.utime(db / "s006.json", ns=(st.st_atime_ns, st.st_mtime_ns))
+    assert (db / "s006.json").stat().st_size == st.st_size and (db / "s006.json").stat().st_mtime_ns == st.st_mtime_ns
+    assert ident.list_all_speakers()[6]["embeddings"]["mi355x"][0]["id"] == "E6"
     (db / "s070.json").write_text(json.dumps({"id": "s070", "embeddings": {}}))                           # addition
     assert len(ident.list_all_speakers()) == 71
     (db / "s000.json").unlink()                                                                           # deletion
     assert ident.list_all_speakers()[0]["id"] == "s001" and len(ident.list_all_speakers()) == 70
+    # a dot-file in db/ IS a profile to the reference's glob, so it is one here too (and sorts first)
+    (db / ".hidden.json").write_text(json.dumps({"id": "hidden", "embeddings": {}}))
+    assert ident.list_all_speakers()[0]["id"] == "hidden" and len(ident.list_all_speakers()) == 71
+    (db / ".hidden.json").unlink()
     assert len(ident.candidates_for("mi355x", tags=["a"])) == 34
     monkeypatch.setenv("SDK_PROFILE_PACK", "0")
     reads.clear()
-    assert len(ident.list_all_speakers()) == 70 and ".profiles-pack.json" not in reads and len(reads) == 71
+    assert len(ident.list_all_speakers()) == 70 and "profiles-pack.json" not in reads and len(reads) == 71
