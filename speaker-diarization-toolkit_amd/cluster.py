@@ -36,6 +36,8 @@ class SpectralResult:
     eigenvalues: np.ndarray       # [k] descending (of S = D^-1/2 A D^-1/2)
     n_iter: int
     timing: Optional[dict] = None  # seconds per phase when spectral_cluster(..., trace=True) (each phase then ends with a device sync)
+    rows: Optional[np.ndarray] = None  # spectral_cluster(..., keep_rows=True): the [N, k] unit rows of the Ritz vectors that k-means clustered (all ranks' rows)
+    retried: bool = False          # the subspace iteration was repeated with shifted CholeskyQR (a pivot fell under the relative-pivot rule)
 
 
 class _Comm:
@@ -63,7 +65,7 @@ def canonical_labels(lab: np.ndarray) -> np.ndarray:
 
 
 def spectral_cluster(provider, E_local: torch.Tensor, Eb_local: torch.Tensor, n_total: int, k: int, n_iter: int = 30,
-                     n_kmeans: int = 20, seed: int = 0, group=None, trace: bool = False) -> SpectralResult:
+                     n_kmeans: int = 20, seed: int = 0, group=None, trace: bool = False, keep_rows: bool = False) -> SpectralResult:
     """E_local / Eb_local: this rank's unit-norm embedding rows (fp32 / bf16) under
     dist.shard_bounds(n_total, world).  Returns identical results on every rank."""
     import time
@@ -115,6 +117,7 @@ def spectral_cluster(provider, E_local: torch.Tensor, Eb_local: torch.Tensor, n_
         mark("apply_S")
         return Vc, comm.sum_(provider.rows_gram(Vc, SVc)).double().cpu().numpy()
 
+    retried = False
     V, H = iterate(False)
     flagged = int(comm.sum_(spd_flag.float()).item()) > 0                # every rank takes the same branch (the Gram matrices are all-reduced: normally equal anyway)
     if flagged and np.isfinite(H).all() and hasattr(provider, "set_option"):
@@ -122,6 +125,7 @@ def spectral_cluster(provider, E_local: torch.Tensor, Eb_local: torch.Tensor, n_
         # near 1e-3 - where plain CholeskyQR2 is at the edge of what an fp32 Gram matrix carries.  One retry with SHIFTED CholeskyQR
         # (first pass on G + 1e-5 mean(diag) I, then two plain passes: "CholeskyQR3"), judged by the same rule on its plain passes.
         spd_flag.zero_()
+        retried = True
         V, H = iterate(True)
         flagged = int(comm.sum_(spd_flag.float()).item()) > 0
     if flagged or not np.isfinite(H).all():
@@ -142,7 +146,8 @@ def spectral_cluster(provider, E_local: torch.Tensor, Eb_local: torch.Tensor, n_
     lab_all = comm.gather_rows(labels_loc.reshape(-1, 1), n_total).reshape(-1)
     labels = canonical_labels(lab_all.cpu().numpy())
     mark("labels")
-    return SpectralResult(labels, lam[order], n_iter, timing)
+    rows = comm.gather_rows(R, n_total).cpu().numpy() if keep_rows else None
+    return SpectralResult(labels, lam[order], n_iter, timing, rows, retried)
 
 
 def _orth(provider, comm: _Comm, Y: torch.Tensor, k: int, spd_flag: Optional[torch.Tensor] = None, shifted: bool = False) -> torch.Tensor:

@@ -685,20 +685,44 @@ def test_spectral_cluster_survives_over_clustering_on_tight_data(engine, monkeyp
     """k just above the true number of speakers on low-noise embeddings puts lambda_k / lambda_1 near the relative-pivot rule of
     sdk_chol_inverse (1e-6 of the diagonal: cond(Y) ~ 1e3), where plain CholeskyQR2 used to end the whole shard in LinAlgError after all
     embeddings had been computed.  spectral_cluster now retries once with shifted CholeskyQR; exact duplicates (a true rank loss: the test
-    above) still raise.  With ONE surplus cluster every cluster found lies inside one true speaker (a speaker is split, none are mixed); with
-    several surplus directions k-means may trade a split for a merge, so there only completion and finiteness are asserted."""
+    above) still raise.
+
+    Compared with oracle/spectral.py on the SAME bf16 rows, k, iteration counts and seed (VERDICT r4 next #1a).  With k above the speaker
+    count c the surplus eigenvalues sit at the noise floor (oracle: 1e-5 / 0, 0 / 4.9e-4, -1.9e-4 for the three cases), so the surplus Ritz
+    DIRECTIONS are not determined by the data - float64 QR and fp32 CholeskyQR legitimately pick different ones - and a label-for-label match
+    is not a property of the algorithm.  What is determined, and asserted:
+      * the c leading eigenvalues equal the oracle's (they are separated from the floor by > 0.6) and the surplus ones are at the floor in both;
+      * k-means itself: the oracle's k-means on the GPU's own rows gives the GPU's labels, row for row;
+      * purity wherever the ORACLE is pure: cases (0.02, 4, 5) and (0.005, 3, 5) split speakers and mix none, in the oracle and here.  At
+        (0.05, 6, 8) the oracle itself puts 63 rows of FOUR speakers into one of its two surplus clusters (two noise directions: k-means
+        trades a split for a merge), so the two-speaker cluster the GPU path showed in round 4 is the algorithm's behaviour, not the retry's:
+        there the assertion is that at least c clusters are pure and the mixed clusters are small (no worse than twice the oracle's mixed rows)."""
     shifted = []
     real = engine.set_option
     monkeypatch.setattr(engine, "set_option", lambda n, v: (shifted.append((n, v)), real(n, v))[1])
+
+    def mixed_rows(lab, truth):
+        return sum(int((lab == l).sum()) for l in np.unique(lab) if len(np.unique(truth[lab == l])) > 1)
+
     for noise, c, k in ((0.02, 4, 5), (0.005, 3, 5), (0.05, 6, 8)):
         E, truth = ospec.vmf_mixture(1500, 192, c, seed=7 + c, noise=noise)
         En, Eb, _ = engine.l2norm(dev(E))
-        res = CL.spectral_cluster(engine, En, Eb, 1500, k, n_iter=12, n_kmeans=10, seed=0)
+        res = CL.spectral_cluster(engine, En, Eb, 1500, k, n_iter=12, n_kmeans=10, seed=0, keep_rows=True)
+        olab, olam = ospec.spectral_cluster(Eb.float().cpu().numpy(), k, n_iter=12, n_kmeans=10, seed=0)
         assert np.isfinite(res.eigenvalues).all() and len(np.unique(res.labels)) <= k
-        if k <= c + 2 and noise <= 0.02:
-            for lab in np.unique(res.labels):
-                assert len(np.unique(truth[res.labels == lab])) == 1, (noise, c, k, lab)
-    print("\nshifted CholeskyQR retries:", sum(1 for n, v in shifted if n == "chol_shift_ppb" and v > 0))
+        assert np.abs(res.eigenvalues[:c] - olam[:c]).max() < 2e-4, (noise, c, k, res.eigenvalues, olam)
+        assert np.abs(res.eigenvalues[c:]).max() < 5e-3 and np.abs(olam[c:]).max() < 5e-3, (res.eigenvalues, olam)
+        klab, _ = ospec.kmeans_maximin(res.rows.astype(np.float64), k, 10)
+        assert np.array_equal(ospec.canonical_labels(klab), res.labels), (noise, c, k)
+        o_mixed, g_mixed = mixed_rows(olab, truth), mixed_rows(res.labels, truth)
+        print(f"\n(noise {noise}, c {c}, k {k}): retried {res.retried}; rows in mixed clusters: oracle {o_mixed}, gpu {g_mixed}; "
+              f"cluster sizes oracle {np.bincount(olab).tolist()} gpu {np.bincount(res.labels).tolist()}")
+        if o_mixed == 0:
+            assert g_mixed == 0, (noise, c, k, g_mixed)
+        else:
+            pure = sum(1 for l in np.unique(res.labels) if len(np.unique(truth[res.labels == l])) == 1)
+            assert pure >= c and g_mixed <= 2 * o_mixed, (noise, c, k, pure, g_mixed, o_mixed)
+    print("shifted CholeskyQR retries:", sum(1 for n, v in shifted if n == "chol_shift_ppb" and v > 0))
     assert all(v in (0, 10_000) for n, v in shifted if n == "chol_shift_ppb")
 
 
