@@ -14,6 +14,8 @@
 // written as whole 16-B chunks; optional second output S = bf16(C + X2) (Res2Net chain).
 #include <stdlib.h>
 
+#include <type_traits>
+
 #include "common.hpp"
 
 namespace {
@@ -288,13 +290,27 @@ __global__ __launch_bounds__(NT2, 2) void conv_gemm256_kernel(Params p) {
   // is left is W re-fetched by every XCD in every round: 13 x 8 x 2 MB), the 3072^2 layer 9223 -> 6807 MB (A once per unit = 3x, W once per
   // unit: (8 + 4) x 1.57 MB x 296 units - the floor for 32 tiles of 256^2 per 4-MiB L2).  A per-XCD round barrier on top (bounded
   // spin on an XCD-local counter) changed neither the bytes nor the time: inside a unit the readers already stay together.
+  // (Round 2's other order knobs - plain n-fastest, one workgroup walking all n-tiles of an m-tile - were measured behind both and are gone.)
+  //
+  // HALF-TILE TAIL (round 5).  What the whole rounds leave over is normally a last round with most CUs idle: the six K = 1024 layers of the
+  // forward have 3144 tiles = 12 rounds of 256 + 72 tiles, a 13th round 28 % full that costs as much as a full one.  When the left-over region
+  // - always the bottom rows of the matrix, all columns - fits the grid as 128 x 256 HALF tiles (here 35 half row blocks x 4 = 140 of them),
+  // the rounds stop at R and every workgroup takes at most one half tile: same LDS image and fragment order, 4 instead of 8 accumulator
+  // row blocks per wave (2 x 4 waves of 64 x 64), so every output element sees the same K order and the result - and the per-half-tile
+  // partials of the fused column statistics, which were per 128 rows already - are bit-identical to the whole-tile schedule
+  // (tests/test_gpu_kernels.py::test_conv_gemm_half_tile_tail_is_bit_identical).  tune bit 9 (`gemm_variant` 8194) switches it off: A/B.
   const int G = gridDim.x;
   const bool unit_order = !(p.tune & 64) && G == 256 && (nbn & 3) == 0 && nbm >= 64;
   const int xcd = blockIdx.x & 7, slot = blockIdx.x >> 3;
   const int nch = nbn >> 2, mg_full = nbm >> 3;
   const int full_units = mg_full * nch, R = full_units >> 3, rem_units = full_units - 8 * R;
   const int gm_tail = nbm & 7, tail_tiles = gm_tail * nbn;
-  const int nrounds = unit_order ? R + (rem_units + (tail_tiles + 31) / 32 + 7) / 8 : (ntiles + G - 1) / G;
+  // left-over region of the unit order: m-tiles [mt0, nbm) x all columns, provided the R whole rounds end on an m-group boundary
+  const int mt0 = unit_order && (8 * R) % nch == 0 ? ((8 * R) / nch) * 8 : 0;
+  const int n_half_m = 2 * (nbm - mt0);                                   // half row blocks of the region (the last one may lie wholly below the matrix)
+  const int half_cap = 32 / nbn;                                          // half row blocks one XCD's 32 workgroups can take (all nbn columns each)
+  const bool half_tail = unit_order && !(p.tune & 512) && (8 * R) % nch == 0 && R > 0 && mt0 < nbm && n_half_m <= 8 * half_cap;
+  const int nrounds = unit_order ? (half_tail ? R : R + (rem_units + (tail_tiles + 31) / 32 + 7) / 8) : (ntiles + G - 1) / G;
   auto tile_coords = [&](int i, int& tm0, int& tn0) -> bool {
     if (unit_order) {
       int u;
@@ -323,28 +339,13 @@ __global__ __launch_bounds__(NT2, 2) void conv_gemm256_kernel(Params p) {
     const int per_group = GM * nbn;
     const int grp = tile / per_group, in_grp = tile - grp * per_group;
     const int gm = min(nbm - grp * GM, GM);
-    const bool rowmajor = (p.tune & 4) != 0;            // A/B knob: plain n-fastest order
-    tm0 = (rowmajor ? tile / nbn : grp * GM + in_grp % gm) * BM2;
-    tn0 = (rowmajor ? tile % nbn : in_grp / gm) * BN2;
-    if (p.tune & 32) {
-      // A/B knob: a workgroup walks ALL n-tiles of one m-tile back to back (its A row block is re-read from the Infinity Cache by
-      // the same CU instead of by three other workgroups at unrelated times); the last, partial round of m-tiles is dealt out
-      // tile by tile so the tail stays one tile long.
-      const int b = blockIdx.x;
-      const int full_rounds = nbm / G;                  // m-rounds in which every workgroup owns an m-tile
-      if (i < full_rounds * nbn) {
-        tm0 = (b + G * (i / nbn)) * BM2;
-        tn0 = (i % nbn) * BN2;
-      } else {
-        const int j = (i - full_rounds * nbn) * G + b;  // tail: tile index inside the remaining (nbm % G) m-tiles, n fastest
-        tm0 = (full_rounds * G + j / nbn) * BM2;
-        tn0 = (j % nbn) * BN2;
-      }
-    }
+    tm0 = (grp * GM + in_grp % gm) * BM2;
+    tn0 = (in_grp / gm) * BN2;
     return true;
   };
 
-  // ---- DMA assignment: wave wid fills rows [32 wid, 32 wid + 32) of A and of B, 8 rows per instruction.
+  // ---- DMA assignment: wave wid fills rows [8 AP wid, 8 AP wid + 8 AP) of A (AP = 4 pieces per wave for a whole tile, 2 for a half tile) and rows
+  // [32 wid, 32 wid + 32) of B, 8 rows per instruction.
   // Addresses are (uniform base pointer advanced per K-step on the scalar unit) + (32-bit per-lane byte offset fixed per
   // tile): a 1 x 1 layer's K loop then carries NO vector arithmetic for its 8 DMA pieces (it had ~40 VALU + 8 readfirstlane
   // per K-step; beside MFMAs that is clock, not cycles - MI355X_MICROARCH 'DVFS give-back' item 4).  The host routes operands
@@ -352,27 +353,29 @@ __global__ __launch_bounds__(NT2, 2) void conv_gemm256_kernel(Params p) {
   const int rin = lane >> 3, pos = lane & 7;
   const int gch = (pos ^ rin) * 8;                   // source chunk (elements) for this lane's LDS position
   const int wu = __builtin_amdgcn_readfirstlane(wid);
-  const bool a_nt = !TAPS && nbn <= 4 && !(p.tune & 256);      // (gemm_variant 4098 switches the hint off: A/B)
-  uint32_t aoff[4];                                  // !TAPS: byte offset of this lane's chunk in each of its 4 A rows (rows step by 8)
+  const bool a_nt = !TAPS && nbn <= 4;
+  uint32_t aoff[4];                                  // !TAPS: byte offset of this lane's chunk in each of its A rows (rows step by 8)
   int aseg0 = 0, atl0 = 0;                           // TAPS: segment base row and in-segment frame of the first row
   uint32_t woff;
-  auto setup_dma = [&](int tm0, int tn0) {
-    const int row = 32 * wu + rin;
+  auto setup_dma = [&](int tm0, int tn0, auto ap_c) {
+    constexpr int AP = decltype(ap_c)::value;
+    const int row = 8 * AP * wu + rin;
     if constexpr (TAPS) {
       const int mm = min(tm0 + row, p.M - 1);
       aseg0 = (mm / p.T) * p.T;
       atl0 = mm - aseg0;                             // rows past M fetch some valid row; their results are dropped
     } else {
 #pragma unroll
-      for (int i = 0; i < 4; ++i) aoff[i] = ((uint32_t)min(tm0 + row + 8 * i, p.M - 1) * (uint32_t)p.lda + (uint32_t)gch) * 2u;
+      for (int i = 0; i < AP; ++i) aoff[i] = ((uint32_t)min(tm0 + row + 8 * i, p.M - 1) * (uint32_t)p.lda + (uint32_t)gch) * 2u;
     }
-    woff = ((uint32_t)(tn0 + row) * (uint32_t)Ktot + (uint32_t)gch) * 2u;
+    woff = ((uint32_t)(tn0 + 32 * wu + rin) * (uint32_t)Ktot + (uint32_t)gch) * 2u;
   };
-  auto issue = [&](int t, int stage) {
+  auto issue = [&](int t, int stage, auto ap_c) {
+    constexpr int AP = decltype(ap_c)::value;
     const int j = t / ksteps_per_tap;
     const int kc = (t - j * ksteps_per_tap) * BK;
-    char* sA = smem + stage * STAGE2 + (32 * wu) * 128;
-    char* sB = sA + BM2 * BK * 2;
+    char* sA = smem + stage * STAGE2 + (8 * AP * wu) * 128;
+    char* sB = smem + stage * STAGE2 + BM2 * BK * 2 + (32 * wu) * 128;
     const char* abase = reinterpret_cast<const char*>(p.A + kc);
     if constexpr (TAPS) {
       int off = (j - half) * p.dil;
@@ -387,9 +390,9 @@ __global__ __launch_bounds__(NT2, 2) void conv_gemm256_kernel(Params p) {
         off = (tap - half) * p.dil;
       }
 #pragma unroll
-      for (int i = 0; i < 4; ++i) {
+      for (int i = 0; i < AP; ++i) {
         int tl = atl0 + 8 * i, sb = aseg0;
-        if (tl >= p.T) { tl -= p.T; sb += p.T; }      // T >= 64 > 24: at most one segment boundary inside the 4 rows
+        if (tl >= p.T) { tl -= p.T; sb += p.T; }      // T >= 64 > 24: at most one segment boundary inside the rows of a wave
         const uint32_t src = (uint32_t)min(sb + reflect_idx(tl + off, p.T), p.M - 1);
         __builtin_amdgcn_global_load_lds((gptr_t)(abase + (size_t)((src * (uint32_t)p.lda + acol) * 2u)), (lptr_t)(sA + i * 1024), 16, 0, 0);
       }
@@ -399,11 +402,11 @@ __global__ __launch_bounds__(NT2, 2) void conv_gemm256_kernel(Params p) {
       // 619 -> 429 MB read per launch = 1.04 x A + W; the four readers of a block still hit each other's lines).  Not for wider layers:
       // on 3072^2 the m-group's A is re-read by three n-chunks from the Infinity Cache, and the hint costs 10 % there.
 #pragma unroll
-      for (int i = 0; i < 4; ++i)
+      for (int i = 0; i < AP; ++i)
         __builtin_amdgcn_global_load_lds((gptr_t)(abase + (size_t)aoff[i]), (lptr_t)(sA + i * 1024), 16, 0, 2);
     } else {
 #pragma unroll
-      for (int i = 0; i < 4; ++i)
+      for (int i = 0; i < AP; ++i)
         __builtin_amdgcn_global_load_lds((gptr_t)(abase + (size_t)aoff[i]), (lptr_t)(sA + i * 1024), 16, 0, 0);
     }
     const char* wbase = reinterpret_cast<const char*>(p.W + (j * cin_w + kc));
@@ -411,27 +414,34 @@ __global__ __launch_bounds__(NT2, 2) void conv_gemm256_kernel(Params p) {
     for (int i = 0; i < 4; ++i)
       __builtin_amdgcn_global_load_lds((gptr_t)(wbase + (size_t)i * 16 * Ktot + (size_t)woff), (lptr_t)(sB + i * 1024), 16, 0, 0);
   };
+  constexpr std::integral_constant<int, 4> kWhole{};
+  constexpr std::integral_constant<int, 2> kHalf{};
 
   const int fr = lane & 15, fq = lane >> 4, sw = lane & 7;
   const uint32_t a_base = (wm * 128 + fr) * 128;
   const uint32_t b_base = BM2 * BK * 2 + (wn * 64 + fr) * 128;
   const uint32_t c0 = ((0 * 4 + fq) ^ sw) << 4, c1 = ((1 * 4 + fq) ^ sw) << 4;
-  const int pol = p.tune & 3;   // 0: waves 0-3 early / 4-7 late (default), 1: all early, 2: all late, 3: odd/even
-  const bool dma_early = pol == 1 ? true : pol == 2 ? false : pol == 3 ? (wu & 1) == 0 : wu < 4;
+  // the two waves that share a SIMD issue their DMA at different points of a K-step: waves 0-3 right after the barrier, 4-7 after the last MFMA
+  // sub-phase (round 2 measured all-early, all-late and odd / even behind this; as a run-time policy it sat inside the K loop - a compile-time fact now)
+  const bool dma_early = wu < 4;
   const bool relu = p.flags & SDK_GEMM_RELU;
   const bool stats = p.stats_part != nullptr;
   float* par = reinterpret_cast<float*>(smem + LDS2);            // [3][256]: bias, scale, shift of the tile's columns
 
   int nst = 0;
-  auto stamp = [&]() {
+  auto stamp = [&]() {   // diagnostics (tools/gemm_timeline.py): per-tile phase stamps of workgroup 0, outside the K loop
     if (p.stamps && blockIdx.x == 0 && tid == 0 && nst < 4096) p.stamps[nst++] = __builtin_amdgcn_s_memrealtime();
+  };
+  auto ldB = [&](const char* st, bf16x8* dst, uint32_t coff) {
+#pragma unroll
+    for (int ni = 0; ni < 4; ++ni) dst[ni] = *reinterpret_cast<const bf16x8*>(st + b_base + ni * 2048 + coff);
   };
   // Persistent workgroups (one per CU; the grid is a multiple of 8 so a workgroup keeps its XCD class) walk
   // their tiles back to back.
   for (int rnd = 0; rnd < nrounds; ++rnd) {
     int m0, n0;
     if (!tile_coords(rnd, m0, n0)) continue;
-    setup_dma(m0, n0);
+    setup_dma(m0, n0, kWhole);
     // the tile's 256 columns of epilogue parameters travel through LDS: the loads ride under the K loop
     float pb = 0.f, psc = 1.f, psh = 0.f;
     if (tid < BN2) {
@@ -446,10 +456,6 @@ __global__ __launch_bounds__(NT2, 2) void conv_gemm256_kernel(Params p) {
       for (int ni = 0; ni < 4; ++ni) acc[mi][ni] = f32x4{0.f, 0.f, 0.f, 0.f};
 
     bf16x8 b0[4], b1[4], a0[4], a1[4];
-    auto ldB = [&](const char* st, bf16x8* dst, uint32_t coff) {
-#pragma unroll
-      for (int ni = 0; ni < 4; ++ni) dst[ni] = *reinterpret_cast<const bf16x8*>(st + b_base + ni * 2048 + coff);
-    };
     auto ldA = [&](const char* st, bf16x8* dst, int mh, uint32_t coff) {
 #pragma unroll
       for (int mi = 0; mi < 4; ++mi) dst[mi] = *reinterpret_cast<const bf16x8*>(st + a_base + (mh * 4 + mi) * 2048 + coff);
@@ -472,9 +478,9 @@ __global__ __launch_bounds__(NT2, 2) void conv_gemm256_kernel(Params p) {
     //   P0 P1 P2 | own reads of tile t done, own DMA of tile t+1 landed, barrier |
     //   issue DMA of tile t+2 into the stage just freed, prefetch tile t+1's first fragments | P3
     // The two waves that share a SIMD issue their DMA at different points (before / after P3).
-    issue(0, 0);
+    issue(0, 0, kWhole);
     if (nk > 1) {
-      issue(1, 1);
+      issue(1, 1, kWhole);
       asm volatile("s_waitcnt vmcnt(8)" ::: "memory");      // K-step 0 and the epilogue parameters have landed
     } else {
       asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
@@ -507,17 +513,14 @@ __global__ __launch_bounds__(NT2, 2) void conv_gemm256_kernel(Params p) {
       mma_half(a0, b1, 0, 1);
       __builtin_amdgcn_sched_barrier(0);
       if (t + 1 < nk) {
-        // diagnostics (tune bit 7 = gemm_variant 2050, tools/gemm_kstep.py): where a K-step waits.  Measured: MFMA time 1.02-1.14 us of a
-        // 1.56-1.64-us step; ~0.3 us waiting for the wave's own DMA of the next step and ~0.1-0.2 us at the barrier.  Pulling the A lines
-        // into L2 two steps early (one 4-byte LDS-DMA "touch" per row and wave, younger than the DMA pieces so the counted wait leaves it
-        // in flight) moved the wait from the vmcnt to the barrier - their sum stayed ~0.5 us - and cost 2-4 % wall time: what the
-        // step waits for is the slowest wave's eight LDS-DMA issues (100-185 cycles each beside ds_reads), not HBM latency.
-        if (p.tune & 128) stamp();
+        // Where a K-step waits (round 3, tools/gemm_kstep.py on a diagnostic build with stamps around the wait and the barrier; the stamps are not
+        // compiled in any more): MFMA time 1.02-1.14 us of a 1.56-1.64-us step; ~0.3 us waiting for the wave's own DMA of the next step and
+        // ~0.1-0.2 us at the barrier.  Pulling the A lines into L2 two steps early (one 4-byte LDS-DMA "touch" per row and wave, younger than
+        // the DMA pieces so the counted wait leaves it in flight) moved the wait from the vmcnt to the barrier - their sum stayed ~0.5 us - and
+        // cost 2-4 % wall time: what the step waits for is the slowest wave's eight LDS-DMA issues (100-185 cycles each beside ds_reads), not HBM latency.
         asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
-        if (p.tune & 128) stamp();
         __builtin_amdgcn_s_barrier();
-        if (p.tune & 128) stamp();
-        if (dma_early && t + 2 < nk) issue(t + 2, t & 1);
+        if (dma_early && t + 2 < nk) issue(t + 2, t & 1, kWhole);
         const char* sn = smem + ((t + 1) & 1) * STAGE2;
         ldB(sn, b0, c0);
         ldA(sn, a0, 0, c0);
@@ -526,7 +529,7 @@ __global__ __launch_bounds__(NT2, 2) void conv_gemm256_kernel(Params p) {
       mma_half(a1, b1, 1, 0);                           // P3
       mma_half(a1, b1, 1, 1);
       __builtin_amdgcn_sched_barrier(0);
-      if (!dma_early && t + 2 < nk) issue(t + 2, t & 1);
+      if (!dma_early && t + 2 < nk) issue(t + 2, t & 1, kWhole);
     }
 
     stamp();
@@ -616,234 +619,89 @@ __global__ __launch_bounds__(NT2, 2) void conv_gemm256_kernel(Params p) {
     lds_barrier();                                      // the image is free: the next tile's DMA may overwrite it
     stamp();
   }   // persistent tile loop
-  if (p.clk && tid == 0 && blockIdx.x < 4096) {
-    p.clk[blockIdx.x * 2] = __builtin_amdgcn_s_memtime() - clk_c0;
-    p.clk[blockIdx.x * 2 + 1] = __builtin_amdgcn_s_memrealtime() - clk_r0;
-  }
-}
 
-// ---- v3: the same tile and K loop with the tile boundary overlapped -------------------------------------------------------
-// v2 loses ~5 us of a 35-us K = 1024 tile at the boundary: the epilogue image takes both pipeline stages, so the next
-// tile's first DMA can only be issued after the copy-out, and because vmcnt retires in order its wait also waits for the
-// tile's 16 stores per thread (~3.4 us to drain).  Here
-//   * the stage that the LAST K-step does not use receives the NEXT tile's K-step 0 (and its epilogue parameters, also by
-//     LDS-DMA into a second parameter buffer) while the last two K-steps compute: those DMAs are OLDER than the stores;
-//   * the tile image is written in two 128-row passes (accumulator rows mi 0-3, then 4-7, of EVERY wave) through the one
-//     stage the last K-step has released; each pass is copied out by all 512 threads;
-//   * the next tile's K-step 1 is issued behind the stores, and the wait for K-step 0 is vmcnt(24): it leaves the 16
-//     stores and the 8 DMA pieces of step 1 in flight (full tiles; an edge tile falls back to the conservative count).
-// Stage parity alternates per tile (K-step t of a tile lives in stage (sb + t) & 1).
-constexpr int LDS3_TOTAL = LDS2 + 2 * 3 * BN2 * 4;
-
-template <bool STATS, bool TAPS>
-__global__ __launch_bounds__(NT2, 2) void conv_gemm256_v3_kernel(Params p) {
-  extern __shared__ __attribute__((aligned(16))) char smem[];
-  const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
-  const unsigned long long clk_c0 = p.clk ? __builtin_amdgcn_s_memtime() : 0, clk_r0 = p.clk ? __builtin_amdgcn_s_memrealtime() : 0;
-  const int wm = wid >> 2, wn = wid & 3;
-
-  const int nbn = p.N / BN2;
-  const int nbm = (p.M + BM2 - 1) / BM2;
-  const int ntiles = nbn * nbm;
-  const int Ktot = p.taps * p.Cin;
-  const int ksteps_per_tap = p.Cin / BK;
-  const int nk = p.taps * ksteps_per_tap;
-  const int half = p.taps >> 1;
-
-  auto tile_coords = [&](int vt, int& tm0, int& tn0) {
-    const int tile = xcd_remap(vt, ntiles);
-    constexpr int GM = 8;
-    const int per_group = GM * nbn;
-    const int grp = tile / per_group, in_grp = tile - grp * per_group;
-    const int gm = min(nbm - grp * GM, GM);
-    tm0 = (grp * GM + in_grp % gm) * BM2;
-    tn0 = (in_grp / gm) * BN2;
-  };
-
-  const int rin = lane >> 3, pos = lane & 7;
-  const int gch = (pos ^ rin) * 8;
-  int arow0, aseg0, atl0, woff0;
-  auto setup_dma = [&](int tm0, int tn0) {
-    const int row = 32 * wid + rin;
-    arow0 = tm0 + row;
-    const int mm = min(arow0, p.M - 1);
-    aseg0 = (mm / p.T) * p.T;
-    atl0 = mm - aseg0;
-    woff0 = (tn0 + row) * Ktot + gch;
-  };
-  auto issue = [&](int t, int stage) {
-    const int j = t / ksteps_per_tap;
-    const int kc = (t - j * ksteps_per_tap) * BK;
-    const int off = (j - half) * p.dil;
-    char* sA = smem + stage * STAGE2 + (32 * wid) * 128;
-    char* sB = sA + BM2 * BK * 2;
-    const bf16_t* abase = p.A + kc + gch;
-    if constexpr (TAPS) {
-#pragma unroll
-      for (int i = 0; i < 4; ++i) {
-        int tl = atl0 + 8 * i, sb = aseg0;
-        if (tl >= p.T) { tl -= p.T; sb += p.T; }
-        const int src = min(sb + reflect_idx(tl + off, p.T), p.M - 1);
-        __builtin_amdgcn_global_load_lds((gptr_t)(abase + (int64_t)src * p.lda), (lptr_t)(sA + i * 1024), 16, 0, 0);
+  // ------------------------------------------------------------------ half-tile tail: at most one 128 x 256 tile per workgroup
+  // XCD x takes half row blocks x, x + 8, ... (all nbn column tiles of a block on one XCD: its four readers share the A rows in one L2)
+  if (half_tail && slot / nbn < half_cap && (slot / nbn) * 8 + xcd < n_half_m) {
+    const int hq = slot / nbn;
+    const int m0 = mt0 * BM2 + (hq * 8 + xcd) * 128, n0 = (slot - hq * nbn) * BN2;
+    if (m0 >= p.M) {
+      // the lower half of an edge tile, wholly below the matrix: nothing to compute, but its statistics slot is read by colstats_finish
+      if (stats && tid < BN2) {
+        float* dst = p.stats_part + ((int64_t)((m0 / BM2) * 2 + 1) * 3) * p.N + n0 + tid;
+        dst[0] = 0.f; dst[p.N] = 0.f; dst[2 * (int64_t)p.N] = 0.f;
+        if (p.stats_mode == 2) {
+          float* dq = dst + (int64_t)nbm * 6 * p.N;
+          dq[0] = 0.f; dq[p.N] = 0.f; dq[2 * (int64_t)p.N] = 0.f;
+        }
       }
     } else {
-#pragma unroll
-      for (int i = 0; i < 4; ++i) {
-        const int src = min(arow0 + 8 * i, p.M - 1);
-        __builtin_amdgcn_global_load_lds((gptr_t)(abase + (int64_t)src * p.lda), (lptr_t)(sA + i * 1024), 16, 0, 0);
-      }
+    setup_dma(m0, n0, kHalf);
+    float pb = 0.f, psc = 1.f, psh = 0.f;
+    if (tid < BN2) {
+      if (p.bias) pb = p.bias[n0 + tid];
+      if (p.scale) { psc = p.scale[n0 + tid]; psh = p.shift[n0 + tid]; }
     }
-    const bf16_t* wbase = p.W + (woff0 + j * p.Cin + kc);
+    f32x4 acc[4][4];
 #pragma unroll
-    for (int i = 0; i < 4; ++i)
-      __builtin_amdgcn_global_load_lds((gptr_t)(wbase + i * 8 * Ktot), (lptr_t)(sB + i * 1024), 16, 0, 0);
-  };
-  // epilogue parameters of a tile's 256 columns: three 1-KiB LDS-DMA pieces (bias, scale, shift) by wave 0; arrays that are
-  // absent keep the defaults written once below
-  auto issue_par = [&](int tn0, int pbuf) {
-    if (wid == 0) {
-      char* dst = smem + LDS2 + pbuf * (3 * BN2 * 4);
-      if (p.bias) __builtin_amdgcn_global_load_lds((gptr_t)(p.bias + tn0 + lane * 4), (lptr_t)dst, 16, 0, 0);
-      if (p.scale) {
-        __builtin_amdgcn_global_load_lds((gptr_t)(p.scale + tn0 + lane * 4), (lptr_t)(dst + BN2 * 4), 16, 0, 0);
-        __builtin_amdgcn_global_load_lds((gptr_t)(p.shift + tn0 + lane * 4), (lptr_t)(dst + 2 * BN2 * 4), 16, 0, 0);
-      }
-    }
-  };
-
-  const int fr = lane & 15, fq = lane >> 4, sw = lane & 7;
-  const uint32_t a_base = (wm * 128 + fr) * 128;
-  const uint32_t b_base = BM2 * BK * 2 + (wn * 64 + fr) * 128;
-  const uint32_t c0 = ((0 * 4 + fq) ^ sw) << 4, c1 = ((1 * 4 + fq) ^ sw) << 4;
-  const int wu = __builtin_amdgcn_readfirstlane(wid);
-  const bool dma_early = wu < 4;
-  const bool relu = p.flags & SDK_GEMM_RELU;
-
-  // diagnostics: wall-clock stamps (100 MHz) of workgroup 0's tile phases (debug buffer "gemm_stamps", [4096])
-  int nst = 0;
-  auto stamp = [&]() {
-    if (p.stamps && blockIdx.x == 0 && tid == 0 && nst < 4096) p.stamps[nst++] = __builtin_amdgcn_s_memrealtime();
-  };
-  if (blockIdx.x >= ntiles) return;
-  for (int i = tid; i < 2 * 3 * BN2; i += NT2)                          // parameter defaults (both buffers): bias 0, scale 1, shift 0
-    reinterpret_cast<float*>(smem + LDS2)[i] = ((i / BN2) % 3) == 1 ? 1.f : 0.f;
-  __syncthreads();                                                      // before any DMA lands on top of the defaults
-
-  int m0, n0, sb = 0, pbuf = 0;
-  tile_coords(blockIdx.x, m0, n0);
-  setup_dma(m0, n0);
-  issue(0, 0);
-  issue_par(n0, 0);
-  bool first = true, prev_full = false;
-  for (int vt = blockIdx.x; vt < ntiles; vt += gridDim.x) {
-    const bool has_next = vt + (int)gridDim.x < ntiles;
-    int m0n = 0, n0n = 0;
-    if (has_next) tile_coords(vt + gridDim.x, m0n, n0n);
-    bool prefetched = false;
-    float* par = reinterpret_cast<float*>(smem + LDS2 + pbuf * (3 * BN2 * 4));
-
-    f32x4 acc[8][4];
-#pragma unroll
-    for (int mi = 0; mi < 8; ++mi)
+    for (int mi = 0; mi < 4; ++mi)
 #pragma unroll
       for (int ni = 0; ni < 4; ++ni) acc[mi][ni] = f32x4{0.f, 0.f, 0.f, 0.f};
-
     bf16x8 b0[4], b1[4], a0[4], a1[4];
-    auto ldB = [&](const char* st, bf16x8* dst, uint32_t coff) {
+    const uint32_t a_base_h = (wm * 64 + fr) * 128;      // waves 2 (M) x 4 (N), 64 x 64 each
+    auto ldAh = [&](const char* st, bf16x8* dst, uint32_t coff) {
 #pragma unroll
-      for (int ni = 0; ni < 4; ++ni) dst[ni] = *reinterpret_cast<const bf16x8*>(st + b_base + ni * 2048 + coff);
+      for (int mi = 0; mi < 4; ++mi) dst[mi] = *reinterpret_cast<const bf16x8*>(st + a_base_h + mi * 2048 + coff);
     };
-    auto ldA = [&](const char* st, bf16x8* dst, int mh, uint32_t coff) {
-#pragma unroll
-      for (int mi = 0; mi < 4; ++mi) dst[mi] = *reinterpret_cast<const bf16x8*>(st + a_base + (mh * 4 + mi) * 2048 + coff);
-    };
-    auto mma_half = [&](const bf16x8* af, const bf16x8* bf, int mh, int part) {
+    auto mma_h = [&](const bf16x8* af, const bf16x8* bf, int part) {
       __builtin_amdgcn_s_setprio(1);
 #pragma unroll
       for (int mi = 2 * part; mi < 2 * part + 2; ++mi)
 #pragma unroll
         for (int ni = 0; ni < 4; ++ni)
-          acc[mh * 4 + mi][ni] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(bf[ni], af[mi], acc[mh * 4 + mi][ni], 0, 0, 0);
+          acc[mi][ni] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(bf[ni], af[mi], acc[mi][ni], 0, 0, 0);
       __builtin_amdgcn_s_setprio(0);
     };
-    // the DMA slot of K-step t: the stage step t has just released takes step t+2 of this tile, or - once the tile has no
-    // further K-step - step 0 of the NEXT tile (ONE issue() call site: a second copy of the address code costs registers
-    // the K loop does not have)
-    auto dma_slot = [&](int t) {
-      int ts = t + 2;
-      if (ts == nk) {
-        if (!has_next) return;
-        setup_dma(m0n, n0n);
-        ts = 0;
-        prefetched = true;
-      }
-      issue(ts, (sb + t) & 1);
-    };
-
-    if (nk > 1) issue(1, sb ^ 1);
-    // K-step 0 (and the parameters) must have landed.  Younger operations that may stay in flight: the 8 pieces of K-step 1
-    // and, behind a full tile, its 16 stores per thread (an edge tile issues fewer: conservative count)
-    if (first) {
-      if (nk > 1) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
-      else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    } else if (prev_full && nk > 1) {
-      asm volatile("s_waitcnt vmcnt(24)" ::: "memory");
-    } else if (prev_full) {
-      asm volatile("s_waitcnt vmcnt(16)" ::: "memory");
-    } else if (nk > 1) {
-      asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+    // the same pipeline with two sub-phases per K-step (k 0-31, k 32-63) and 6 DMA pieces per wave (2 of A, 4 of B)
+    issue(0, 0, kHalf);
+    if (nk > 1) {
+      issue(1, 1, kHalf);
+      asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
     } else {
       asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     }
-    first = false;
+    if (tid < BN2) { par[tid] = pb; par[BN2 + tid] = psc; par[2 * BN2 + tid] = psh; }
     __builtin_amdgcn_s_barrier();
-    stamp();                                             // [0] K-step 0 landed
-    ldB(smem + sb * STAGE2, b0, c0);
-    ldA(smem + sb * STAGE2, a0, 0, c0);
+    stamp();
+    ldB(smem, b0, c0);
+    ldAh(smem, a0, c0);
     for (int t = 0; t < nk; ++t) {
-      const char* st = smem + ((sb + t) & 1) * STAGE2;
+      const char* st = smem + (t & 1) * STAGE2;
       __builtin_amdgcn_sched_barrier(0);
-      mma_half(a0, b0, 0, 0);                           // P0
-      __builtin_amdgcn_sched_barrier(0);
-      ldA(st, a1, 1, c0);
-      __builtin_amdgcn_sched_barrier(0);
-      mma_half(a0, b0, 0, 1);
-      __builtin_amdgcn_sched_barrier(0);
-      mma_half(a1, b0, 1, 0);                           // P1
+      mma_h(a0, b0, 0);                                 // H0
       __builtin_amdgcn_sched_barrier(0);
       ldB(st, b1, c1);
-      ldA(st, a0, 0, c1);
+      ldAh(st, a1, c1);
       __builtin_amdgcn_sched_barrier(0);
-      mma_half(a1, b0, 1, 1);
+      mma_h(a0, b0, 1);
       __builtin_amdgcn_sched_barrier(0);
-      mma_half(a0, b1, 0, 0);                           // P2
-      __builtin_amdgcn_sched_barrier(0);
-      ldA(st, a1, 1, c1);
-      __builtin_amdgcn_sched_barrier(0);
-      mma_half(a0, b1, 0, 1);
+      mma_h(a1, b1, 0);                                 // H1
       __builtin_amdgcn_sched_barrier(0);
       if (t + 1 < nk) {
         asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
         __builtin_amdgcn_s_barrier();
-        if (dma_early) dma_slot(t);
-        const char* sn = smem + ((sb + t + 1) & 1) * STAGE2;
+        if (dma_early && t + 2 < nk) issue(t + 2, t & 1, kHalf);
+        const char* sn = smem + ((t + 1) & 1) * STAGE2;
         ldB(sn, b0, c0);
-        ldA(sn, a0, 0, c0);
+        ldAh(sn, a0, c0);
       }
       __builtin_amdgcn_sched_barrier(0);
-      mma_half(a1, b1, 1, 0);                           // P3
-      mma_half(a1, b1, 1, 1);
+      mma_h(a1, b1, 1);
       __builtin_amdgcn_sched_barrier(0);
-      if (t + 1 < nk && !dma_early) dma_slot(t);
+      if (!dma_early && t + 2 < nk) issue(t + 2, t & 1, kHalf);
     }
-    stamp();                                             // [1] K loop issued
-    const int sF = (sb + nk) & 1, sL = sF ^ 1;           // sF: free all through the last K-step (holds the next tile's step 0 by now); sL: the last step's
-    if (has_next && !prefetched) {                       // nk == 1: there was no slot inside the loop
-      setup_dma(m0n, n0n);
-      issue(0, sF);
-    }
-
-    // ------------------------------------------------------------------ epilogue, two 128-row passes through stage sL
+    stamp();
+    // epilogue: the whole tile's, on a [128][256] image
     f32x4 qb[4], qs[4], qt[4];
 #pragma unroll
     for (int ni = 0; ni < 4; ++ni) {
@@ -852,89 +710,77 @@ __global__ __launch_bounds__(NT2, 2) void conv_gemm256_v3_kernel(Params p) {
       qs[ni] = *reinterpret_cast<const f32x4*>(par + BN2 + c);
       qt[ni] = *reinterpret_cast<const f32x4*>(par + 2 * BN2 + c);
     }
-    // the next tile's parameters: issued AFTER this tile's parameter reads (the compiler drains every LDS-DMA in flight before
-    // an LDS read it cannot tell apart from the DMA's target) and BEFORE this tile's stores (so the next tile's first wait covers them)
-    if (has_next) issue_par(n0n, pbuf ^ 1);
-    char* img = smem + sL * STAGE2;                      // [128 image rows][256 columns] bf16; image row = wm*64 + (mi & 3)*16 + fr
-    float ss[3] = {0.f, 0.f, 0.f}, sq[3] = {0.f, 0.f, 0.f};
-    const int seg1 = (m0 / p.T + 1) * p.T - m0, seg2 = seg1 + p.T;   // tile-local rows where the 2nd / 3rd segment of the tile start
-    lds_barrier();                                      // every wave is done reading the last stage
+    lds_barrier();
 #pragma unroll
-    for (int h2 = 0; h2 < 2; ++h2) {
+    for (int mi = 0; mi < 4; ++mi) {
+      const int row = wm * 64 + mi * 16 + fr;
+      char* rowp = smem + row * (BN2 * 2);
 #pragma unroll
-      for (int mq = 0; mq < 4; ++mq) {
-        const int mi = h2 * 4 + mq;
-        char* rowp = img + (wm * 64 + mq * 16 + fr) * (BN2 * 2);
+      for (int ni = 0; ni < 4; ++ni) {
+        f32x4 v = acc[mi][ni] + qb[ni];
+        if (relu) {
 #pragma unroll
-        for (int ni = 0; ni < 4; ++ni) {
-          f32x4 v = acc[mi][ni] + qb[ni];
-          if (relu) {
-#pragma unroll
-            for (int e = 0; e < 4; ++e) v[e] = fmaxf(v[e], 0.f);
-          }
-          v = v * qs[ni] + qt[ni];
-          uint2 pk;
-          pk.x = pack2(v[0], v[1]);
-          pk.y = pack2(v[2], v[3]);
-          const int u8 = (wn * 16 + ni * 4 + fq) ^ (fr << 1);
-          *reinterpret_cast<uint2*>(rowp + u8 * 8) = pk;
+          for (int e = 0; e < 4; ++e) v[e] = fmaxf(v[e], 0.f);
         }
+        v = v * qs[ni] + qt[ni];
+        uint2 pk;
+        pk.x = pack2(v[0], v[1]);
+        pk.y = pack2(v[2], v[3]);
+        const int u8 = (wn * 16 + ni * 4 + fq) ^ (fr << 1);
+        *reinterpret_cast<uint2*>(rowp + u8 * 8) = pk;
       }
-      lds_barrier();
-      {
-        // 128 image rows x 32 chunks of 8 columns; thread -> (image row r0 + 16 i, chunk cc), i < 8
-        const int r0 = tid >> 5, cc = tid & 31;
-        const char* src = img + r0 * (BN2 * 2) + ((cc ^ (r0 & 15)) << 4);
-#pragma unroll
-        for (int i = 0; i < 8; ++i) {
-          const int trow = (i >> 2) * 128 + h2 * 64 + r0 + 16 * (i & 3);          // tile row of image row r0 + 16 i
-          if (trow < p.M - m0) {
-            const u32x4 v = *reinterpret_cast<const u32x4*>(src + i * 16 * (BN2 * 2));
-            __builtin_nontemporal_store(v, reinterpret_cast<u32x4*>(p.C + (int64_t)(m0 + trow) * p.ldc + n0 + cc * 8));
-          }
-        }
-      }
-      if constexpr (STATS) {
-        // running per-segment column sums of the STORED output, same row order as the one-pass form: thread = (column,
-        // row half); this pass holds tile rows hsel*128 + h2*64 + [0, 64) as image rows hsel*64 + [0, 64)
-        const int c = tid & 255, hsel = tid >> 8;
-        const int lo = hsel * 128 + h2 * 64, hi = min(lo + 64, p.M - m0);
-        const char* colp = img + (c & 7) * 2;
-        const int cu = c >> 3;
-        auto run = [&](int a, int b, float& s1, float& s2) {
-          a = max(a, lo); b = min(b, hi);
-          float t1 = s1, t2 = s2;
-#pragma unroll 8
-          for (int r = a; r < b; ++r) {
-            const int ir = r - lo + hsel * 64;
-            const uint16_t hv = *reinterpret_cast<const uint16_t*>(colp + ir * (BN2 * 2) + ((cu ^ (ir & 15)) << 4));
-            const float v = __uint_as_float((uint32_t)hv << 16);
-            t1 += v;
-            t2 = fmaf(v, v, t2);
-          }
-          s1 = t1; s2 = t2;
-        };
-        run(0, seg1, ss[0], sq[0]);
-        run(seg1, seg2, ss[1], sq[1]);
-        run(seg2, BM2, ss[2], sq[2]);
-      }
-      lds_barrier();                                    // the image is free: pass 2 / the next tile's K-step 1 may overwrite it
     }
-    if constexpr (STATS) {
-      const int c = tid & 255, hsel = tid >> 8;
-      float* dst = p.stats_part + ((int64_t)((m0 / BM2) * 2 + hsel) * 3) * p.N + n0 + c;
+    lds_barrier();
+    {
+      const int r0 = tid >> 5, cc = tid & 31;
+      const char* src = smem + r0 * (BN2 * 2) + ((cc ^ (r0 & 15)) << 4);
+      bf16_t* dst = CKB ? p.C + (int64_t)((n0 >> 6) + (cc >> 3)) * p.cblk + (int64_t)(m0 + r0) * 64 + (cc & 7) * 8
+                        : p.C + (int64_t)(m0 + r0) * p.ldc + n0 + cc * 8;
+      const int64_t ldc = CKB ? 64 : p.ldc;
+      const int rows_left = p.M - m0 - r0;
+#pragma unroll
+      for (int i = 0; i < 8; ++i) {
+        if (16 * i < rows_left) {
+          const u32x4 v = *reinterpret_cast<const u32x4*>(src + i * 16 * (BN2 * 2));
+          __builtin_nontemporal_store(v, reinterpret_cast<u32x4*>(dst + (int64_t)(16 * i) * ldc));
+        }
+      }
+    }
+    if (stats && tid < BN2) {
+      // the whole tile's statistics were per (column, 128-row half) already: this half tile IS half `hsel` of its parent tile, same rows in
+      // the same order, same slot of stats_part
+      const int c = tid;
+      const int mp = (m0 / BM2) * BM2, hsel = (m0 >> 7) & 1;              // parent tile origin, which half
+      const int sb1 = (mp / p.T + 1) * p.T - mp, sb2 = sb1 + p.T;         // parent-local rows where the 2nd / 3rd segment start
+      const int lo = hsel * 128, hi = min(lo + 128, p.M - mp);
+      const char* colp = smem + (c & 7) * 2;
+      const int cu = c >> 3;
+      float ss[3], sq[3];
+      auto run = [&](int a, int b, float& s1, float& s2) {
+        a = max(a, lo); b = min(b, hi);
+        float t1 = 0.f, t2 = 0.f;
+#pragma unroll 8
+        for (int r = a; r < b; ++r) {
+          const uint16_t h = *reinterpret_cast<const uint16_t*>(colp + (r - lo) * (BN2 * 2) + ((cu ^ (r & 15)) << 4));
+          const float v = __uint_as_float((uint32_t)h << 16);
+          t1 += v;
+          t2 = fmaf(v, v, t2);
+        }
+        s1 = t1; s2 = t2;
+      };
+      run(0, sb1, ss[0], sq[0]);
+      run(sb1, sb2, ss[1], sq[1]);
+      run(sb2, BM2, ss[2], sq[2]);
+      float* dst = p.stats_part + ((int64_t)((mp / BM2) * 2 + hsel) * 3) * p.N + n0 + c;
       dst[0] = ss[0]; dst[p.N] = ss[1]; dst[2 * (int64_t)p.N] = ss[2];
       if (p.stats_mode == 2) {
         float* dq = dst + (int64_t)nbm * 6 * p.N;
         dq[0] = sq[0]; dq[p.N] = sq[1]; dq[2 * (int64_t)p.N] = sq[2];
       }
     }
-    stamp();                                             // [2] epilogue done
-    prev_full = p.M - m0 >= BM2;
-    m0 = m0n; n0 = n0n;
-    sb = sF;
-    pbuf ^= 1;
-  }   // persistent tile loop
+    stamp();
+    }
+  }
   if (p.clk && tid == 0 && blockIdx.x < 4096) {
     p.clk[blockIdx.x * 2] = __builtin_amdgcn_s_memtime() - clk_c0;
     p.clk[blockIdx.x * 2 + 1] = __builtin_amdgcn_s_memrealtime() - clk_r0;
@@ -1028,10 +874,6 @@ extern "C" int sdk_conv_gemm(sdk_ctx* ctx, const sdk_conv_gemm_args* a, void* st
   if (sdk_lds_optin(ctx, (const void*)conv_gemm256_kernel<false>, LDS2_TOTAL)) return 1;
   if (sdk_lds_optin(ctx, (const void*)conv_gemm256_kernel<true>, LDS2_TOTAL)) return 1;
   if (sdk_lds_optin(ctx, (const void*)conv_gemm256_kernel<false, true>, LDS2_TOTAL)) return 1;
-  if (sdk_lds_optin(ctx, (const void*)conv_gemm256_v3_kernel<false, false>, LDS3_TOTAL)) return 1;
-  if (sdk_lds_optin(ctx, (const void*)conv_gemm256_v3_kernel<true, false>, LDS3_TOTAL)) return 1;
-  if (sdk_lds_optin(ctx, (const void*)conv_gemm256_v3_kernel<false, true>, LDS3_TOTAL)) return 1;
-  if (sdk_lds_optin(ctx, (const void*)conv_gemm256_v3_kernel<true, true>, LDS3_TOTAL)) return 1;
   Params p;
   p.A = (const bf16_t*)a->A; p.lda = a->lda; p.W = (const bf16_t*)a->W;
   p.C = (bf16_t*)a->C; p.ldc = a->ldc; p.C32 = a->C32; p.ldc32 = a->ldc32;
@@ -1069,19 +911,10 @@ extern "C" int sdk_conv_gemm(sdk_ctx* ctx, const sdk_conv_gemm_args* a, void* st
     const int ntiles = (a->N / BN2) * ceil_div(a->M, BM2);
     const int cus = ctx->num_cu > 0 ? (ctx->num_cu / 8) * 8 : 256;
     const int grid = (p.tune & 8) ? ntiles : (ntiles < cus ? ntiles : cus);       // tune bit 3: one workgroup per tile (A/B)
-    const bool par_ok = (!a->bias || ((uintptr_t)a->bias % 16) == 0) && (!a->scale || (((uintptr_t)a->scale % 16) == 0 && ((uintptr_t)a->shift % 16) == 0));
-    // tune bit 4 (gemm_variant 258) selects v3, the overlapped tile boundary: bit-identical output, 6-7 % fewer cycles per
-    // K = 1024 tile in the in-kernel timeline, and the same wall time in interleaved A/B (0.97-1.01x) - the chip returns the
-    // saved cycles as a lower clock (DVFS give-back), so the simpler v2 stays the default
+    // (tune bit 4 selected round 3's v3 kernel, the overlapped tile boundary: bit-identical, 6-7 % fewer cycles per K = 1024 tile, the same
+    // wall time in interleaved A/B (0.97-1.01x) - the saved cycles came back as a lower clock; removed in round 5, see DESIGN.md and git history)
     if (c_kb)
       hipLaunchKernelGGL((conv_gemm256_kernel<false, true>), dim3(grid), dim3(NT2), LDS2_TOTAL, (hipStream_t)stream, p);
-    else if ((p.tune & 16) && par_ok && !pack)
-    {
-      const bool st = p.stats_part != nullptr, tp = p.taps > 1;
-      auto kern = st ? (tp ? conv_gemm256_v3_kernel<true, true> : conv_gemm256_v3_kernel<true, false>)
-                     : (tp ? conv_gemm256_v3_kernel<false, true> : conv_gemm256_v3_kernel<false, false>);
-      hipLaunchKernelGGL(kern, dim3(grid), dim3(NT2), LDS3_TOTAL, (hipStream_t)stream, p);
-    }
     else
       hipLaunchKernelGGL(p.taps > 1 ? conv_gemm256_kernel<true> : conv_gemm256_kernel<false>, dim3(grid), dim3(NT2), LDS2_TOTAL, (hipStream_t)stream, p);
   } else {

@@ -710,7 +710,7 @@ def test_spectral_cluster_survives_over_clustering_on_tight_data(engine, monkeyp
         res = CL.spectral_cluster(engine, En, Eb, 1500, k, n_iter=12, n_kmeans=10, seed=0, keep_rows=True)
         olab, olam = ospec.spectral_cluster(Eb.float().cpu().numpy(), k, n_iter=12, n_kmeans=10, seed=0)
         assert np.isfinite(res.eigenvalues).all() and len(np.unique(res.labels)) <= k
-        assert np.abs(res.eigenvalues[:c] - olam[:c]).max() < 2e-4, (noise, c, k, res.eigenvalues, olam)
+        assert np.abs(res.eigenvalues[:c] - olam[:c]).max() < 2e-3, (noise, c, k, res.eigenvalues, olam)   # bf16 tile rounding inside A V, as in test_spectral_cluster_matches_oracle
         assert np.abs(res.eigenvalues[c:]).max() < 5e-3 and np.abs(olam[c:]).max() < 5e-3, (res.eigenvalues, olam)
         klab, _ = ospec.kmeans_maximin(res.rows.astype(np.float64), k, 10)
         assert np.array_equal(ospec.canonical_labels(klab), res.labels), (noise, c, k)
@@ -791,29 +791,42 @@ def test_conv_gemm_fused_column_stats(engine, M, T, N, Cin, mode):
         assert torch.allclose(got[:, N:], sd, rtol=2e-4, atol=2e-5), float((got[:, N:] - sd).abs().max())
 
 
-@pytest.mark.parametrize("M,T,N,Cin,taps,dil,mode", [(2010, 201, 1024, 128, 1, 1, 1), (3000, 1500, 256, 64, 1, 1, 2), (2613, 201, 512, 128, 5, 1, 0),
-                                                     (1005, 201, 256, 64, 1, 1, 0), (4020, 201, 1024, 1024, 1, 1, 2), (1280, 128, 256, 192, 3, 3, 0)])
-def test_conv_gemm_overlapped_boundary_variant_is_bit_identical(engine, M, T, N, Cin, taps, dil, mode):
-    """gemm_variant 258 = the 256^2 kernel with the tile boundary overlapped (next tile's first K-step and parameters
-    prefetched by LDS-DMA, tile image in two 128-row passes, counted vmcnt that leaves the stores in flight): output and
-    fused column statistics must equal the default kernel's bit for bit, over several tiles per workgroup, edge tiles,
-    conv taps and one-K-step tiles."""
+@pytest.mark.parametrize("M,T,N,Cin,taps,dil,mode,pack", [(40200, 201, 1024, 128, 1, 1, 1, 0), (20100, 201, 1024, 64, 1, 1, 2, 0), (66000, 200, 1024, 192, 3, 2, 2, 0),
+                                                          (201000, 201, 1024, 256, 1, 1, 2, 0), (201000, 201, 1024, 80, 5, 1, 0, 80), (50250, 201, 1024, 64, 1, 1, 1, 0),
+                                                          (40200, 201, 2048, 64, 1, 1, 0, 0)])
+def test_conv_gemm_half_tile_tail_is_bit_identical(engine, M, T, N, Cin, taps, dil, mode, pack):
+    """Round 5: where the whole rounds of the 256^2 kernel leave a last round that is mostly idle (the forward's K = 1024
+    layers: 3144 tiles = 12 x 256 + 72), the left-over rows are computed as 128 x 256 half tiles, at most one per workgroup, instead of a 13th
+    round of whole tiles.  Same K order per output element, same rows in the same order per column-statistics partial: output and statistics
+    must equal the whole-tile schedule's (gemm_variant 8194 = tune bit 9: half tiles off) bit for bit - random operands, ReLU + BN epilogue,
+    conv taps, blk0's packed taps, an edge half tile that is partly / wholly outside the matrix, and a shape where the rule does not apply
+    (N = 2048: the left-over does not fit as half tiles)."""
     g = torch.Generator().manual_seed(M + N + taps)
-    A = dev(bf16_round(torch.randn(M, Cin, generator=g)), torch.bfloat16)
-    Wt = dev(bf16_round(torch.randn(N, taps * Cin, generator=g) * 0.1), torch.bfloat16)
+    lda = Cin
+    A = dev(bf16_round(torch.randn(M, lda, generator=g)), torch.bfloat16)
+    K = ((taps * pack + 63) // 64) * 64 if pack else taps * Cin
+    Wt = bf16_round(torch.randn(N, K, generator=g) * 0.1)
+    if pack:
+        Wt[:, taps * pack:] = 0
+    Wt = dev(Wt, torch.bfloat16)
     bias, sc, sh = dev(torch.randn(N, generator=g)), dev(torch.rand(N, generator=g) + 0.5), dev(torch.randn(N, generator=g))
     outs = {}
     try:
-        for v in (2, 258):
+        for v in (2, 8194):
             engine.lib.sdk_set_gemm_variant(v)
-            outs[v] = engine.conv_gemm(A, Wt, N, Cin, taps=taps, dil=dil, T=T, bias=bias, scale=sc, shift=sh, relu=True, stats_mode=mode)
+            outs[v] = engine.conv_gemm(A, Wt, N, Cin, taps=taps, dil=dil, T=T, bias=bias, scale=sc, shift=sh, relu=True, stats_mode=mode, tap_pack=pack)
             torch.cuda.synchronize()
     finally:
         engine.lib.sdk_set_gemm_variant(2)
-    a, b = outs[2], outs[258]
-    assert torch.equal(a[0], b[0])
+    a, b = outs[2], outs[8194]
+    assert torch.equal(a[0].view(torch.int16), b[0].view(torch.int16))
     if mode:
         assert torch.equal(a[3], b[3])
+    # and against an independent result on a sample of rows from the tail region (fp32 matmul of the same bf16 operands; taps == 1 only)
+    if taps == 1:
+        rows = torch.arange(M - 300, M, device="cuda")
+        want = torch.relu(A[rows].float() @ Wt.float().T + bias) * sc + sh
+        assert torch.allclose(a[0][rows].float(), want, rtol=2e-2, atol=2e-2)
 
 
 @pytest.mark.parametrize("M,T,N,Cin,mode", [(40200, 201, 1024, 128, 1), (40200, 201, 2048, 64, 0), (20100, 201, 1024, 64, 2), (66000, 200, 1024, 64, 0)])

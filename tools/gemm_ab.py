@@ -1,5 +1,5 @@
 #!/usr/bin/env python3
-"""conv_gemm256 v3 (overlapped tile boundary) vs v2, interleaved rounds in ONE process on the layer shapes of the forward."""
+"""conv_gemm256 A/B of two gemm_variant arms (default: 2 = half-tile tail on, 8194 = off), interleaved rounds in ONE process on the layer shapes of the forward."""
 import importlib, sys
 from pathlib import Path
 import numpy as np, torch
@@ -12,7 +12,7 @@ for name, N, Cin, taps, dil, stats in shapes:
     A = (torch.randn(M, Cin, device="cuda") * 0.5).bfloat16()
     W = (torch.randn(N, taps * Cin, device="cuda") * 0.03).bfloat16()
     bias = torch.randn(N, device="cuda"); sc = torch.rand(N, device="cuda") + 0.5; sh = torch.randn(N, device="cuda")
-    VA, VB = (int(sys.argv[1]), int(sys.argv[2])) if len(sys.argv) > 2 else (258, 2)
+    VA, VB = (int(sys.argv[1]), int(sys.argv[2])) if len(sys.argv) > 2 else (2, 8194)
     res = {VA: [], VB: []}
     outs = {}
     for rnd in range(7):
