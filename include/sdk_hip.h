@@ -172,6 +172,7 @@ int sdk_ingest_copy_ms(sdk_ingest* ing, int ticket, float* ms, double* bytes);
  * read by the skinny attention-hidden GEMM (A_KBLOCKED: taps == 1, lda ignored; runs on the 128^2 kernel) and by sdk_asp_fused_kblocked. */
 #define SDK_GEMM_A_KBLOCKED 4u
 #define SDK_GEMM_C_KBLOCKED 8u
+#define SDK_GEMM_F16 16u          /* A, W and the 2-byte outputs are fp16 (IEEE binary16) instead of bf16: the single-plane fp16 contract (precision 2) */
 
 /* Dilated 1-D convolution over frames as one MFMA GEMM:
  *   pre[m, n] = bias[n] + ubias[m / T, n] + sum_{j<taps} sum_{c<Cin}

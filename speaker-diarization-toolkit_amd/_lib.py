@@ -70,6 +70,7 @@ GEMM_RELU = 1
 GEMM_TANH = 2
 GEMM_A_KBLOCKED = 4      # A read / C written as [cols / 64][M][64] (include/sdk_hip.h)
 GEMM_C_KBLOCKED = 8
+GEMM_F16 = 16             # fp16 operands and outputs (single-plane fp16 contract)
 
 _vp, _i, _i64, _sz = C.c_void_p, C.c_int, C.c_int64, C.c_size_t
 

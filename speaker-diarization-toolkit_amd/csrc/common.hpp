@@ -128,6 +128,35 @@ __device__ __forceinline__ uint32_t pack2(float a, float b) {
   t[1] = (bf16_t)b;
   return __builtin_bit_cast(uint32_t, t);
 }
+// the same for a 2-byte storage type chosen at compile time: bf16 (default contract) or fp16 (the single-plane fp16 contract, round 5); fp16 values
+// are clamped to the format's finite range first (a saturated activation, never an inf that turns the next layer into NaN)
+typedef _Float16 f16x8_t __attribute__((ext_vector_type(8)));
+typedef _Float16 f16x2_t __attribute__((ext_vector_type(2)));
+template <bool F16>
+__device__ __forceinline__ uint32_t pack2t(float a, float b) {
+  if constexpr (F16) {
+    f16x2_t t;
+    t[0] = (_Float16)fminf(fmaxf(a, -65504.f), 65504.f);
+    t[1] = (_Float16)fminf(fmaxf(b, -65504.f), 65504.f);
+    return __builtin_bit_cast(uint32_t, t);
+  } else {
+    return pack2(a, b);
+  }
+}
+template <bool F16>
+__device__ __forceinline__ void unpack8t(const u32x4& v, float* f) {
+  if constexpr (F16) {
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      const f16x2_t t = __builtin_bit_cast(f16x2_t, v[i]);
+      f[2 * i] = (float)t[0];
+      f[2 * i + 1] = (float)t[1];
+    }
+  } else {
+    unpack8(v, f);
+  }
+}
+
 __device__ __forceinline__ u32x4 pack8(const float* f) {
   u32x4 v;
 #pragma unroll

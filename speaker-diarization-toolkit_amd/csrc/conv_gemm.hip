@@ -252,13 +252,17 @@ namespace {
 constexpr int BM2 = 256, BN2 = 256, NT2 = 512;
 constexpr int STAGE2 = (BM2 + BN2) * BK * 2;         // 65536
 constexpr int LDS2 = 2 * STAGE2;                     // 131072
-constexpr int LDS2_TOTAL = LDS2 + 3 * BN2 * 4;       // + the tile's bias / scale / shift columns
+constexpr int LDS2_PAR = LDS2 + 3 * BN2 * 4;         // + the tile's bias / scale / shift columns
+constexpr int LDS2_TOTAL = LDS2_PAR + 8 * 2 * BN2 * 4;   // + the per-wave partials of the fused column statistics: [8 waves][2 parts][256 columns] fp32 (147 KiB of 160)
 static_assert(BM2 * BN2 * 2 <= LDS2, "the bf16 image of a finished tile must fit in the two pipeline stages");
 
 typedef const void __attribute__((address_space(1)))* gptr_t;
 typedef void __attribute__((address_space(3)))* lptr_t;
 
-template <bool TAPS, bool CKB = false>   // CKB: the output is written K-blocked (Params::cblk) - its own instantiation, so the default kernel's code is untouched
+// CKB: the output is written K-blocked (Params::cblk) - its own instantiation, so the default kernel's code is untouched.
+// F16: operands and output are fp16 instead of bf16 (SDK_GEMM_F16: the single-plane fp16 contract) - the same kernel with mfma_f32_16x16x32_f16,
+// the output clamped to fp16's finite range and rounded to nearest even; everything else (tile order, K order, epilogue, statistics) is shared.
+template <bool TAPS, bool CKB = false, bool F16 = false>
 __global__ __launch_bounds__(NT2, 2) void conv_gemm256_kernel(Params p) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
@@ -436,6 +440,101 @@ __global__ __launch_bounds__(NT2, 2) void conv_gemm256_kernel(Params p) {
 #pragma unroll
     for (int ni = 0; ni < 4; ++ni) dst[ni] = *reinterpret_cast<const bf16x8*>(st + b_base + ni * 2048 + coff);
   };
+  // Fused per-segment column statistics of the STORED (bf16-rounded) output, from the tile's LDS image (round 5 form; round 2's read the image
+  // column by column, 128 two-byte LDS reads per thread, and cost 57 us of a 494-us K = 1024 launch - as much as a separate sweep of the output).
+  //   phase 1: thread = (16-row slab g = tid >> 5, 8-column chunk cc = tid & 31): sixteen 16-byte reads, 8 running column sums (+ 8 sums of squares).
+  //            A wave covers 32 consecutive rows and T >= 128, so at most ONE segment boundary falls inside it: rows before it go to part L, rows
+  //            from it on to part U (no boundary: everything is L).  The two slabs of a wave are added across lane ^ 32; per wave
+  //            wst[wave][L | U][256 columns].
+  //   barrier (this is also the point after which the image may be overwritten by the next tile's DMA)
+  //   phase 2: thread = (column, 128-row half): its half's four waves in order, L then U, each into the segment slot it belongs to.
+  // Fixed order throughout (reproducible); a half tile runs the same code for its 128 rows, so its partials equal the whole tile's.
+  // mp = origin of the 256-row tile the rows belong to (segment slots and stats_part rows are per such tile), lo = first image row's offset in
+  // it (0, or 128 for the lower half tile), nrows = rows in the image (256 / 128).  Every thread of the workgroup calls it (barriers inside).
+  float* wst = reinterpret_cast<float*>(smem + LDS2_PAR);
+  auto tile_stats = [&](int mp, int lo, int nrows, int n0) {
+    const int sb1 = (mp / p.T + 1) * p.T - mp, sb2 = sb1 + p.T;          // tile-local rows where the tile's 2nd / 3rd segment start
+    const int valid = min(nrows, p.M - mp - lo);                        // image rows [0, valid) are rows of the matrix
+    const bool mode2 = p.stats_mode == 2;
+    const bool active = 32 * wu < nrows;                                // (half tile: waves 0-3)
+    const int g = tid >> 5, cc = tid & 31;
+    float L[8], U[8], LQ[8], UQ[8];
+#pragma unroll
+    for (int e = 0; e < 8; ++e) { L[e] = 0.f; U[e] = 0.f; LQ[e] = 0.f; UQ[e] = 0.f; }
+    if (active) {
+      const int wlo = lo + 32 * wu;                                     // tile-local first row of this wave
+      int bnd = wlo + 32;
+      if (sb1 > wlo && sb1 < wlo + 32) bnd = sb1;
+      else if (sb2 > wlo && sb2 < wlo + 32) bnd = sb2;
+      const char* base = smem + (16 * g) * (BN2 * 2);
+      if (bnd == wlo + 32 && 32 * wu + 32 <= valid) {                   // the usual wave: one segment, all rows inside the matrix (wave-uniform)
+#pragma unroll
+        for (int i = 0; i < 16; ++i) {
+          const u32x4 v = *reinterpret_cast<const u32x4*>(base + i * (BN2 * 2) + ((cc ^ i) << 4));      // (16 g + i) & 15 == i
+          float f[8];
+          unpack8t<F16>(v, f);
+#pragma unroll
+          for (int e = 0; e < 8; ++e) {
+            L[e] += f[e];
+            if (mode2) LQ[e] = fmaf(f[e], f[e], LQ[e]);
+          }
+        }
+      } else {
+        const int ti = bnd - lo - 16 * g, ni = valid - 16 * g;          // this slab: rows i < ti are before the boundary, rows i < ni inside the matrix
+#pragma unroll
+        for (int i = 0; i < 16; ++i) {
+          const u32x4 v = *reinterpret_cast<const u32x4*>(base + i * (BN2 * 2) + ((cc ^ i) << 4));
+          float f[8];
+          unpack8t<F16>(v, f);
+          const bool keep = i < ni, inl = i < ti;
+#pragma unroll
+          for (int e = 0; e < 8; ++e) {
+            const float x = keep ? f[e] : 0.f;                          // (rows below the matrix hold whatever the padded MFMA rows produced)
+            const float xl = inl ? x : 0.f, xu = inl ? 0.f : x;
+            L[e] += xl; U[e] += xu;
+            if (mode2) { LQ[e] = fmaf(xl, xl, LQ[e]); UQ[e] = fmaf(xu, xu, UQ[e]); }
+          }
+        }
+      }
+#pragma unroll
+      for (int e = 0; e < 8; ++e) {                                     // the wave's two slabs (lanes l, l ^ 32): both lanes end up with the same totals
+        L[e] += __shfl_xor(L[e], 32, 64); U[e] += __shfl_xor(U[e], 32, 64);
+        if (mode2) { LQ[e] += __shfl_xor(LQ[e], 32, 64); UQ[e] += __shfl_xor(UQ[e], 32, 64); }
+      }
+    }
+    float* wrow = wst + (size_t)((((lo >> 5) + wu) * 2 + (lane >> 5)) * BN2) + cc * 8;       // lanes 0-31 publish L, lanes 32-63 U
+    const int c = tid & 255, hs = nrows == BM2 ? tid >> 8 : lo >> 7;
+    const bool fin = nrows == BM2 || tid < BN2;
+    auto publish = [&](const float* l, const float* u) {
+      if (active) {
+        const bool up = lane >= 32;
+        *reinterpret_cast<f32x4*>(wrow) = f32x4{up ? u[0] : l[0], up ? u[1] : l[1], up ? u[2] : l[2], up ? u[3] : l[3]};
+        *reinterpret_cast<f32x4*>(wrow + 4) = f32x4{up ? u[4] : l[4], up ? u[5] : l[5], up ? u[6] : l[6], up ? u[7] : l[7]};
+      }
+    };
+    auto combine = [&](float* dst) {
+      float s0 = 0.f, s1 = 0.f, s2 = 0.f;
+#pragma unroll
+      for (int k = 0; k < 4; ++k) {
+        const int w = 4 * hs + k, wl = 32 * w;                          // tile-local first row of wave w's 32 rows
+        const int seg = (wl >= sb1) + (wl >= sb2);
+        const float a = wst[(w * 2) * BN2 + c], b = wst[(w * 2 + 1) * BN2 + c];       // b = 0 where the wave holds no boundary
+        s0 += seg == 0 ? a : 0.f; s1 += seg == 1 ? a : 0.f; s2 += seg == 2 ? a : 0.f;
+        s1 += seg == 0 ? b : 0.f; s2 += seg == 1 ? b : 0.f;
+      }
+      dst[0] = s0; dst[p.N] = s1; dst[2 * (int64_t)p.N] = s2;
+    };
+    float* dst = p.stats_part + ((int64_t)((mp / BM2) * 2 + hs) * 3) * p.N + n0 + c;
+    publish(L, U);
+    lds_barrier();                                      // partials visible - and every read of the image is done: the next tile's DMA may overwrite it
+    if (fin) combine(dst);
+    if (mode2) {
+      lds_barrier();                                    // the partial buffer is free again
+      publish(LQ, UQ);
+      lds_barrier();
+      if (fin) combine(dst + (int64_t)nbm * 6 * p.N);
+    }
+  };
   // Persistent workgroups (one per CU; the grid is a multiple of 8 so a workgroup keeps its XCD class) walk
   // their tiles back to back.
   for (int rnd = 0; rnd < nrounds; ++rnd) {
@@ -470,7 +569,10 @@ __global__ __launch_bounds__(NT2, 2) void conv_gemm256_kernel(Params p) {
       for (int mi = 2 * part; mi < 2 * part + 2; ++mi)
 #pragma unroll
         for (int ni = 0; ni < 4; ++ni)
-          acc[mh * 4 + mi][ni] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(bf[ni], af[mi], acc[mh * 4 + mi][ni], 0, 0, 0);
+          if constexpr (F16)
+            acc[mh * 4 + mi][ni] = __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(f16x8_t, bf[ni]), __builtin_bit_cast(f16x8_t, af[mi]), acc[mh * 4 + mi][ni], 0, 0, 0);
+          else
+            acc[mh * 4 + mi][ni] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(bf[ni], af[mi], acc[mh * 4 + mi][ni], 0, 0, 0);
       __builtin_amdgcn_s_setprio(0);
     };
 
@@ -561,8 +663,8 @@ __global__ __launch_bounds__(NT2, 2) void conv_gemm256_kernel(Params p) {
         }
         v = v * qs[ni] + qt[ni];
         uint2 pk;
-        pk.x = pack2(v[0], v[1]);
-        pk.y = pack2(v[2], v[3]);
+        pk.x = pack2t<F16>(v[0], v[1]);
+        pk.y = pack2t<F16>(v[2], v[3]);
         const int u8 = (wn * 16 + ni * 4 + fq) ^ (fr << 1);            // 8-byte unit inside the 512-byte row
         *reinterpret_cast<uint2*>(rowp + u8 * 8) = pk;
       }
@@ -585,37 +687,8 @@ __global__ __launch_bounds__(NT2, 2) void conv_gemm256_kernel(Params p) {
         }
       }
     }
-    if (stats) {
-      // fused per-segment column statistics of the STORED (bf16-rounded) output: thread = (column, row half);
-      // a 256-row tile overlaps at most 3 segments (T >= 128), told apart by the tile-local row bounds
-      const int c = tid & 255, hsel = tid >> 8;
-      const int sb1 = (m0 / p.T + 1) * p.T - m0, sb2 = sb1 + p.T;
-      const int lo = hsel * 128, hi = min(lo + 128, p.M - m0);
-      const char* colp = smem + (c & 7) * 2;
-      const int cu = c >> 3;
-      float ss[3], sq[3];
-      auto run = [&](int a, int b, float& s1, float& s2) {      // branch-free body so the LDS reads pipeline
-        a = max(a, lo); b = min(b, hi);
-        float t1 = 0.f, t2 = 0.f;
-#pragma unroll 8
-        for (int r = a; r < b; ++r) {
-          const uint16_t h = *reinterpret_cast<const uint16_t*>(colp + r * (BN2 * 2) + ((cu ^ (r & 15)) << 4));
-          const float v = __uint_as_float((uint32_t)h << 16);
-          t1 += v;
-          t2 = fmaf(v, v, t2);
-        }
-        s1 = t1; s2 = t2;
-      };
-      run(0, sb1, ss[0], sq[0]);
-      run(sb1, sb2, ss[1], sq[1]);
-      run(sb2, BM2, ss[2], sq[2]);
-      float* dst = p.stats_part + ((int64_t)((m0 / BM2) * 2 + hsel) * 3) * p.N + n0 + c;
-      dst[0] = ss[0]; dst[p.N] = ss[1]; dst[2 * (int64_t)p.N] = ss[2];
-      if (p.stats_mode == 2) {
-        float* dq = dst + (int64_t)nbm * 6 * p.N;
-        dq[0] = sq[0]; dq[p.N] = sq[1]; dq[2 * (int64_t)p.N] = sq[2];
-      }
-    }
+    if (stats) tile_stats(m0, 0, BM2, n0);
+    else
     lds_barrier();                                      // the image is free: the next tile's DMA may overwrite it
     stamp();
   }   // persistent tile loop
@@ -659,7 +732,10 @@ __global__ __launch_bounds__(NT2, 2) void conv_gemm256_kernel(Params p) {
       for (int mi = 2 * part; mi < 2 * part + 2; ++mi)
 #pragma unroll
         for (int ni = 0; ni < 4; ++ni)
-          acc[mi][ni] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(bf[ni], af[mi], acc[mi][ni], 0, 0, 0);
+          if constexpr (F16)
+            acc[mi][ni] = __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(f16x8_t, bf[ni]), __builtin_bit_cast(f16x8_t, af[mi]), acc[mi][ni], 0, 0, 0);
+          else
+            acc[mi][ni] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(bf[ni], af[mi], acc[mi][ni], 0, 0, 0);
       __builtin_amdgcn_s_setprio(0);
     };
     // the same pipeline with two sub-phases per K-step (k 0-31, k 32-63) and 6 DMA pieces per wave (2 of A, 4 of B)
@@ -724,8 +800,8 @@ __global__ __launch_bounds__(NT2, 2) void conv_gemm256_kernel(Params p) {
         }
         v = v * qs[ni] + qt[ni];
         uint2 pk;
-        pk.x = pack2(v[0], v[1]);
-        pk.y = pack2(v[2], v[3]);
+        pk.x = pack2t<F16>(v[0], v[1]);
+        pk.y = pack2t<F16>(v[2], v[3]);
         const int u8 = (wn * 16 + ni * 4 + fq) ^ (fr << 1);
         *reinterpret_cast<uint2*>(rowp + u8 * 8) = pk;
       }
@@ -746,38 +822,8 @@ __global__ __launch_bounds__(NT2, 2) void conv_gemm256_kernel(Params p) {
         }
       }
     }
-    if (stats && tid < BN2) {
-      // the whole tile's statistics were per (column, 128-row half) already: this half tile IS half `hsel` of its parent tile, same rows in
-      // the same order, same slot of stats_part
-      const int c = tid;
-      const int mp = (m0 / BM2) * BM2, hsel = (m0 >> 7) & 1;              // parent tile origin, which half
-      const int sb1 = (mp / p.T + 1) * p.T - mp, sb2 = sb1 + p.T;         // parent-local rows where the 2nd / 3rd segment start
-      const int lo = hsel * 128, hi = min(lo + 128, p.M - mp);
-      const char* colp = smem + (c & 7) * 2;
-      const int cu = c >> 3;
-      float ss[3], sq[3];
-      auto run = [&](int a, int b, float& s1, float& s2) {
-        a = max(a, lo); b = min(b, hi);
-        float t1 = 0.f, t2 = 0.f;
-#pragma unroll 8
-        for (int r = a; r < b; ++r) {
-          const uint16_t h = *reinterpret_cast<const uint16_t*>(colp + (r - lo) * (BN2 * 2) + ((cu ^ (r & 15)) << 4));
-          const float v = __uint_as_float((uint32_t)h << 16);
-          t1 += v;
-          t2 = fmaf(v, v, t2);
-        }
-        s1 = t1; s2 = t2;
-      };
-      run(0, sb1, ss[0], sq[0]);
-      run(sb1, sb2, ss[1], sq[1]);
-      run(sb2, BM2, ss[2], sq[2]);
-      float* dst = p.stats_part + ((int64_t)((mp / BM2) * 2 + hsel) * 3) * p.N + n0 + c;
-      dst[0] = ss[0]; dst[p.N] = ss[1]; dst[2 * (int64_t)p.N] = ss[2];
-      if (p.stats_mode == 2) {
-        float* dq = dst + (int64_t)nbm * 6 * p.N;
-        dq[0] = sq[0]; dq[p.N] = sq[1]; dq[2 * (int64_t)p.N] = sq[2];
-      }
-    }
+    // (the whole tile's statistics are per 128-row half: this half tile IS half (m0 >> 7) & 1 of its parent tile, same rows, same order, same slot)
+    if (stats) tile_stats((m0 / BM2) * BM2, m0 & 128, 128, n0);
     stamp();
     }
   }
@@ -855,7 +901,7 @@ extern "C" int sdk_conv_gemm(sdk_ctx* ctx, const sdk_conv_gemm_args* a, void* st
   SDK_REQUIRE(a->T > 0 && a->M % a->T == 0, "sdk_conv_gemm: M=%d must be a multiple of T=%d", a->M, a->T);
   SDK_REQUIRE((int64_t)a->N * a->taps * a->Cin < (1ll << 31), "sdk_conv_gemm: weight matrix of %d x %d elements exceeds 2^31", a->N, a->taps * a->Cin);
   SDK_REQUIRE(a->taps == 1 || (a->taps / 2) * a->dil < a->T, "sdk_conv_gemm: segment of T=%d frames shorter than the conv halo %d", a->T, (a->taps / 2) * a->dil);
-  const bool a_kb = (a->flags & SDK_GEMM_A_KBLOCKED) != 0, c_kb = (a->flags & SDK_GEMM_C_KBLOCKED) != 0;
+  const bool a_kb = (a->flags & SDK_GEMM_A_KBLOCKED) != 0, c_kb = (a->flags & SDK_GEMM_C_KBLOCKED) != 0, f16 = (a->flags & SDK_GEMM_F16) != 0;
   if (a_kb) SDK_REQUIRE(a->taps == 1 && !pack && !a->A2, "sdk_conv_gemm: a K-blocked A operand needs taps == 1, no tap packing and no A2");
   else
   SDK_REQUIRE(a->lda % 8 == 0 && a->lda >= a->Cin, "sdk_conv_gemm: lda=%lld must be >= Cin and a multiple of 8", (long long)a->lda);
@@ -874,6 +920,9 @@ extern "C" int sdk_conv_gemm(sdk_ctx* ctx, const sdk_conv_gemm_args* a, void* st
   if (sdk_lds_optin(ctx, (const void*)conv_gemm256_kernel<false>, LDS2_TOTAL)) return 1;
   if (sdk_lds_optin(ctx, (const void*)conv_gemm256_kernel<true>, LDS2_TOTAL)) return 1;
   if (sdk_lds_optin(ctx, (const void*)conv_gemm256_kernel<false, true>, LDS2_TOTAL)) return 1;
+  if (sdk_lds_optin(ctx, (const void*)conv_gemm256_kernel<false, false, true>, LDS2_TOTAL)) return 1;
+  if (sdk_lds_optin(ctx, (const void*)conv_gemm256_kernel<true, false, true>, LDS2_TOTAL)) return 1;
+  if (sdk_lds_optin(ctx, (const void*)conv_gemm256_kernel<false, true, true>, LDS2_TOTAL)) return 1;
   Params p;
   p.A = (const bf16_t*)a->A; p.lda = a->lda; p.W = (const bf16_t*)a->W;
   p.C = (bf16_t*)a->C; p.ldc = a->ldc; p.C32 = a->C32; p.ldc32 = a->ldc32;
@@ -913,7 +962,12 @@ extern "C" int sdk_conv_gemm(sdk_ctx* ctx, const sdk_conv_gemm_args* a, void* st
     const int grid = (p.tune & 8) ? ntiles : (ntiles < cus ? ntiles : cus);       // tune bit 3: one workgroup per tile (A/B)
     // (tune bit 4 selected round 3's v3 kernel, the overlapped tile boundary: bit-identical, 6-7 % fewer cycles per K = 1024 tile, the same
     // wall time in interleaved A/B (0.97-1.01x) - the saved cycles came back as a lower clock; removed in round 5, see DESIGN.md and git history)
-    if (c_kb)
+    if (f16) {
+      void (*kern)(Params) = conv_gemm256_kernel<false, false, true>;
+      if (c_kb) kern = conv_gemm256_kernel<false, true, true>;
+      else if (p.taps > 1) kern = conv_gemm256_kernel<true, false, true>;
+      hipLaunchKernelGGL(kern, dim3(grid), dim3(NT2), LDS2_TOTAL, (hipStream_t)stream, p);
+    } else if (c_kb)
       hipLaunchKernelGGL((conv_gemm256_kernel<false, true>), dim3(grid), dim3(NT2), LDS2_TOTAL, (hipStream_t)stream, p);
     else
       hipLaunchKernelGGL(p.taps > 1 ? conv_gemm256_kernel<true> : conv_gemm256_kernel<false>, dim3(grid), dim3(NT2), LDS2_TOTAL, (hipStream_t)stream, p);
