@@ -408,8 +408,15 @@ def main() -> int:
     # one process per GPU.  SDK_BENCH_BACKEND=gloo rehearses the N > 1 path on a box with fewer GPUs than ranks (ranks then
     # share devices and the collectives are staged through the host): a plumbing check, never a measurement
     backend = os.environ.get("SDK_BENCH_BACKEND", "nccl")
+    ndev = torch.cuda.device_count()                   # (counting devices does not initialise the GPU)
     if backend != "nccl":
-        local = local % max(1, torch.cuda.device_count())
+        local = local % max(1, ndev)
+    elif ndev < world or local >= ndev:
+        # one rank per GPU over RCCL: say so before set_device fails with an opaque HIP error (or two ranks land on one device and RCCL hangs)
+        if rank == 0:
+            print(f"bench.py: --gpus {world} needs {world} visible GPUs for the RCCL path, this node shows {ndev} (HIP_VISIBLE_DEVICES / ROCR_VISIBLE_DEVICES?); "
+                  "to rehearse the N > 1 plumbing on fewer devices set SDK_BENCH_BACKEND=gloo (ranks share devices: not a measurement)", file=sys.stderr)
+        return 2
     torch.cuda.set_device(local)
     dist = None
     use_dist = world > 1 or ("RANK" in os.environ and "MASTER_PORT" in os.environ)   # launched by torch.distributed.run
@@ -690,6 +697,13 @@ def main() -> int:
             out["rccl_version"] = ".".join(str(x) for x in torch.cuda.nccl.version())
         except Exception:  # noqa: BLE001
             out["rccl_version"] = None
+        if use_dist:
+            # what decides the all-gather's algorithm: nothing in this tree forces one (dist.py hands the exchange to RCCL), so the line carries the
+            # settings a reader needs to tell a 7-link direct exchange (floor 0.63 ms for config #4's 96-MB shards) from a ring (4.4 ms at 153 GB/s per link)
+            out["collective_env"] = {"backend": backend, **{k: os.environ.get(k) for k in ("NCCL_ALGO", "NCCL_PROTO", "NCCL_MIN_NCHANNELS", "NCCL_MAX_NCHANNELS",
+                                                                                          "RCCL_ENABLE_INTRANET", "RCCL_MSCCL_ENABLE", "RCCL_MSCCLPP_ENABLE",
+                                                                                          "HSA_ENABLE_IPC_MODE_LEGACY", "HSA_FORCE_FINE_GRAIN_PCIE")},
+                                     "note": "unset = RCCL's own choice for the topology; compare embedding_exchange.config4_shard.ms with 0.63 ms (direct) / 4.4 ms (ring)"}
         if world == 1 and not args.no_extras:
             # sustained: >= 200 steps (~2 s) of the same step, with the in-kernel clock of the dominant kernel before and after, so a reader (and
             # the driver's utilisation sampler) can see whether the 20-step headline holds

@@ -27,8 +27,9 @@ Environment:
   SDK_PROFILE_PACK    1 (default) / 0: serve a candidate set from its packed profile matrix (embeddings/packs/, built at the first identify over
                       the set: one file mapped, no per-embedding I/O); SDK_PROFILE_PACK_MIN (16): smallest set that is packed
   SDK_PRECISION       0 (default: bf16 operands) / 1 (precise mode: fp16 hi+lo planes, within 1e-5,
-                      ~3.6x the step time).  Both modes embed into the SAME space (they differ from each other at the 4e-3 level), so
-                      model_version does not depend on it
+                      ~3.6x the step time) / 2 (one fp16 plane: the default mode's kernels with fp16 storage and operands, within ~1e-4 with the
+                      bias correction, ~1.04x the step time; ECAPA-TDNN only).  All modes embed into the SAME space (they differ from each other at
+                      the 4e-3 level), so model_version does not depend on it
 """
 from __future__ import annotations
 
@@ -141,7 +142,7 @@ class Backend(EmbeddingBackend):
         """The numerical setting embeddings are made under (stored beside every enrolled vector; identify warns when a candidate was made
         under another one): model_version names the WEIGHTS - both settings embed into the same space, ~4e-3 apart."""
         prec = int(os.environ.get("SDK_PRECISION", "0"))
-        return {"precision": prec, "bias_correction": bool(os.environ.get("SDK_BIAS_CORRECTION", "1") != "0") and prec == 0}
+        return {"precision": prec, "bias_correction": bool(os.environ.get("SDK_BIAS_CORRECTION", "1") != "0") and prec in (0, 2)}
 
     @property
     def lite(self) -> bool:
@@ -187,6 +188,8 @@ class Backend(EmbeddingBackend):
             if self.model == "xvector":
                 from .xvector import XVector
                 prec = int(os.environ.get("SDK_PRECISION", "0"))
+                if prec == 2:
+                    raise ValueError("SDK_PRECISION=2 (one fp16 plane) is built for the ECAPA-TDNN family; SDK_MODEL=xvector serves precision 0 and 1")
                 self._engine = Engine(dev)               # front end, k3, k4; its ECAPA weights are never packed (lazy)
                 if prec:
                     self._engine.set_precision(prec)

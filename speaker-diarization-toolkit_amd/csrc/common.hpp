@@ -58,12 +58,12 @@ int sdk_lds_optin(sdk_ctx* ctx, const void* func, int bytes);
 
 // pool_se.hip: sdk_asp_fused with the optional fragment-ordered copy of w2 (internal; sdk_ecapa_forward)
 int asp_fused_launch(sdk_ctx* ctx, const uint16_t* ah, int64_t ldah, const uint16_t* w2, const uint16_t* w2p, const float* b2,
-                     const uint16_t* h, int64_t ldh, int B, int T, int C, int A, float* pooled, void* stream, bool kblocked = false);
+                     const uint16_t* h, int64_t ldh, int B, int T, int C, int A, float* pooled, void* stream, bool kblocked = false, bool f16 = false);
 
 // res2net.hip: sdk_res2net_chain with the optional fragment-ordered weight copies (internal; sdk_ecapa_forward)
 int res2net_chain_launch(sdk_ctx* ctx, const uint16_t* U, int64_t ldu, uint16_t* R, int64_t ldr, const uint16_t* const* W,
                          const uint16_t* const* Wpk, const float* const* bias, const float* const* scale, const float* const* shift,
-                         int nconv, int B, int T, int dil, void* stream);
+                         int nconv, int B, int T, int dil, void* stream, bool f16 = false);
 
 struct ProfScope {   // brackets one kernel launch with two events when profiling is enabled
   sdk_ctx* c; hipStream_t s; size_t slot; bool on;
@@ -148,7 +148,8 @@ __device__ __forceinline__ void unpack8t(const u32x4& v, float* f) {
   if constexpr (F16) {
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
-      const f16x2_t t = __builtin_bit_cast(f16x2_t, v[i]);
+      const uint32_t w = v[i];                               // (a bit_cast applied to the vector ELEMENT expression reads element 0 every time)
+      const f16x2_t t = __builtin_bit_cast(f16x2_t, w);
       f[2 * i] = (float)t[0];
       f[2 * i + 1] = (float)t[1];
     }
@@ -162,6 +163,30 @@ __device__ __forceinline__ u32x4 pack8(const float* f) {
 #pragma unroll
   for (int i = 0; i < 4; ++i) v[i] = pack2(f[2 * i], f[2 * i + 1]);
   return v;
+}
+template <bool F16>
+__device__ __forceinline__ u32x4 pack8t(const float* f) {
+  u32x4 v;
+#pragma unroll
+  for (int i = 0; i < 4; ++i) v[i] = pack2t<F16>(f[2 * i], f[2 * i + 1]);
+  return v;
+}
+// one stored 2-byte element -> fp32 (the element type of the pointers stays bf16_t in every signature: 16 bits either way)
+template <bool F16>
+__device__ __forceinline__ float load1t(const bf16_t* q) {
+  if constexpr (F16) return (float)*reinterpret_cast<const _Float16*>(q);
+  else return bf16_to_f32(*q);
+}
+// the dense 16-bit MFMAs on fragments held as bf16x8 registers (bit patterns): bf16 or fp16 arithmetic, fp32 accumulate
+template <bool F16>
+__device__ __forceinline__ f32x4 mfma_16x16x32(bf16x8 a, bf16x8 b, f32x4 c) {
+  if constexpr (F16) return __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(f16x8_t, a), __builtin_bit_cast(f16x8_t, b), c, 0, 0, 0);
+  else return __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, b, c, 0, 0, 0);
+}
+template <bool F16>
+__device__ __forceinline__ f32x16 mfma_32x32x16(bf16x8 a, bf16x8 b, f32x16 c) {
+  if constexpr (F16) return __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8_t, a), __builtin_bit_cast(f16x8_t, b), c, 0, 0, 0);
+  else return __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b, c, 0, 0, 0);
 }
 
 __device__ __forceinline__ float wave_sum(float v) {

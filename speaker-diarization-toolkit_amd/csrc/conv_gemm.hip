@@ -53,6 +53,7 @@ struct Params {
   unsigned long long* stamps;          // diagnostics (256^2 kernel): [4096] wall-clock stamps of workgroup 0's phases (own buffer: "gemm_stamps"), or null
 };
 
+template <bool F16>   // F16: fp16 operands / 2-byte outputs instead of bf16 (SDK_GEMM_F16)
 __global__ __launch_bounds__(NT, 2) void conv_gemm_kernel(Params p) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   char* sA = smem;
@@ -147,11 +148,11 @@ __global__ __launch_bounds__(NT, 2) void conv_gemm_kernel(Params p) {
     for (int i = 0; i < 4; ++i) {
       if (p.A2) {                                            // Res2Net running sum formed on the way into LDS
         float fa[8], fb[8];
-        unpack8(ra[i], fa);
-        unpack8(ra2[i], fb);
+        unpack8t<F16>(ra[i], fa);
+        unpack8t<F16>(ra2[i], fb);
 #pragma unroll
         for (int e = 0; e < 8; ++e) fa[e] += fb[e];
-        ra[i] = pack8(fa);
+        ra[i] = pack8t<F16>(fa);
       }
       *reinterpret_cast<u32x4*>(sA + lds_w[i]) = ra[i];
       *reinterpret_cast<u32x4*>(sB + lds_w[i]) = rb[i];
@@ -171,7 +172,7 @@ __global__ __launch_bounds__(NT, 2) void conv_gemm_kernel(Params p) {
       for (int mi = 0; mi < 4; ++mi)
 #pragma unroll
         for (int ni = 0; ni < 4; ++ni)
-          acc[mi][ni] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[mi], bfr[ni], acc[mi][ni], 0, 0, 0);
+          acc[mi][ni] = mfma_16x16x32<F16>(af[mi], bfr[ni], acc[mi][ni]);
     }
     __syncthreads();
   }
@@ -206,7 +207,7 @@ __global__ __launch_bounds__(NT, 2) void conv_gemm_kernel(Params p) {
         v = v * cs[ni] + ct[ni];
         if (tnh) v = tanh_bf16(v);
         if (p.C32 && m < p.M) p.C32[(int64_t)m * p.ldc32 + n0 + lc] = v;
-        *reinterpret_cast<bf16_t*>(smem + row * CT_STRIDE + lc * 2) = f32_to_bf16(v);
+        *reinterpret_cast<uint16_t*>(smem + row * CT_STRIDE + lc * 2) = (uint16_t)pack2t<F16>(v, 0.f);
       }
     }
   }
@@ -223,11 +224,11 @@ __global__ __launch_bounds__(NT, 2) void conv_gemm_kernel(Params p) {
         if (p.S) {
           const u32x4 x = *reinterpret_cast<const u32x4*>(p.X2 + (int64_t)m * p.ldx2 + n0 + cc * 8);
           float fv[8], fx[8];
-          unpack8(v, fv);
-          unpack8(x, fx);
+          unpack8t<F16>(v, fv);
+          unpack8t<F16>(x, fx);
 #pragma unroll
           for (int e = 0; e < 8; ++e) fv[e] += fx[e];
-          *reinterpret_cast<u32x4*>(p.S + (int64_t)m * p.lds + n0 + cc * 8) = pack8(fv);
+          *reinterpret_cast<u32x4*>(p.S + (int64_t)m * p.lds + n0 + cc * 8) = pack8t<F16>(fv);
         }
       }
     }
@@ -972,7 +973,7 @@ extern "C" int sdk_conv_gemm(sdk_ctx* ctx, const sdk_conv_gemm_args* a, void* st
     else
       hipLaunchKernelGGL(p.taps > 1 ? conv_gemm256_kernel<true> : conv_gemm256_kernel<false>, dim3(grid), dim3(NT2), LDS2_TOTAL, (hipStream_t)stream, p);
   } else {
-    hipLaunchKernelGGL(conv_gemm_kernel, dim3((a->N / BN) * ceil_div(a->M, BM)), dim3(NT), LDS_BYTES, (hipStream_t)stream, p);
+    hipLaunchKernelGGL(f16 ? conv_gemm_kernel<true> : conv_gemm_kernel<false>, dim3((a->N / BN) * ceil_div(a->M, BM)), dim3(NT), LDS_BYTES, (hipStream_t)stream, p);
   }
   SDK_LAUNCH_CHECK();
   return 0;

@@ -221,7 +221,7 @@ __global__ __launch_bounds__(NW * 64) __attribute__((amdgpu_waves_per_eu(4, 4)))
   stamp();
 }
 
-template <bool HP>
+template <bool HP, bool F16 = false>   // HP: fp16 hi | lo planes (precision 1); F16: one fp16 plane (precision 2); neither: bf16
 __global__ __launch_bounds__(256) void fbank_norm_kernel(const float* __restrict__ L, int T, bf16_t* __restrict__ feats,
                                                         int ldf) {
   __shared__ float red[256];
@@ -258,7 +258,7 @@ __global__ __launch_bounds__(256) void fbank_norm_kernel(const float* __restrict
       f[e] = c < NMEL ? fmaxf(Ls[t * NMEL + c], flo) - mean[c] : 0.f;
     }
     if constexpr (HP) sdk_hp::store8(reinterpret_cast<uint16_t*>(out) + (int64_t)t * ldf + c8 * 8, ldf >> 1, f);   // planes: hi | lo, ldf / 2 columns each
-    else *reinterpret_cast<u32x4*>(out + (int64_t)t * ldf + c8 * 8) = pack8(f);
+    else *reinterpret_cast<u32x4*>(out + (int64_t)t * ldf + c8 * 8) = pack8t<F16>(f);
   }
 }
 
@@ -268,7 +268,7 @@ __global__ __launch_bounds__(256) void fbank_norm_kernel(const float* __restrict
 // Arithmetic (and its order per mel bin: frames g, g + 3, ... per thread, three partial sums) is the streaming form's, so the
 // features are bit-identical.
 constexpr int NORM_LDS_MAX_T = 480;                      // 480 x 80 x 4 B = 150 KiB
-template <bool HP>
+template <bool HP, bool F16 = false>   // HP: fp16 hi | lo planes (precision 1); F16: one fp16 plane (precision 2); neither: bf16
 __global__ __launch_bounds__(256) void fbank_norm_lds_kernel(const float* __restrict__ L, int T, bf16_t* __restrict__ feats,
                                                             int ldf) {
   extern __shared__ __attribute__((aligned(16))) float tile[];
@@ -319,7 +319,7 @@ __global__ __launch_bounds__(256) void fbank_norm_lds_kernel(const float* __rest
       f[e] = c < NMEL ? fmaxf(tile[t * NMEL + c], flo) - mean[c] : 0.f;
     }
     if constexpr (HP) sdk_hp::store8(reinterpret_cast<uint16_t*>(out) + (int64_t)t * ldf + c8 * 8, ldf >> 1, f);   // planes: hi | lo, ldf / 2 columns each
-    else *reinterpret_cast<u32x4*>(out + (int64_t)t * ldf + c8 * 8) = pack8(f);
+    else *reinterpret_cast<u32x4*>(out + (int64_t)t * ldf + c8 * 8) = pack8t<F16>(f);
   }
 }
 
@@ -446,12 +446,15 @@ static int fbank_launch(sdk_ctx* ctx, const int16_t* pcm, const int32_t* starts,
   }
   SDK_LAUNCH_CHECK();
   ProfScope ps2(ctx, stream, SDK_K_FBANK_NORM, 3.0 * B * T * NMEL, 4.0 * B * T * NMEL + 2.0 * B * T * ldf);
+  const bool f16 = ctx->precision == 2;                  // one fp16 plane, the default mode's [B*T, ldf] layout
+  void (*norm_lds)(const float*, int, bf16_t*, int) = hp ? fbank_norm_lds_kernel<true> : f16 ? fbank_norm_lds_kernel<false, true> : fbank_norm_lds_kernel<false>;
+  void (*norm)(const float*, int, bf16_t*, int) = hp ? fbank_norm_kernel<true> : f16 ? fbank_norm_kernel<false, true> : fbank_norm_kernel<false>;
   if (T <= NORM_LDS_MAX_T) {
     const int lds = T * NMEL * 4;
-    if (sdk_lds_optin(ctx, hp ? (const void*)fbank_norm_lds_kernel<true> : (const void*)fbank_norm_lds_kernel<false>, NORM_LDS_MAX_T * NMEL * 4)) return 1;   // (opt-in is per function: the maximum)
-    hipLaunchKernelGGL(hp ? fbank_norm_lds_kernel<true> : fbank_norm_lds_kernel<false>, dim3(B), dim3(256), lds, (hipStream_t)stream, (const float*)ws, T, (bf16_t*)feats, ldf);
+    if (sdk_lds_optin(ctx, (const void*)norm_lds, NORM_LDS_MAX_T * NMEL * 4)) return 1;   // (opt-in is per function: the maximum)
+    hipLaunchKernelGGL(norm_lds, dim3(B), dim3(256), lds, (hipStream_t)stream, (const float*)ws, T, (bf16_t*)feats, ldf);
   } else {
-    hipLaunchKernelGGL(hp ? fbank_norm_kernel<true> : fbank_norm_kernel<false>, dim3(B), dim3(256), 0, (hipStream_t)stream, (const float*)ws, T, (bf16_t*)feats, ldf);
+    hipLaunchKernelGGL(norm, dim3(B), dim3(256), 0, (hipStream_t)stream, (const float*)ws, T, (bf16_t*)feats, ldf);
   }
   SDK_LAUNCH_CHECK();
   return 0;

@@ -10,6 +10,8 @@ constexpr int NT = 256;
 
 // ------------------------------------------------------------------------------------------
 // SE: one workgroup per segment.  Thread (grp, c8) owns 8 channels and every ngrp-th frame.
+// (F16 on this and the other sweeps: the 2-byte activations are fp16 instead of bf16 - the single-plane fp16 contract; fp32 arithmetic either way)
+template <bool F16>
 __global__ __launch_bounds__(NT) void se_gate_residual_kernel(
     const bf16_t* __restrict__ z, int64_t ldz, const bf16_t* __restrict__ x, int64_t ldx,
     const float* __restrict__ w1t, const float* __restrict__ b1, const float* __restrict__ w2t,
@@ -39,14 +41,14 @@ __global__ __launch_bounds__(NT) void se_gate_residual_kernel(
 #pragma unroll
       for (int u = 0; u < 4; ++u) {
         float f[8];
-        unpack8(v[u], f);
+        unpack8t<F16>(v[u], f);
 #pragma unroll
         for (int e = 0; e < 8; ++e) s[e] += f[e];
       }
     }
     for (; t < T; t += ngrp) {
       float f[8];
-      unpack8(*reinterpret_cast<const u32x4*>(zp + (int64_t)t * ldz), f);
+      unpack8t<F16>(*reinterpret_cast<const u32x4*>(zp + (int64_t)t * ldz), f);
 #pragma unroll
       for (int e = 0; e < 8; ++e) s[e] += f[e];
     }
@@ -95,11 +97,11 @@ __global__ __launch_bounds__(NT) void se_gate_residual_kernel(
     bf16_t* op = out + base * ldo + c8 * 8;
     auto one = [&](const u32x4& zv, const u32x4& xv, int t) {
       float fz[8], fx[8];
-      unpack8(zv, fz);
-      unpack8(xv, fx);
+      unpack8t<F16>(zv, fz);
+      unpack8t<F16>(xv, fx);
 #pragma unroll
       for (int e = 0; e < 8; ++e) fz[e] = g[e] * fz[e] + fx[e];
-      *reinterpret_cast<u32x4*>(op + (int64_t)t * ldo) = pack8(fz);
+      *reinterpret_cast<u32x4*>(op + (int64_t)t * ldo) = pack8t<F16>(fz);
     };
     int t = grp;
     for (; t + 3 * ngrp < T; t += 4 * ngrp) {
@@ -119,6 +121,7 @@ __global__ __launch_bounds__(NT) void se_gate_residual_kernel(
 
 // ------------------------------------------------------------------------------------------
 // ASP global context: mean / std over frames.  grid (B, C/1024) ; 128 chunk-columns x 2 frame groups.
+template <bool F16>
 __global__ __launch_bounds__(NT) void asp_stats_kernel(const bf16_t* __restrict__ h, int64_t ldh, int T, int C,
                                                       float* __restrict__ out) {
   __shared__ float red[2][2][1024];
@@ -131,10 +134,10 @@ __global__ __launch_bounds__(NT) void asp_stats_kernel(const bf16_t* __restrict_
 #pragma unroll
   for (int e = 0; e < 8; ++e) { K[e] = 0.f; s1[e] = 0.f; s2[e] = 0.f; }
   if (live) {
-    unpack8(*reinterpret_cast<const u32x4*>(h + base * ldh + cbase), K);   // shift = frame 0
+    unpack8t<F16>(*reinterpret_cast<const u32x4*>(h + base * ldh + cbase), K);   // shift = frame 0
     for (int t = grp; t < T; t += 2) {
       float f[8];
-      unpack8(*reinterpret_cast<const u32x4*>(h + (base + t) * ldh + cbase), f);
+      unpack8t<F16>(*reinterpret_cast<const u32x4*>(h + (base + t) * ldh + cbase), f);
 #pragma unroll
       for (int e = 0; e < 8; ++e) {
         const float d = f[e] - K[e];
@@ -329,6 +332,7 @@ __global__ __launch_bounds__(KW * 64) void rows_fc_mfma_kernel(const float* __re
 }
 
 // SE building blocks used by the forward schedule: per-segment channel means, and the gate application.
+template <bool F16>
 __global__ __launch_bounds__(NT) void seg_mean_kernel(const bf16_t* __restrict__ z, int64_t ldz, int T, int C, float* __restrict__ out) {
   __shared__ float red[2][1024];
   const int tid = threadIdx.x, c8 = tid & 127, grp = tid >> 7;
@@ -347,14 +351,14 @@ __global__ __launch_bounds__(NT) void seg_mean_kernel(const bf16_t* __restrict__
 #pragma unroll
       for (int u = 0; u < 4; ++u) {
         float f[8];
-        unpack8(v[u], f);
+        unpack8t<F16>(v[u], f);
 #pragma unroll
         for (int e = 0; e < 8; ++e) s[e] += f[e];
       }
     }
     for (; t < T; t += 2) {
       float f[8];
-      unpack8(*reinterpret_cast<const u32x4*>(zp + (int64_t)t * ldz), f);
+      unpack8t<F16>(*reinterpret_cast<const u32x4*>(zp + (int64_t)t * ldz), f);
 #pragma unroll
       for (int e = 0; e < 8; ++e) s[e] += f[e];
     }
@@ -371,6 +375,7 @@ __global__ __launch_bounds__(NT) void seg_mean_kernel(const bf16_t* __restrict__
 
 // out[b,t,c] = bf16(gate[b,c] * z[b,t,c] + x[b,t,c]);  grid (B, ceil(T/TCH)), thread = 8 channels x frame stripe
 constexpr int SE_TCH = 32;
+template <bool F16>
 __global__ __launch_bounds__(NT) void se_apply_kernel(const bf16_t* __restrict__ z, int64_t ldz, const bf16_t* __restrict__ x,
                                                      int64_t ldx, const float* __restrict__ gate, bf16_t* __restrict__ out,
                                                      int64_t ldo, int T, int C) {
@@ -390,11 +395,11 @@ __global__ __launch_bounds__(NT) void se_apply_kernel(const bf16_t* __restrict__
   for (int t = t0 + grp; t < t1; t += ngrp) {
     float fz[8], fx[8];
     // z is read exactly once, here: non-temporal (5.0 -> 5.3 TB/s; nt on x and on the store as well measured no better)
-    unpack8(__builtin_nontemporal_load(reinterpret_cast<const u32x4*>(zp + (int64_t)t * ldz)), fz);
-    unpack8(*reinterpret_cast<const u32x4*>(xp + (int64_t)t * ldx), fx);
+    unpack8t<F16>(__builtin_nontemporal_load(reinterpret_cast<const u32x4*>(zp + (int64_t)t * ldz)), fz);
+    unpack8t<F16>(*reinterpret_cast<const u32x4*>(xp + (int64_t)t * ldx), fx);
 #pragma unroll
     for (int e = 0; e < 8; ++e) fz[e] = g[e] * fz[e] + fx[e];
-    *reinterpret_cast<u32x4*>(op + (int64_t)t * ldo) = pack8(fz);
+    *reinterpret_cast<u32x4*>(op + (int64_t)t * ldo) = pack8t<F16>(fz);
   }
 }
 
@@ -402,6 +407,7 @@ __global__ __launch_bounds__(NT) void se_apply_kernel(const bf16_t* __restrict__
 // ASP pooling: softmax over frames per (segment, channel), attention-weighted mean and std.
 // grid (B, C/64); thread = (channel cl = tid & 63, frame group g = tid >> 6); three sweeps
 // (max; sum-exp + weighted sum; weighted variance) - the 77-KB working set stays in L2.
+template <bool F16>
 __global__ __launch_bounds__(NT) void asp_pool_kernel(const float* __restrict__ logits, int64_t ldl,
                                                      const bf16_t* __restrict__ h, int64_t ldh, int T, int C,
                                                      float* __restrict__ pooled) {
@@ -425,7 +431,7 @@ __global__ __launch_bounds__(NT) void asp_pool_kernel(const float* __restrict__ 
   for (int t = g; t < T; t += 4) {
     const float w = __expf(lp[(int64_t)t * ldl] - mx);
     l += w;
-    s1 += w * bf16_to_f32(hp[(int64_t)t * ldh]);
+    s1 += w * load1t<F16>(hp + (int64_t)t * ldh);
   }
   red[g][cl] = l;
   red2[g][cl] = s1;
@@ -438,7 +444,7 @@ __global__ __launch_bounds__(NT) void asp_pool_kernel(const float* __restrict__ 
   float s2 = 0.f;
   for (int t = g; t < T; t += 4) {
     const float w = __expf(lp[(int64_t)t * ldl] - mx);
-    const float d = bf16_to_f32(hp[(int64_t)t * ldh]) - mu;
+    const float d = load1t<F16>(hp + (int64_t)t * ldh) - mu;
     s2 += w * d * d;
   }
   red[g][cl] = s2;
@@ -459,7 +465,7 @@ __global__ __launch_bounds__(NT) void asp_pool_kernel(const float* __restrict__ 
 //   LDS (57 KiB, one buffer used twice): the segment's attention-hidden tile, 256-B rows with the
 //   16-B chunk index XORed by (row & 15) (conflict-free ds_read_b128 A fragments), then - after the
 //   MFMA phase - the segment's [T x 128] slab of h, read back 2 bytes per lane (64 B per half-wave).
-template <int NTILES>
+template <int NTILES, bool F16>
 __global__ __launch_bounds__(NT, 2) void asp_fused_kernel(const bf16_t* __restrict__ ah, int64_t ldah,
                                                       const bf16_t* __restrict__ w2, const float* __restrict__ b2,
                                                       const bf16_t* __restrict__ h, int64_t ldh, int T, int C,
@@ -506,7 +512,7 @@ __global__ __launch_bounds__(NT, 2) void asp_fused_kernel(const bf16_t* __restri
 #pragma unroll
     for (int ks = 0; ks < 8; ++ks) {
       const bf16x8 a = *reinterpret_cast<const bf16x8*>(lds + row * 256 + (((ks * 2 + hh) ^ (row & 15)) << 4));
-      acc[rt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, bfrag[ks], acc[rt], 0, 0, 0);
+      acc[rt] = mfma_32x32x16<F16>(a, bfrag[ks], acc[rt]);
     }
   }
   __syncthreads();
@@ -529,7 +535,7 @@ __global__ __launch_bounds__(NT, 2) void asp_fused_kernel(const bf16_t* __restri
   // ---- phase C: weighted moments about K = h[t = 0] (shifted single pass, fp32).  Rows >= T hold
   // stale but finite bytes of the hidden tile and get weight 0, so every LDS read is unconditional.
   const bf16_t* hl = reinterpret_cast<const bf16_t*>(lds) + wid * 32 + col;
-  const float K = bf16_to_f32(hl[0]);
+  const float K = load1t<F16>(hl);
   float l = 0.f, s1 = 0.f, s2 = 0.f;
 #pragma unroll
   for (int rt = 0; rt < NTILES; ++rt)
@@ -537,7 +543,7 @@ __global__ __launch_bounds__(NT, 2) void asp_fused_kernel(const bf16_t* __restri
     for (int r = 0; r < 16; ++r) {
       const int t = rt * 32 + (r & 3) + 8 * (r >> 2) + 4 * hh;
       const float e = t < T ? __expf(acc[rt][r] - mx) : 0.f;
-      const float d = bf16_to_f32(hl[t * 128]) - K;
+      const float d = load1t<F16>(hl + t * 128) - K;
       l += e;
       s1 = fmaf(e, d, s1);
       s2 = fmaf(e * d, d, s2);
@@ -587,7 +593,7 @@ typedef void __attribute__((address_space(3)))* seg_lptr_t;
 
 #define SEG_WAIT_VM(n) asm volatile("s_waitcnt vmcnt(" #n ")" ::: "memory")
 
-template <bool PACKED>
+template <bool PACKED, bool F16>
 __global__ __launch_bounds__(SEG_NT, 2) void asp_seg_kernel(const bf16_t* __restrict__ ah, int64_t ldah,
                                                            const bf16_t* __restrict__ w2, const bf16_t* __restrict__ h,
                                                            int64_t ldh, int T, int C, float* __restrict__ pooled, int64_t hblk) {
@@ -666,6 +672,12 @@ __global__ __launch_bounds__(SEG_NT, 2) void asp_seg_kernel(const bf16_t* __rest
   uint32_t kv = 0u;
   int tlim = T - 4 * hh;                                       // frame (const + 4 hh) exists  <=>  const < tlim
 
+  // a slab element as read by ds_read_u16_d16_hi (value in the register's HIGH half, low half zero): bf16 - the register is the fp32 value;
+  // fp16 - one conversion
+  auto slab_f32 = [](uint32_t v) -> float {
+    if constexpr (F16) return (float)__builtin_bit_cast(_Float16, (uint16_t)(v >> 16));
+    else return __uint_as_float(v);
+  };
   auto process = [&](int blk, const bf16x8* bcur, bf16x8* bnext) {
     const int ch = blk * 32 + col;
     const bool more = blk + 8 < nblk;
@@ -677,9 +689,9 @@ __global__ __launch_bounds__(SEG_NT, 2) void asp_seg_kernel(const bf16_t* __rest
       for (int ks = 0; ks < 8; ++ks) asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(a[ks]) : "v"(aoff[ks]), "n"(rt * 32 * 256));
     };
     auto chain = [&](const bf16x8* a) {
-      f32x16 acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[0], bcur[0], zero16, 0, 0, 0);
+      f32x16 acc = mfma_32x32x16<F16>(a[0], bcur[0], zero16);
 #pragma unroll
-      for (int ks = 1; ks < 8; ++ks) acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[ks], bcur[ks], acc, 0, 0, 0);
+      for (int ks = 1; ks < 8; ++ks) acc = mfma_32x32x16<F16>(a[ks], bcur[ks], acc);
       return acc;
     };
     f32x16 cur;
@@ -723,7 +735,7 @@ __global__ __launch_bounds__(SEG_NT, 2) void asp_seg_kernel(const bf16_t* __rest
       }
       // this tile's slab rows have been read: request the same rows of the wave's next block
       if (more) fetch_piece(blk + 8, rt);
-      if (rt == 0) Kf = __uint_as_float(kv);
+      if (rt == 0) Kf = slab_f32(kv);
       f32x16 nxt = cur;
       auto step = [&](const bool masked) {
         if (rt + 1 < NTILES) nxt = chain(a);
@@ -750,7 +762,7 @@ __global__ __launch_bounds__(SEG_NT, 2) void asp_seg_kernel(const bf16_t* __rest
             e[0] = t0 < tlim ? e[0] : 0.f;
             e[1] = t0 + 1 < tlim ? e[1] : 0.f;
           }
-          f32x2 d = {__uint_as_float(hv[r]), __uint_as_float(hv[r + 1])};
+          f32x2 d = {slab_f32(hv[r]), slab_f32(hv[r + 1])};
           d = d - K2;
           const f32x2 ed = e * d;
           l2 += e;
@@ -830,6 +842,7 @@ extern "C" int sdk_se_gate_residual(sdk_ctx* ctx, const uint16_t* z, int64_t ldz
   SDK_REQUIRE(C % 8 == 0 && C / 8 <= NT && NT % (C / 8) == 0, "sdk_se_gate_residual: C=%d unsupported (need C/8 | 256)", C);
   SDK_REQUIRE(Cse > 0 && Cse <= NT && NT % Cse == 0 && Cse <= C, "sdk_se_gate_residual: Cse=%d unsupported (need Cse | 256)", Cse);
   SDK_REQUIRE(ldz % 8 == 0 && ldx % 8 == 0 && ldo % 8 == 0, "sdk_se_gate_residual: row strides must be multiples of 8");
+  const bool f16 = ctx->precision == 2;                     // the context's storage format (sdk_set_option "precision" 2: fp16 activations)
   if (ws && ws_bytes >= sdk_se_workspace_bytes(B, C, Cse)) {
     // split schedule: channel means (one sweep of z) -> the two gate FCs batched over all segments on the
     // matrix pipe (weights read once per 32 segments instead of once per segment) -> gate*z + x sweep
@@ -840,14 +853,14 @@ extern "C" int sdk_se_gate_residual(sdk_ctx* ctx, const uint16_t* z, int64_t ldz
       mean = const_cast<float*>(mean_in);                   // squeeze already produced by the GEMM epilogue
     } else {
       ProfScope ps(ctx, stream, SDK_K_SE_GATE, 1.0 * B * T * C, 2.0 * B * T * C);
-      hipLaunchKernelGGL(seg_mean_kernel, dim3(B, ceil_div(C, 1024)), dim3(NT), 0, (hipStream_t)stream, (const bf16_t*)z, ldz, T, C, mean);
+      hipLaunchKernelGGL(f16 ? seg_mean_kernel<true> : seg_mean_kernel<false>, dim3(B, ceil_div(C, 1024)), dim3(NT), 0, (hipStream_t)stream, (const bf16_t*)z, ldz, T, C, mean);
     }
     SDK_LAUNCH_CHECK();
     if (int rc = sdk_rows_fc(ctx, mean, C, nullptr, nullptr, w1t, b1, hid, Cse, B, C, Cse, 1, stream)) return rc;
     if (int rc = sdk_rows_fc(ctx, hid, Cse, nullptr, nullptr, w2t, b2, gate, C, B, Cse, C, 2, stream)) return rc;
     {
       ProfScope ps(ctx, stream, SDK_K_SE_GATE, 2.0 * B * T * C, 6.0 * B * T * C);
-      hipLaunchKernelGGL(se_apply_kernel, dim3(B, ceil_div(T, SE_TCH)), dim3(NT), 0, (hipStream_t)stream, (const bf16_t*)z, ldz,
+      hipLaunchKernelGGL(f16 ? se_apply_kernel<true> : se_apply_kernel<false>, dim3(B, ceil_div(T, SE_TCH)), dim3(NT), 0, (hipStream_t)stream, (const bf16_t*)z, ldz,
                          (const bf16_t*)x, ldx, gate, (bf16_t*)out, ldo, T, C);
     }
     SDK_LAUNCH_CHECK();
@@ -858,7 +871,7 @@ extern "C" int sdk_se_gate_residual(sdk_ctx* ctx, const uint16_t* z, int64_t ldz
   const size_t lds = (size_t)(ngrp * C + C + Cse) * sizeof(float);
   SDK_REQUIRE((size_t)(NT / Cse) * Cse <= (size_t)ngrp * C, "sdk_se_gate_residual: scratch too small");
   ProfScope ps(ctx, stream, SDK_K_SE_GATE, 3.0 * B * T * C, 6.0 * B * T * C);   // z, x read + out written (z re-read from L2)
-  hipLaunchKernelGGL(se_gate_residual_kernel, dim3(B), dim3(NT), lds, (hipStream_t)stream, (const bf16_t*)z, ldz,
+  hipLaunchKernelGGL(f16 ? se_gate_residual_kernel<true> : se_gate_residual_kernel<false>, dim3(B), dim3(NT), lds, (hipStream_t)stream, (const bf16_t*)z, ldz,
                      (const bf16_t*)x, ldx, w1t, b1, w2t, b2, (bf16_t*)out, ldo, T, C, Cse);
   SDK_LAUNCH_CHECK();
   return 0;
@@ -869,7 +882,7 @@ extern "C" int sdk_asp_stats(sdk_ctx* ctx, const uint16_t* h, int64_t ldh, int B
   SDK_REQUIRE(ctx && h && out_ctx, "sdk_asp_stats: null argument");
   SDK_REQUIRE(B > 0 && T > 0 && C % 8 == 0 && ldh % 8 == 0, "sdk_asp_stats: bad shape (C=%d ldh=%lld)", C, (long long)ldh);
   ProfScope ps(ctx, stream, SDK_K_ASP_STATS, 3.0 * B * T * C, 2.0 * B * T * C);
-  hipLaunchKernelGGL(asp_stats_kernel, dim3(B, ceil_div(C, 1024)), dim3(NT), 0, (hipStream_t)stream, (const bf16_t*)h,
+  hipLaunchKernelGGL(ctx->precision == 2 ? asp_stats_kernel<true> : asp_stats_kernel<false>, dim3(B, ceil_div(C, 1024)), dim3(NT), 0, (hipStream_t)stream, (const bf16_t*)h,
                      ldh, T, C, out_ctx);
   SDK_LAUNCH_CHECK();
   return 0;
@@ -913,7 +926,7 @@ extern "C" int sdk_asp_pool(sdk_ctx* ctx, const float* logits, int64_t ldl, cons
   SDK_REQUIRE(ctx && logits && h && pooled, "sdk_asp_pool: null argument");
   SDK_REQUIRE(B > 0 && T > 0 && C % 64 == 0, "sdk_asp_pool: C=%d must be a multiple of 64", C);
   ProfScope ps(ctx, stream, SDK_K_ASP_POOL, 8.0 * B * T * C, 6.0 * B * T * C);
-  hipLaunchKernelGGL(asp_pool_kernel, dim3(B, C / 64), dim3(NT), 0, (hipStream_t)stream, logits, ldl,
+  hipLaunchKernelGGL(ctx->precision == 2 ? asp_pool_kernel<true> : asp_pool_kernel<false>, dim3(B, C / 64), dim3(NT), 0, (hipStream_t)stream, logits, ldl,
                      (const bf16_t*)h, ldh, T, C, pooled);
   SDK_LAUNCH_CHECK();
   return 0;
@@ -925,7 +938,7 @@ extern "C" int sdk_asp_fused_max_frames(void) { return 224; }
 static bool asp_seg_ok(const sdk_ctx* ctx, int T, int C) { return T > 96 && T <= SEG_ROWS && C % 256 == 0 && !ctx->no_asp_seg; }
 
 int asp_fused_launch(sdk_ctx* ctx, const uint16_t* ah, int64_t ldah, const uint16_t* w2, const uint16_t* w2p, const float* b2,
-                     const uint16_t* h, int64_t ldh, int B, int T, int C, int A, float* pooled, void* stream, bool kblocked) {
+                     const uint16_t* h, int64_t ldh, int B, int T, int C, int A, float* pooled, void* stream, bool kblocked, bool f16) {
   SDK_REQUIRE(ctx && ah && w2 && b2 && h && pooled, "sdk_asp_fused: null argument");
   const int64_t hblk = kblocked ? (int64_t)B * T * 64 : 0;
   if (kblocked) {
@@ -938,34 +951,33 @@ int asp_fused_launch(sdk_ctx* ctx, const uint16_t* ah, int64_t ldah, const uint1
   SDK_REQUIRE(C % 128 == 0 && ldah % 8 == 0 && ldh % 8 == 0, "sdk_asp_fused: C=%d must be a multiple of 128", C);
   ProfScope ps(ctx, stream, SDK_K_ASP_FUSED, 2.0 * B * T * (double)A * C, 2.0 * B * T * ((double)C + A) + 8.0 * B * C);
   if (asp_seg_ok(ctx, T, C)) {     // one workgroup per segment (hidden tile read once)
-    if (sdk_lds_optin(ctx, (const void*)asp_seg_kernel<false>, SEG_LDS)) return 1;
-    if (sdk_lds_optin(ctx, (const void*)asp_seg_kernel<true>, SEG_LDS)) return 1;
-    if (w2p && !ctx->no_asp_packed)
-      hipLaunchKernelGGL(asp_seg_kernel<true>, dim3(B), dim3(SEG_NT), SEG_LDS, (hipStream_t)stream, (const bf16_t*)ah, ldah, (const bf16_t*)w2p,
-                         (const bf16_t*)h, ldh, T, C, pooled, hblk);
-    else
-      hipLaunchKernelGGL(asp_seg_kernel<false>, dim3(B), dim3(SEG_NT), SEG_LDS, (hipStream_t)stream, (const bf16_t*)ah, ldah, (const bf16_t*)w2,
-                         (const bf16_t*)h, ldh, T, C, pooled, hblk);
+    const bool pk = w2p && !ctx->no_asp_packed;
+    void (*kern)(const bf16_t*, int64_t, const bf16_t*, const bf16_t*, int64_t, int, int, float*, int64_t) =
+        f16 ? (pk ? asp_seg_kernel<true, true> : asp_seg_kernel<false, true>) : (pk ? asp_seg_kernel<true, false> : asp_seg_kernel<false, false>);
+    if (sdk_lds_optin(ctx, (const void*)kern, SEG_LDS)) return 1;
+    hipLaunchKernelGGL(kern, dim3(B), dim3(SEG_NT), SEG_LDS, (hipStream_t)stream, (const bf16_t*)ah, ldah, (const bf16_t*)(pk ? w2p : w2),
+                       (const bf16_t*)h, ldh, T, C, pooled, hblk);
     SDK_LAUNCH_CHECK();
     return 0;
   }
   const dim3 grid(C / 128, B);
-  if (T <= 96) hipLaunchKernelGGL(asp_fused_kernel<3>, grid, dim3(NT), 0, (hipStream_t)stream, (const bf16_t*)ah, ldah, (const bf16_t*)w2, b2, (const bf16_t*)h, ldh, T, C, pooled);
-  else hipLaunchKernelGGL(asp_fused_kernel<7>, grid, dim3(NT), 0, (hipStream_t)stream, (const bf16_t*)ah, ldah, (const bf16_t*)w2, b2, (const bf16_t*)h, ldh, T, C, pooled);
+  void (*kf)(const bf16_t*, int64_t, const bf16_t*, const float*, const bf16_t*, int64_t, int, int, float*) =
+      T <= 96 ? (f16 ? asp_fused_kernel<3, true> : asp_fused_kernel<3, false>) : (f16 ? asp_fused_kernel<7, true> : asp_fused_kernel<7, false>);
+  hipLaunchKernelGGL(kf, grid, dim3(NT), 0, (hipStream_t)stream, (const bf16_t*)ah, ldah, (const bf16_t*)w2, b2, (const bf16_t*)h, ldh, T, C, pooled);
   SDK_LAUNCH_CHECK();
   return 0;
 }
 
 extern "C" int sdk_asp_fused(sdk_ctx* ctx, const uint16_t* ah, int64_t ldah, const uint16_t* w2, const float* b2,
                              const uint16_t* h, int64_t ldh, int B, int T, int C, int A, float* pooled, void* stream) {
-  return asp_fused_launch(ctx, ah, ldah, w2, nullptr, b2, h, ldh, B, T, C, A, pooled, stream, false);
+  return asp_fused_launch(ctx, ah, ldah, w2, nullptr, b2, h, ldh, B, T, C, A, pooled, stream, false, ctx && ctx->precision == 2);
 }
 
 extern "C" int sdk_asp_kblocked_ok(sdk_ctx* ctx, int T, int C) { return ctx && asp_seg_ok(ctx, T, C) ? 1 : 0; }
 
 extern "C" int sdk_asp_fused_kblocked(sdk_ctx* ctx, const uint16_t* ah, int64_t ldah, const uint16_t* w2, const float* b2, const uint16_t* h,
                                       int B, int T, int C, int A, float* pooled, void* stream) {
-  return asp_fused_launch(ctx, ah, ldah, w2, nullptr, b2, h, 64, B, T, C, A, pooled, stream, true);
+  return asp_fused_launch(ctx, ah, ldah, w2, nullptr, b2, h, 64, B, T, C, A, pooled, stream, true, ctx && ctx->precision == 2);
 }
 
 extern "C" int sdk_l2norm(sdk_ctx* ctx, const float* X, int N, int d, float* E, uint16_t* Eb, float* resid,

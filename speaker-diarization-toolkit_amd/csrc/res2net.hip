@@ -17,6 +17,8 @@
 //   u and y move through buffer instructions (uniform resource + one 32-bit lane offset + scalar pass offset).
 //   Arithmetic order is identical to seven conv_gemm launches (tap-major, 32-wide k-steps, fp32 epilogue,
 //   bf16 rounding points), so results are bit-identical to the unfused schedule.
+#include <type_traits>
+
 #include "common.hpp"
 
 namespace {
@@ -35,7 +37,7 @@ struct ChainParams {
   unsigned long long* dbg;               // diagnostics only: [workgroup][64] 100 MHz time stamps of wave 0 (tools/res2net_timeline.py), or null
 };
 
-template <int MT, bool PACKED>
+template <int MT, bool PACKED, bool F16 = false>   // F16: fp16 storage and operands (the single-plane fp16 contract) instead of bf16
 __global__ __launch_bounds__(RNT, 2) void res2net_chain_kernel(ChainParams p) {
   constexpr int TP = MT * 16;
   extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -176,8 +178,8 @@ __global__ __launch_bounds__(RNT, 2) void res2net_chain_kernel(ChainParams p) {
         __builtin_amdgcn_sched_barrier(0);
         if (s + RING - 1 < NSTEP) rd(s + RING - 1);
         const int ks = s / MH, mi = s % MH;
-        acc[mi][0] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(bcur[0][ks], af[s % RING], acc[mi][0], 0, 0, 0);
-        acc[mi][1] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(bcur[1][ks], af[s % RING], acc[mi][1], 0, 0, 0);
+        acc[mi][0] = mfma_16x16x32<F16>(bcur[0][ks], af[s % RING], acc[mi][0]);
+        acc[mi][1] = mfma_16x16x32<F16>(bcur[1][ks], af[s % RING], acc[mi][1]);
       }
       __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
@@ -214,8 +216,8 @@ __global__ __launch_bounds__(RNT, 2) void res2net_chain_kernel(ChainParams p) {
           for (int e = 0; e < 4; ++e) v[e] = fmaxf(v[e], 0.f);
           v = v * cs[h] + ct[h];
           uint2 pk;
-          pk.x = pack2(v[0], v[1]);
-          pk.y = pack2(v[2], v[3]);
+          pk.x = pack2t<F16>(v[0], v[1]);
+          pk.y = pack2t<F16>(v[2], v[3]);
           *reinterpret_cast<uint2*>(nxt + ebase[h] + mi * (16 * 256)) = pk;    // row & 15 == fr for every mi: one offset per h
         }
       }
@@ -238,11 +240,11 @@ __global__ __launch_bounds__(RNT, 2) void res2net_chain_kernel(ChainParams p) {
         __builtin_amdgcn_raw_buffer_store_b128(y, yrs, yoff, (uint32_t)i * ystride + (uint32_t)(c * RS * 2), 0);
         if (c < p.nconv) {
           float fy[8], fu[8];
-          unpack8(y, fy);
-          unpack8(upre[i], fu);
+          unpack8t<F16>(y, fy);
+          unpack8t<F16>(upre[i], fu);
 #pragma unroll
           for (int e = 0; e < 8; ++e) fy[e] += fu[e];
-          *reinterpret_cast<u32x4*>(q) = pack8(fy);
+          *reinterpret_cast<u32x4*>(q) = pack8t<F16>(fy);
         }
       }
     }
@@ -262,7 +264,7 @@ __global__ __launch_bounds__(RNT, 2) void res2net_chain_kernel(ChainParams p) {
 //   u_{c+1} is requested at the top of the epilogue (behind the next conv's tap-0 weights, which are pinned first).
 // Same arithmetic order: bit-identical to the 8-wave kernel and to seven conv_gemm launches.
 constexpr int RNT4 = 256;
-template <int MT, bool PACKED>
+template <int MT, bool PACKED, bool F16 = false>
 __global__ __launch_bounds__(RNT4, 2) void res2net_chain4_kernel(ChainParams p) {
   constexpr int TP = MT * 16;
   extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -371,8 +373,8 @@ __global__ __launch_bounds__(RNT4, 2) void res2net_chain4_kernel(ChainParams p) 
         __builtin_amdgcn_sched_barrier(0);
         if (s + RING - 1 < NSTEP) rd(s + RING - 1);
         const int ks = s / MT, mi = s % MT;
-        acc[mi][0] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(bcur[0][ks], af[s % RING], acc[mi][0], 0, 0, 0);
-        acc[mi][1] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(bcur[1][ks], af[s % RING], acc[mi][1], 0, 0, 0);
+        acc[mi][0] = mfma_16x16x32<F16>(bcur[0][ks], af[s % RING], acc[mi][0]);
+        acc[mi][1] = mfma_16x16x32<F16>(bcur[1][ks], af[s % RING], acc[mi][1]);
       }
       __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
@@ -404,8 +406,8 @@ __global__ __launch_bounds__(RNT4, 2) void res2net_chain4_kernel(ChainParams p) 
           for (int e = 0; e < 4; ++e) v[e] = fmaxf(v[e], 0.f);
           v = v * cs[h] + ct[h];
           uint2 pk;
-          pk.x = pack2(v[0], v[1]);
-          pk.y = pack2(v[2], v[3]);
+          pk.x = pack2t<F16>(v[0], v[1]);
+          pk.y = pack2t<F16>(v[2], v[3]);
           *reinterpret_cast<uint2*>(img + ebase[h] + mi * (16 * 256)) = pk;
         }
       }
@@ -430,11 +432,11 @@ __global__ __launch_bounds__(RNT4, 2) void res2net_chain4_kernel(ChainParams p) 
         __builtin_amdgcn_raw_buffer_store_b128(y, yrs, yoff, (uint32_t)i * ystride + (uint32_t)(c * RS * 2), 0);
         if (c < p.nconv) {
           float fy[8], fu[8];
-          unpack8(y, fy);
-          unpack8(upre[i], fu);
+          unpack8t<F16>(y, fy);
+          unpack8t<F16>(upre[i], fu);
 #pragma unroll
           for (int e = 0; e < 8; ++e) fy[e] += fu[e];
-          *reinterpret_cast<u32x4*>(q) = pack8(fy);
+          *reinterpret_cast<u32x4*>(q) = pack8t<F16>(fy);
         }
       }
     }
@@ -450,7 +452,7 @@ extern "C" int sdk_res2net_chain_max_frames(void) { return 208; }
 // Internal entry (sdk_ecapa_forward): Wpk may be null, or hold the fragment-ordered copies of W (ecapa_layout.h EL_CHAINPACK).
 int res2net_chain_launch(sdk_ctx* ctx, const uint16_t* U, int64_t ldu, uint16_t* R, int64_t ldr, const uint16_t* const* W,
                          const uint16_t* const* Wpk, const float* const* bias, const float* const* scale, const float* const* shift,
-                         int nconv, int B, int T, int dil, void* stream) {
+                         int nconv, int B, int T, int dil, void* stream, bool f16) {
   SDK_REQUIRE(ctx && U && R && W && bias && scale && shift, "sdk_res2net_chain: null argument");
   SDK_REQUIRE(nconv >= 1 && nconv <= 7, "sdk_res2net_chain: nconv=%d must be in [1, 7]", nconv);
   SDK_REQUIRE(B > 0 && T > dil && T <= 208 && dil >= 1, "sdk_res2net_chain: T=%d frames (dilation %d) unsupported (dil < T <= 208)", T, dil);
@@ -469,21 +471,23 @@ int res2net_chain_launch(sdk_ctx* ctx, const uint16_t* U, int64_t ldu, uint16_t*
     p.Wpk[i] = packed ? (const bf16_t*)Wpk[k] : nullptr;
   }
   ProfScope ps(ctx, stream, SDK_K_RES2NET, 2.0 * B * T * (double)RS * 3 * RS * nconv, 2.0 * 2.0 * B * T * RS * nconv);
-  auto launch = [&](auto kern, int lds) -> int {
+  auto launch = [&](auto kern, int lds, int nt) -> int {
     if (sdk_lds_optin(ctx, (const void*)kern, lds)) return 1;
-    hipLaunchKernelGGL(kern, dim3(B), dim3(RNT), lds, (hipStream_t)stream, p);
+    hipLaunchKernelGGL(kern, dim3(B), dim3(nt), lds, (hipStream_t)stream, p);
     return 0;
   };
-  int rc;
-  if (T > 112 && !ctx->no_chain_two_per_cu) {             // two segments per CU (4-wave workgroups, one image in place)
-    const int lds4 = 208 * 256 + PAR_BYTES;
-    rc = packed ? [&] { if (sdk_lds_optin(ctx, (const void*)res2net_chain4_kernel<13, true>, lds4)) return 1;
-                        hipLaunchKernelGGL((res2net_chain4_kernel<13, true>), dim3(B), dim3(RNT4), lds4, (hipStream_t)stream, p); return 0; }()
-                : [&] { if (sdk_lds_optin(ctx, (const void*)res2net_chain4_kernel<13, false>, lds4)) return 1;
-                        hipLaunchKernelGGL((res2net_chain4_kernel<13, false>), dim3(B), dim3(RNT4), lds4, (hipStream_t)stream, p); return 0; }();
-  } else
-  if (T <= 112) rc = packed ? launch(res2net_chain_kernel<7, true>, 2 * 112 * 256 + PAR_BYTES) : launch(res2net_chain_kernel<7, false>, 2 * 112 * 256 + PAR_BYTES);
-  else rc = packed ? launch(res2net_chain_kernel<13, true>, 2 * 208 * 256 + PAR_BYTES) : launch(res2net_chain_kernel<13, false>, 2 * 208 * 256 + PAR_BYTES);
+  // kernel choice: two segments per CU (4-wave workgroups, one image in place) for T > 112, else the 8-wave form; the weights' fragment-ordered
+  // copy when present; fp16 or bf16 arithmetic
+  auto pick = [&](auto f16c) -> int {
+    constexpr bool F = decltype(f16c)::value;
+    if (T > 112 && !ctx->no_chain_two_per_cu) {
+      const int lds4 = 208 * 256 + PAR_BYTES;
+      return packed ? launch(res2net_chain4_kernel<13, true, F>, lds4, RNT4) : launch(res2net_chain4_kernel<13, false, F>, lds4, RNT4);
+    }
+    if (T <= 112) return packed ? launch(res2net_chain_kernel<7, true, F>, 2 * 112 * 256 + PAR_BYTES, RNT) : launch(res2net_chain_kernel<7, false, F>, 2 * 112 * 256 + PAR_BYTES, RNT);
+    return packed ? launch(res2net_chain_kernel<13, true, F>, 2 * 208 * 256 + PAR_BYTES, RNT) : launch(res2net_chain_kernel<13, false, F>, 2 * 208 * 256 + PAR_BYTES, RNT);
+  };
+  const int rc = f16 ? pick(std::true_type{}) : pick(std::false_type{});
   if (rc) return rc;
   SDK_LAUNCH_CHECK();
   return 0;
@@ -492,5 +496,5 @@ int res2net_chain_launch(sdk_ctx* ctx, const uint16_t* U, int64_t ldu, uint16_t*
 extern "C" int sdk_res2net_chain(sdk_ctx* ctx, const uint16_t* U, int64_t ldu, uint16_t* R, int64_t ldr, const uint16_t* const* W,
                                  const float* const* bias, const float* const* scale, const float* const* shift, int nconv,
                                  int B, int T, int dil, void* stream) {
-  return res2net_chain_launch(ctx, U, ldu, R, ldr, W, nullptr, bias, scale, shift, nconv, B, T, dil, stream);
+  return res2net_chain_launch(ctx, U, ldu, R, ldr, W, nullptr, bias, scale, shift, nconv, B, T, dil, stream, ctx && ctx->precision == 2);
 }

@@ -115,7 +115,7 @@ extern "C" int sdk_set_option(sdk_ctx* ctx, const char* name, int value) {
   if (strcmp(name, "asp_per_segment") == 0) { ctx->no_asp_seg = value == 0; return 0; }
   if (strcmp(name, "h_kblocked") == 0) { ctx->no_h_kblocked = value == 0; return 0; }
   if (strcmp(name, "precision") == 0) {
-    SDK_REQUIRE(value == 0 || value == 1, "sdk_set_option: precision must be 0 (bf16 operands) or 1 (fp16 hi+lo planes), got %d", value);
+    SDK_REQUIRE(value >= 0 && value <= 2, "sdk_set_option: precision must be 0 (bf16 operands), 1 (fp16 hi+lo planes) or 2 (one fp16 plane), got %d", value);
     ctx->precision = value;
     return 0;
   }
@@ -252,7 +252,7 @@ int check_desc(const sdk_ecapa_desc* d) {
   SDK_REQUIRE(d->scale >= 2 && d->sub_channels * d->scale == d->channels && d->sub_channels % 128 == 0, "ecapa desc: res2net scale=%d sub=%d", d->scale, d->sub_channels);
   SDK_REQUIRE(d->attn_channels % 128 == 0 && d->n_mels_padded % (d->precision == 1 ? 32 : 64) == 0, "ecapa desc: attn=%d mels=%d", d->attn_channels, d->n_mels_padded);
   SDK_REQUIRE((d->kernel0 & 1) == 1, "ecapa desc: kernel0=%d must be odd", d->kernel0);
-  SDK_REQUIRE(d->precision == 0 || d->precision == 1, "ecapa desc: precision=%d", d->precision);
+  SDK_REQUIRE(d->precision >= 0 && d->precision <= 2, "ecapa desc: precision=%d", d->precision);
   return 0;
 }
 
@@ -372,7 +372,7 @@ extern "C" int sdk_ecapa_forward(sdk_ctx* ctx, const void* wblob, const sdk_ecap
 
 extern "C" int sdk_ecapa_forward_calib(sdk_ctx* ctx, const void* wblob, const sdk_ecapa_desc* d, const uint16_t* feats, int ldf,
                                        int B, int T, void* ws, size_t ws_bytes, float* emb, float* calib, void* stream) {
-  SDK_REQUIRE(calib && d && d->precision == 0, "sdk_ecapa_forward_calib: calib is null or the blob is not a default-mode blob");
+  SDK_REQUIRE(calib && d && d->precision != 1, "sdk_ecapa_forward_calib: calib is null or the blob is a precise-mode blob (calibration serves the single-plane modes 0 and 2)");
   return ecapa_forward_impl(ctx, wblob, d, feats, ldf, B, T, ws, ws_bytes, emb, calib, stream);
 }
 
@@ -407,6 +407,11 @@ static int ecapa_forward_impl(sdk_ctx* ctx, const void* wblob, const sdk_ecapa_d
   auto P32 = [&](int slot) -> const float* { return d->off[slot] < 0 ? nullptr : (const float*)(wb + d->off[slot]); };
   const int M = B * T, C = d->channels, Cm = d->mfa_channels, S = d->sub_channels, A = d->attn_channels;
   hipStream_t st = (hipStream_t)stream;
+  // precision 2 (round 5): the same schedule with every 2-byte tensor - features, weights, activations - in fp16 instead of bf16 (11 significand
+  // bits: 7 x closer to the fp32 model at one MFMA per product, profiles/r05_fp16_decision.txt); the sweeps take the format from the context
+  // (checked equal to the descriptor's above), the GEMMs from their flag, the two internal launches from their argument
+  const bool f16 = d->precision == 2;
+  const uint32_t fmt = f16 ? SDK_GEMM_F16 : 0u;
 
   auto tdnn = [&](const uint16_t* Ain, int64_t lda, int Cin, int taps, int dil, int slot, int N, uint16_t* Cout, int64_t ldc,
                   const uint16_t* X2, int64_t ldx2, uint16_t* Sout, int64_t lds, int stats_mode = 0, uint32_t layout = 0) -> int {
@@ -415,7 +420,7 @@ static int ecapa_forward_impl(sdk_ctx* ctx, const void* wblob, const sdk_ecapa_d
     g.A = Ain; g.lda = lda; g.W = P16(slot + EL_W); g.C = Cout; g.ldc = ldc;
     g.bias = P32(slot + EL_B); g.scale = P32(slot + EL_SCALE); g.shift = P32(slot + EL_SHIFT);
     g.X2 = X2; g.ldx2 = ldx2; g.S = Sout; g.lds = lds;
-    g.M = M; g.N = N; g.Cin = Cin; g.taps = taps; g.dil = dil; g.T = T; g.flags = SDK_GEMM_RELU | layout;
+    g.M = M; g.N = N; g.Cin = Cin; g.taps = taps; g.dil = dil; g.T = T; g.flags = SDK_GEMM_RELU | layout | fmt;
     g.stats_mode = stats_mode; g.stats_part = stats_mode ? w.stats : nullptr;
     SDK_REQUIRE(g.W && g.bias && g.scale && g.shift, "sdk_ecapa_forward: weight slot %d missing", slot);
     return sdk_conv_gemm(ctx, &g, stream);
@@ -427,7 +432,7 @@ static int ecapa_forward_impl(sdk_ctx* ctx, const void* wblob, const sdk_ecapa_d
     memset(&g, 0, sizeof(g));
     g.A = feats; g.lda = ldf; g.W = P16(EL_BLK0 + EL_W); g.C = w.X0; g.ldc = C;
     g.bias = P32(EL_BLK0 + EL_B); g.scale = P32(EL_BLK0 + EL_SCALE); g.shift = P32(EL_BLK0 + EL_SHIFT);
-    g.M = M; g.N = C; g.Cin = d->blk0_tap_pack; g.taps = d->kernel0; g.dil = 1; g.T = T; g.flags = SDK_GEMM_RELU; g.tap_pack = d->blk0_tap_pack;
+    g.M = M; g.N = C; g.Cin = d->blk0_tap_pack; g.taps = d->kernel0; g.dil = 1; g.T = T; g.flags = SDK_GEMM_RELU | fmt; g.tap_pack = d->blk0_tap_pack;
     SDK_REQUIRE(g.W && g.bias && g.scale && g.shift && d->blk0_tap_pack <= ldf, "sdk_ecapa_forward: blk0 weight slots missing or tap_pack > ldf");
     if (int rc = sdk_conv_gemm(ctx, &g, stream)) return rc;
   } else if (int rc = tdnn(feats, ldf, d->n_mels_padded, d->kernel0, 1, EL_BLK0, C, w.X0, C, nullptr, 0, nullptr, 0)) return rc;
@@ -451,7 +456,7 @@ static int ecapa_forward_impl(sdk_ctx* ctx, const void* wblob, const sdk_ecapa_d
         Wp[j] = P16(slot + EL_W); bp[j] = P32(slot + EL_B); sp[j] = P32(slot + EL_SCALE); tp[j] = P32(slot + EL_SHIFT);
         Wk[j] = (i <= 4 && d->off[EL_CHAINPACK(i, j)] >= 0) ? P16(EL_CHAINPACK(i, j)) : nullptr;   // optional fragment-ordered copy
       }
-      if (int rc = res2net_chain_launch(ctx, w.U, C, w.U, C, Wp, Wk, bp, sp, tp, d->scale - 1, B, T, dil, stream)) return rc;
+      if (int rc = res2net_chain_launch(ctx, w.U, C, w.U, C, Wp, Wk, bp, sp, tp, d->scale - 1, B, T, dil, stream, f16)) return rc;
       r2out = w.U;
     } else {
       // separate launches: the running sum is produced by the previous conv's epilogue (S output), ping-ponging
@@ -509,15 +514,15 @@ static int ecapa_forward_impl(sdk_ctx* ctx, const void* wblob, const sdk_ecapa_d
     memset(&g, 0, sizeof(g));
     g.A = w.H; g.lda = Cm; g.W = P16(tb + EL_ASP_WH); g.C = w.AH; g.ldc = A;
     g.ubias = w.ubias; g.ldub = A; g.scale = P32(tb + EL_ASP_SCALE); g.shift = P32(tb + EL_ASP_SHIFT);
-    g.M = M; g.N = A; g.Cin = Cm; g.taps = 1; g.dil = 1; g.T = T; g.flags = SDK_GEMM_RELU | SDK_GEMM_TANH | (h_kb ? SDK_GEMM_A_KBLOCKED : 0);
+    g.M = M; g.N = A; g.Cin = Cm; g.taps = 1; g.dil = 1; g.T = T; g.flags = SDK_GEMM_RELU | SDK_GEMM_TANH | (h_kb ? SDK_GEMM_A_KBLOCKED : 0) | fmt;
     if (int rc = sdk_conv_gemm(ctx, &g, stream)) return rc;
     if (A == 128 && T <= sdk_asp_fused_max_frames()) {
       // logits GEMM + softmax pooling fused: no [M, Cm] fp32 logits round trip through HBM
-      if (int rc = asp_fused_launch(ctx, w.AH, A, P16(tb + EL_ASP_W2), P16(tb + EL_ASP_W2PACK), P32(tb + EL_ASP_B2), w.H, Cm, B, T, Cm, A, w.pooled, stream, h_kb)) return rc;
+      if (int rc = asp_fused_launch(ctx, w.AH, A, P16(tb + EL_ASP_W2), P16(tb + EL_ASP_W2PACK), P32(tb + EL_ASP_B2), w.H, Cm, B, T, Cm, A, w.pooled, stream, h_kb, f16)) return rc;
     } else {
       memset(&g, 0, sizeof(g));
       g.A = w.AH; g.lda = A; g.W = P16(tb + EL_ASP_W2); g.C32 = w.logits; g.ldc32 = Cm; g.bias = P32(tb + EL_ASP_B2);
-      g.M = M; g.N = Cm; g.Cin = A; g.taps = 1; g.dil = 1; g.T = T; g.flags = 0;
+      g.M = M; g.N = Cm; g.Cin = A; g.taps = 1; g.dil = 1; g.T = T; g.flags = fmt;
       if (int rc = sdk_conv_gemm(ctx, &g, stream)) return rc;
       if (int rc = sdk_asp_pool(ctx, w.logits, Cm, w.H, Cm, B, T, Cm, w.pooled, stream)) return rc;
     }

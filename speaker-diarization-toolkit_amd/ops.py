@@ -64,7 +64,8 @@ class Engine:
         self.cache_hit = False
         import os
         self.bias_correction = (os.environ.get("SDK_BIAS_CORRECTION", "1") != "0") if bias_correction is None else bool(bias_correction)
-        self._bias_host: Dict[str, np.ndarray] = {}        # layer name -> corrected bias (default mode), for effective_weights()
+        self._bias_host: Dict[str, np.ndarray] = {}        # layer name -> corrected bias of the CURRENT single-plane mode, for effective_weights()
+        self._bias_by_precision: Dict[int, Dict[str, np.ndarray]] = {}
         self._seed = seed
         self._wblob = None
         self._desc = None
@@ -100,9 +101,9 @@ class Engine:
             self._cache_key = None                      # explicit weights: their identity is unknown to the cache
         if self.precision not in self._packed:
             from . import weights_cache
-            correct = self.bias_correction and self.precision == 0
+            correct = self.bias_correction and self.precision in (0, 2)
             from .weights_pack import calibration_tag
-            ckey = ("0c" + calibration_tag()) if correct else self.precision            # a bias-corrected blob is its own cache entry (per calibration recording)
+            ckey = (f"{self.precision}c" + calibration_tag()) if correct else self.precision   # a bias-corrected blob is its own cache entry (per calibration recording)
             hit = weights_cache.load_blob(self._cache_key, ckey) if self._cache_key else None
             need_store = False
             if hit is not None:
@@ -143,7 +144,7 @@ class Engine:
         """One calibration forward with the plain blob (already uploaded), corrected biases computed on the host from the measured channel means of
         every GEMM layer's input, written into the device blob and into `blob` (returned, for the cache)."""
         from .weights_pack import bias_corrections, bias_slot, calib_layout
-        wdev, d = self._packed[0]
+        wdev, d = self._packed[self.precision]
         pcm = torch.from_numpy(self.calibration_pcm()).to(self.device)
         B, S = pcm.shape
         T = num_frames(S)
@@ -163,7 +164,7 @@ class Engine:
         layout, per_seg = calib_layout(self.cfg)
         assert per_seg * B == nfl, (per_seg, B, nfl)
         means = {name: cal[off * B:(off + 2 * ch) * B].reshape(B, 2 * ch)[:, :ch].mean(axis=0) for name, ch, off in layout}
-        self._bias_host = bias_corrections(self._weights_host, means, self.cfg)
+        self._bias_by_precision[self.precision] = self._bias_host = bias_corrections(self._weights_host, means, self.cfg, precision=self.precision)
         for name, bias in self._bias_host.items():
             o = fields["off"][bias_slot(name, self.cfg)]
             raw = np.ascontiguousarray(bias, dtype=np.float32).view(np.uint8)
@@ -178,7 +179,8 @@ class Engine:
         if self._weights_host is None:
             self._weights_host = self._weights_fn() if self._weights_fn else synthetic_weights(self._seed, self.cfg)
         w = dict(self._weights_host)
-        if self.bias_correction and self.precision == 0:
+        if self.bias_correction and self.precision in (0, 2):
+            self._bias_host = self._bias_by_precision.setdefault(self.precision, {})
             if not self._bias_host:                   # cache hit: read the corrected biases back from the device blob
                 from .weights_pack import bias_slot, calib_layout
                 for name, ch, _ in calib_layout(self.cfg)[0]:
@@ -193,9 +195,12 @@ class Engine:
         """0 (default): bf16 GEMM operands, bf16 layer-boundary storage - PCM -> cosine score within ~4e-3 of the fp32 model.
         1: the precise mode (csrc/hp.hip): fp16 hi+lo planes and three MFMAs per product everywhere, within 1e-5 (north_star's
         tolerance), ~3x the GEMM time.  Selects the fbank output format and the weight blob together; embeddings of the two modes
-        are comparable with each other at the 4e-3 level only."""
-        if precision not in (0, 1):
-            raise SdkError(f"precision must be 0 or 1, got {precision}")
+        are comparable with each other at the 4e-3 level only.
+        2 (round 5): one fp16 plane - the default mode's kernels and schedule with fp16 instead of bf16 storage and MFMA operands (11
+        significand bits instead of 8): PCM -> score within ~1e-4 of the fp32 model with the bias correction, at the default mode's MFMA
+        count (the chip holds a ~5 % lower clock on fp16 products: profiles/r05_gemm_f16_probe.txt)."""
+        if precision not in (0, 1, 2):
+            raise SdkError(f"precision must be 0, 1 or 2, got {precision}")
         self.set_option("precision", precision)
         self.precision = precision
         self._wblob = self._desc = None
@@ -263,7 +268,7 @@ class Engine:
         T = num_frames(S)
         if ldf is None:
             ldf = 2 * N_MELS_PADDED_HP if self.precision == 1 else N_MELS_PADDED
-        feats = torch.empty((B * T, ldf), dtype=torch.float16 if self.precision == 1 else torch.bfloat16, device=self.device)
+        feats = torch.empty((B * T, ldf), dtype=torch.bfloat16 if self.precision == 0 else torch.float16, device=self.device)
         wsb = self.lib.sdk_fbank_workspace_bytes(B, S)
         ws = self._scratch_bytes("fbank", wsb)
         check(self.lib.sdk_fbank(self.ctx, pcm.data_ptr(), B, S, self.fbank_tables().data_ptr(), feats.data_ptr(), ldf,
@@ -277,7 +282,7 @@ class Engine:
         T = num_frames(S)
         if ldf is None:
             ldf = 2 * N_MELS_PADDED_HP if self.precision == 1 else N_MELS_PADDED
-        feats = torch.empty((B * T, ldf), dtype=torch.float16 if self.precision == 1 else torch.bfloat16, device=self.device)
+        feats = torch.empty((B * T, ldf), dtype=torch.bfloat16 if self.precision == 0 else torch.float16, device=self.device)
         ws = self._scratch_bytes("fbank", self.lib.sdk_fbank_workspace_bytes(B, S))
         check(self.lib.sdk_fbank_windows(self.ctx, samples_ptr, n_samples, starts_ptr, B, S, self.fbank_tables().data_ptr(), feats.data_ptr(), ldf,
                                          ws.data_ptr(), ws.numel(), _stream()), "sdk_fbank_windows")
@@ -339,7 +344,7 @@ class Engine:
     # ------------------------------------------------------------------ k2
     def ecapa_forward(self, feats: torch.Tensor, B: int, T: int) -> torch.Tensor:
         """feats [B*T, ldf] bf16 (precise mode: fp16 planes) -> raw embeddings [B, 192] fp32."""
-        _need(feats, torch.float16 if self.precision == 1 else torch.bfloat16, "feats")
+        _need(feats, torch.bfloat16 if self.precision == 0 else torch.float16, "feats")
         self._sync_precision()
         if feats.shape[0] != B * T or feats.stride(1) != 1:
             raise SdkError(f"feats must be [B*T={B * T}, ldf] row-major, got {tuple(feats.shape)}")

@@ -71,6 +71,22 @@ def bf16_bits_to_f32(b: np.ndarray) -> np.ndarray:
     return (np.ascontiguousarray(b, dtype=np.uint16).astype(np.uint32) << 16).view(np.float32)
 
 
+def f32_to_f16_bits(x: np.ndarray) -> np.ndarray:
+    """fp32 -> IEEE binary16 bit pattern, round-to-nearest-even, saturated at the format's finite range (precision 2's storage)."""
+    return np.clip(np.ascontiguousarray(x, dtype=np.float32), -65504.0, 65504.0).astype(np.float16).view(np.uint16)
+
+
+def to_bits16(x: np.ndarray, precision: int) -> np.ndarray:
+    """the 2-byte GEMM operand format of a single-plane contract: bf16 (precision 0) or fp16 (precision 2)"""
+    return f32_to_f16_bits(x) if precision == 2 else f32_to_bf16_bits(x)
+
+
+def round16(x: np.ndarray, precision: int) -> np.ndarray:
+    """x rounded to that format, as fp32 values"""
+    x = np.ascontiguousarray(x, dtype=np.float32)
+    return f32_to_f16_bits(x).view(np.float16).astype(np.float32) if precision == 2 else bf16_bits_to_f32(f32_to_bf16_bits(x))
+
+
 def asp_w2_fragment_order(w2: np.ndarray) -> np.ndarray:
     """[Cm, 128] bf16 bits -> [Cm/32][ks 8][lane 64][8] (csrc/ecapa_layout.h EL_ASP_W2PACK): lane l of a 32x32x16 fragment holds
     W2[32 blk + (l & 31)][16 ks + 8 (l >> 5) + 0..7]."""
@@ -86,13 +102,13 @@ def asp_w2_fragment_order(w2: np.ndarray) -> np.ndarray:
     return out
 
 
-def conv_weight_kmajor(w: np.ndarray, cin_pad: int | None = None) -> np.ndarray:
-    """[C_out, C_in, k] -> bf16 bits [C_out, k * C_in_pad] (tap-major, zero-padded channels)."""
+def conv_weight_kmajor(w: np.ndarray, cin_pad: int | None = None, precision: int = 0) -> np.ndarray:
+    """[C_out, C_in, k] -> bf16 (precision 2: fp16) bits [C_out, k * C_in_pad] (tap-major, zero-padded channels)."""
     co, ci, k = w.shape
     cp = cin_pad or ci
     out = np.zeros((co, k, cp), dtype=np.float32)
     out[:, :, :ci] = np.transpose(w, (0, 2, 1))
-    return f32_to_bf16_bits(out.reshape(co, k * cp))
+    return to_bits16(out.reshape(co, k * cp), precision)
 
 
 N_MELS_PADDED_HP = 96          # precise mode: the mel channels padded to the next multiple of its 32-wide K-step
@@ -138,9 +154,10 @@ def pack_weights(weights: Dict[str, np.ndarray], cfg: EcapaConfig = DEFAULT_CONF
     """Return (blob: np.uint8 [bytes], desc_fields: dict) - host side only, no device access.
     precision 0: bf16 GEMM operands (default mode).  precision 1 (precise mode, csrc/hp.hip): every GEMM weight slot holds fp16
     hi+lo planes behind a scale header (hp_weight_planes), the mel channels are padded to 96, no fragment-ordered copies;
-    everything fp32 is identical in both blobs."""
+    everything fp32 is identical in both blobs.  precision 2 (one fp16 plane, round 5): the default mode's blob layout - packed blk0 taps,
+    fragment-ordered copies - with every 2-byte weight in fp16 instead of bf16."""
     check_weights(weights, cfg)
-    assert precision in (0, 1)
+    assert precision in (0, 1, 2)
     hp = precision == 1
     mel_pad = N_MELS_PADDED_HP if hp else N_MELS_PADDED
     chunks: List[Tuple[int, np.ndarray]] = []
@@ -158,7 +175,7 @@ def pack_weights(weights: Dict[str, np.ndarray], cfg: EcapaConfig = DEFAULT_CONF
 
     def gemm_w(w3: np.ndarray, cin_pad=None) -> np.ndarray:
         """[C_out, C_in, k] conv weight -> the slot content of the blob's precision"""
-        return hp_weight_planes(conv_weight_kmajor_f32(w3, cin_pad)) if hp else conv_weight_kmajor(w3, cin_pad)
+        return hp_weight_planes(conv_weight_kmajor_f32(w3, cin_pad)) if hp else conv_weight_kmajor(w3, cin_pad, precision)
 
     def tdnn(slot: int, name: str, cin_pad=None):
         put(slot + EL_W, gemm_w(weights[f"{name}.conv.w"], cin_pad))
@@ -173,7 +190,7 @@ def pack_weights(weights: Dict[str, np.ndarray], cfg: EcapaConfig = DEFAULT_CONF
         # default mode: the first layer's taps packed along K - [C][round_up(kernel0 * n_mels, 64)] (5 x 80 = 400 -> 448: 7 K-steps of 64
         # where the per-tap padding 80 -> 128 took 10); the activations stay [M, 128] with zero columns 80.., read 80 wide per tap
         blk0_pack = cfg.n_mels
-        wk = conv_weight_kmajor(weights["blk0.conv.w"])                       # [C, kernel0 * n_mels] bf16 bits
+        wk = conv_weight_kmajor(weights["blk0.conv.w"], None, precision)      # [C, kernel0 * n_mels] bf16 / fp16 bits
         kp = (wk.shape[1] + 63) // 64 * 64
         wp = np.zeros((wk.shape[0], kp), dtype=np.uint16)
         wp[:, :wk.shape[1]] = wk
@@ -190,7 +207,7 @@ def pack_weights(weights: Dict[str, np.ndarray], cfg: EcapaConfig = DEFAULT_CONF
         for j in range(cfg.res2net_scale - 1):
             tdnn(b + res2net_slot(j), f"blk{i}.res2net.{j}")
             if cfg.sub_channels == 128 and i <= 4 and j < 7 and not hp:
-                put(chainpack_slot(i, j), chain_fragment_order(conv_weight_kmajor(weights[f"blk{i}.res2net.{j}.conv.w"])))
+                put(chainpack_slot(i, j), chain_fragment_order(conv_weight_kmajor(weights[f"blk{i}.res2net.{j}.conv.w"], None, precision)))
         tdnn(b + EL_TDNN2, f"blk{i}.tdnn2")
         put(b + EL_SE_W1T, weights[f"blk{i}.se.conv1.w"][:, :, 0].T.astype(np.float32))
         put(b + EL_SE_B1, weights[f"blk{i}.se.conv1.b"])
@@ -200,15 +217,15 @@ def pack_weights(weights: Dict[str, np.ndarray], cfg: EcapaConfig = DEFAULT_CONF
     tdnn(t + EL_MFA, "mfa")
     m = cfg.mfa_channels
     wt = weights["asp.tdnn.conv.w"][:, :, 0]
-    put(t + EL_ASP_WH, hp_weight_planes(wt[:, :m]) if hp else f32_to_bf16_bits(wt[:, :m]))
+    put(t + EL_ASP_WH, hp_weight_planes(wt[:, :m]) if hp else to_bits16(wt[:, :m], precision))
     put(t + EL_ASP_WMS_T, wt[:, m:].T.astype(np.float32))
     put(t + EL_ASP_B, weights["asp.tdnn.conv.b"])
     s, sh = bn_affine(weights, "asp.tdnn.bn")
     put(t + EL_ASP_SCALE, s)
     put(t + EL_ASP_SHIFT, sh)
-    put(t + EL_ASP_W2, hp_weight_planes(weights["asp.conv.w"][:, :, 0]) if hp else f32_to_bf16_bits(weights["asp.conv.w"][:, :, 0]))
+    put(t + EL_ASP_W2, hp_weight_planes(weights["asp.conv.w"][:, :, 0]) if hp else to_bits16(weights["asp.conv.w"][:, :, 0], precision))
     if cfg.attn_channels == 128 and m % 32 == 0 and not hp:
-        put(t + EL_ASP_W2PACK, asp_w2_fragment_order(f32_to_bf16_bits(weights["asp.conv.w"][:, :, 0])))
+        put(t + EL_ASP_W2PACK, asp_w2_fragment_order(to_bits16(weights["asp.conv.w"][:, :, 0], precision)))
     put(t + EL_ASP_B2, weights["asp.conv.b"])
     s, sh = bn_affine(weights, "asp_bn")
     put(t + EL_ASPBN_SCALE, s)
@@ -245,14 +262,15 @@ def calib_layout(cfg: EcapaConfig = DEFAULT_CONFIG):
     return out, off
 
 
-def bias_corrections(weights: Dict[str, np.ndarray], means: Dict[str, np.ndarray], cfg: EcapaConfig = DEFAULT_CONFIG) -> Dict[str, np.ndarray]:
-    """layer name -> corrected fp32 bias  b + (W - bf16(W)) . mu  (float64 inside; every tap of a k3 conv sees the same channel means)."""
+def bias_corrections(weights: Dict[str, np.ndarray], means: Dict[str, np.ndarray], cfg: EcapaConfig = DEFAULT_CONFIG, precision: int = 0) -> Dict[str, np.ndarray]:
+    """layer name -> corrected fp32 bias  b + (W - round16(W)) . mu  (float64 inside; every tap of a k3 conv sees the same channel means);
+    round16 = the blob's 2-byte weight format: bf16 (precision 0) or fp16 (precision 2)."""
     out = {}
     for name, mu in means.items():
         w = weights[f"{name}.conv.w"].astype(np.float64)                     # [C_out, C_in(, k)]
         if name == "asp.tdnn":
             w = w[:, :cfg.mfa_channels]                                       # the per-frame part of the attention hidden layer (the context part is fp32)
-        dw = w - bf16_bits_to_f32(f32_to_bf16_bits(w.astype(np.float32))).astype(np.float64)
+        dw = w - round16(w.astype(np.float32), precision).astype(np.float64)
         corr = np.tensordot(dw.sum(axis=2) if dw.ndim == 3 else dw, np.asarray(mu, np.float64)[:dw.shape[1]], axes=([1], [0]))
         out[name] = (weights[f"{name}.conv.b"].astype(np.float64) + corr).astype(np.float32)
     return out

@@ -166,3 +166,22 @@ def test_bench_gpus_n_spawns_its_own_ranks_before_any_gpu_call(monkeypatch):
     monkeypatch.setenv("WORLD_SIZE", "2")
     seen.clear()
     assert bench.main() == 2 and not seen
+
+
+def test_bench_rccl_path_refuses_more_ranks_than_devices(monkeypatch, capsys):
+    """`--gpus N` with fewer than N visible devices must end in a readable message before set_device (here: 0 devices,
+    world 2, the rank environment of torch.distributed.run), not in a HIP error or an RCCL hang; the gloo rehearsal path is not refused."""
+    import sys as _sys
+    import torch
+    _sys.path.insert(0, str(ROOT))
+    import bench
+    for k, v in (("WORLD_SIZE", "2"), ("RANK", "0"), ("LOCAL_RANK", "0"), ("MASTER_ADDR", "127.0.0.1"), ("MASTER_PORT", "29999")):
+        monkeypatch.setenv(k, v)
+    monkeypatch.delenv("SDK_BENCH_BACKEND", raising=False)
+    monkeypatch.setattr(_sys, "argv", ["bench.py", "--gpus", "2"])
+    monkeypatch.setattr(torch.cuda, "device_count", lambda: 1)
+    called = []
+    monkeypatch.setattr(torch.cuda, "set_device", lambda d: called.append(d))
+    assert bench.main() == 2 and not called
+    err = capsys.readouterr().err
+    assert "needs 2 visible GPUs" in err and "shows 1" in err and "SDK_BENCH_BACKEND=gloo" in err
