@@ -475,6 +475,8 @@ __global__ __launch_bounds__(WAVES * 64, 2) void aff_rowcol_kernel(const bf16_t*
 struct BlockPlan {
   int q, G, nst, parts, items;      // main blocks per workgroup, workgroups, stages per sweep, parts per leftover block, leftover items
   int prio;
+  int main_parts;                   // records a WHOLE sweep writes (round 5): 1 = one record at the end; 2 / 3 = the row / column maxima are flushed and
+                                    // reset at the stage boundaries p nst / main_parts, so the certificate is that of sweeps a half / a third as long
 };
 
 // the blocks of wave `wid` of workgroup `g` (host and device share this; tests/test_cabi_cpu.py replays it through sdk_affinity_block_plan_wave)
@@ -560,10 +562,19 @@ __global__ __launch_bounds__(WAVES * 64, 2) void aff_rowcol_blocks_kernel(const 
 #pragma unroll
     for (int q = 0; q < 4; ++q) tl[sb][q] = EMPTY;
   }
+  // A block whose whole sweep this wave makes alone (every main block; a leftover block when parts == 1) writes pl.main_parts records: a whole sweep's
+  // fourth-largest row maximum is that of 32 tiles at config #3 - a weaker certificate than the range plan's parts of ~12 tiles (201 instead of
+  // 88 rows to rescan, round 4) - so the lists are flushed and reset at the stage boundaries p nst / main_parts
+  const int mp = pl.main_parts < 1 ? 1 : (pl.main_parts > MAXP ? MAXP : pl.main_parts);
+  const bool whole1 = has1 && cnt1 == 1;
   if (lane == 0) {
-    part_base[blk0 * MAXP] = 0;
-    part_cnt[blk0] = 1;
-    if (has1) {
+    for (int pp = 0; pp < mp; ++pp) {
+      part_base[blk0 * MAXP + pp] = (pp * nst / mp) * TPS;
+      if (whole1) part_base[blk1 * MAXP + pp] = (pp * nst / mp) * TPS;
+    }
+    part_cnt[blk0] = mp;
+    if (whole1) part_cnt[blk1] = mp;
+    else if (has1) {
       part_base[blk1 * MAXP + slot1] = e0 * TPS;
       part_cnt[blk1] = cnt1;                                       // (every part of a leftover block writes the same count)
     }
@@ -592,8 +603,35 @@ __global__ __launch_bounds__(WAVES * 64, 2) void aff_rowcol_blocks_kernel(const 
         if (tile * PT + (r & 3) + 8 * (r >> 2) + 4 * h >= P) acc[r] = MASKED;
     }
   };
+  // one record: the sorted top-4 row maxima (tile tags relative to the part) + the top-4 of the 16 column maxima; then the lists start afresh
+  auto flush = [&](int sb, int slot) {
+    float cl[4] = {EMPTY, EMPTY, EMPTY, EMPTY};
+#pragma unroll
+    for (int r = 0; r < 16; ++r) insert_sorted<4>(__uint_as_float((__float_as_uint(C[sb][r]) & ~CMASK) | (uint32_t)r), cl);
+    const int seg = (sb == 0 ? blk0 : blk1) * 32 + col;
+    if (seg < N) {
+      float* dst = stats + (((int64_t)seg * MAXP + slot) * 2 + h) * 8;
+      f32x4 tv, cv;
+#pragma unroll
+      for (int q = 0; q < 4; ++q) { tv[q] = tl[sb][q]; cv[q] = cl[q]; }
+      *reinterpret_cast<f32x4*>(dst) = tv;
+      *reinterpret_cast<f32x4*>(dst + 4) = cv;
+    }
+#pragma unroll
+    for (int r = 0; r < 16; ++r) C[sb][r] = EMPTY;
+#pragma unroll
+    for (int q = 0; q < 4; ++q) tl[sb][q] = EMPTY;
+  };
+  int pcur = 0, tbase = 0, next_b = mp > 1 ? nst / mp : nst;        // current part of the whole sweeps, its first tile, the stage where the next one starts
   stamp();
   for (int s = 0; s < nst; ++s) {
+    if (s == next_b) {                                             // (uniform over the workgroup)
+      flush(0, pcur);
+      if (whole1) flush(1, pcur);
+      ++pcur;
+      tbase = s * TPS;
+      next_b = (pcur + 1) * nst / mp;
+    }
     const int after = nst - 1 - s < AHEAD - 1 ? nst - 1 - s : AHEAD - 1;
     if (after >= 2) {
       if constexpr (DPW == 3) asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
@@ -625,37 +663,23 @@ __global__ __launch_bounds__(WAVES * 64, 2) void aff_rowcol_blocks_kernel(const 
       if (has_t1) TileStep<0, 1, true, 0>::run(sqa, bfrag, acc, ring);
       else TileStep<0, 1, false, 0>::run(sqa, bfrag, acc, ring);
     }
+    const int tb1 = whole1 ? tbase : e0 * TPS;                      // tag base of slot 1: its part's first tile
     mask1(t0, acc[0]);
-    reduce1(acc[0], 0, t0);
-    if (two) { mask1(t0, acc[1]); reduce1(acc[1], 1, t0 - e0 * TPS); }
+    reduce1(acc[0], 0, t0 - tbase);
+    if (two) { mask1(t0, acc[1]); reduce1(acc[1], 1, t0 - tb1); }
     if (has_t1) {
 #pragma unroll
       for (int r = 0; r < 16; ++r) { acc[0][r] = 0.f; acc[1][r] = 0.f; }
       if (two) TileStep<1, 2, false, 0>::run(sqa, bfrag, acc, ring);
       else TileStep<1, 1, false, 0>::run(sqa, bfrag, acc, ring);
       mask1(t1, acc[0]);
-      reduce1(acc[0], 0, t1);
-      if (two) { mask1(t1, acc[1]); reduce1(acc[1], 1, t1 - e0 * TPS); }
+      reduce1(acc[0], 0, t1 - tbase);
+      if (two) { mask1(t1, acc[1]); reduce1(acc[1], 1, t1 - tb1); }
     }
   }
   stamp();
-#pragma unroll
-  for (int sb = 0; sb < 2; ++sb) {
-    if (sb == 1 && !has1) break;
-    float cl[4] = {EMPTY, EMPTY, EMPTY, EMPTY};
-#pragma unroll
-    for (int r = 0; r < 16; ++r) insert_sorted<4>(__uint_as_float((__float_as_uint(C[sb][r]) & ~CMASK) | (uint32_t)r), cl);
-    const int seg = (sb == 0 ? blk0 : blk1) * 32 + col;
-    const int slot = sb == 0 ? 0 : slot1;
-    if (seg < N) {
-      float* dst = stats + (((int64_t)seg * MAXP + slot) * 2 + h) * 8;
-      f32x4 tv, cv;
-#pragma unroll
-      for (int q = 0; q < 4; ++q) { tv[q] = tl[sb][q]; cv[q] = cl[q]; }
-      *reinterpret_cast<f32x4*>(dst) = tv;
-      *reinterpret_cast<f32x4*>(dst + 4) = cv;
-    }
-  }
+  flush(0, pcur);
+  if (has1) flush(1, whole1 ? pcur : slot1);
   stamp();
   if (dbg && threadIdx.x == 0) {
     dbg[blockIdx.x * 64 + 1] = nstamp;
@@ -679,7 +703,7 @@ bool plan_blocks(int N, int P, int tps, int num_cu, BlockPlan* out, bool force) 
   if (r > 0 && parts == 0) return false;
   if (r == 0) parts = 1;
   const long long items = r * parts;
-  out->q = q; out->G = G; out->nst = nst; out->parts = parts; out->items = (int)items; out->prio = 0;
+  out->q = q; out->G = G; out->nst = nst; out->parts = parts; out->items = (int)items; out->prio = 0; out->main_parts = 1;
   const long long per_wg = (items + G - 1) / G;                                   // leftover items in the fullest workgroup
   const double cost_blocks = (double)nst * (q / 4) + (double)((per_wg + 3) / 4) * ceil_div(nst, parts);
   const int ngroups = ceil_div(N, 512);
@@ -1113,7 +1137,7 @@ extern "C" int sdk_affinity_plan_range(int N, int P, int num_cu, int wg, int64_t
 // Host-only: the block plan of a shape (tests).  out6 = {1 if the plan is taken / 0 if the range plan stays, q, workgroups, stages, parts per leftover block, items}
 extern "C" int sdk_affinity_block_plan(int N, int P, int num_cu, int force, int32_t* out6) {
   SDK_REQUIRE(N > 0 && P > 0 && num_cu > 0 && out6, "sdk_affinity_block_plan: bad argument");
-  BlockPlan bp = {0, 0, 0, 0, 0, 0};
+  BlockPlan bp = {0, 0, 0, 0, 0, 0, 1};
   const bool ok = plan_blocks(N, P, 2, num_cu, &bp, force != 0);
   out6[0] = ok ? 1 : 0; out6[1] = bp.q; out6[2] = bp.G; out6[3] = bp.nst; out6[4] = bp.parts; out6[5] = bp.items;
   return 0;
@@ -1122,7 +1146,7 @@ extern "C" int sdk_affinity_block_plan(int N, int P, int num_cu, int force, int3
 // record slot, parts of that block}
 extern "C" int sdk_affinity_block_plan_wave(int N, int P, int num_cu, int wg, int wave, int32_t* out6) {
   SDK_REQUIRE(N > 0 && P > 0 && num_cu > 0 && out6 && wave >= 0 && wave < 8, "sdk_affinity_block_plan_wave: bad argument");
-  BlockPlan bp = {0, 0, 0, 0, 0, 0};
+  BlockPlan bp = {0, 0, 0, 0, 0, 0, 1};
   SDK_REQUIRE(plan_blocks(N, P, 2, num_cu, &bp, true) && wg >= 0 && wg < bp.G, "sdk_affinity_block_plan_wave: the shape has no block plan, or workgroup %d out of range", wg);
   int b0, b1, e0, e1, s1, c1;
   block_slots(bp, wg, wave, b0, b1, e0, e1, s1, c1);
@@ -1147,7 +1171,10 @@ int aff_rowcol_top1(sdk_ctx* ctx, const float* E, const uint16_t* Eb, const floa
     // `affinity_variant` 8 = the block plan whenever the shape fits (A/B, tests).  NOT the default: measured (profiles/r04_aff_block_plan_ab.txt) the
     // coarse pass gains 6-9 % at config #3 (47.1 -> 42.7-44.1 us) and whole sweeps give weaker certificates (201 instead of 88 rows to rescan:
     // +5.6 us), so end to end it is level (82.9-84.2 vs 81.4-82.4 us); config #4's shape is level either way.
-    if (ctx->aff_variant == 8 && plan_blocks(N, Pn, 2, ctx->num_cu, &bp, true)) {
+    const int av = ctx->aff_variant;                 // 8 / 12 / 13: the block plan with 1 / 2 / 3 records per whole sweep
+    if ((av == 8 || av == 12 || av == 13) && plan_blocks(N, Pn, 2, ctx->num_cu, &bp, true)) {
+      bp.main_parts = av == 8 ? 1 : av == 12 ? 2 : 3;
+      if (bp.nst < 2 * bp.main_parts) bp.main_parts = 1;        // (a part is at least two stages)
       auto kern = aff_rowcol_blocks_kernel<8, 2, 4>;
       constexpr int LDSB = 4 * 2 * TILE_BYTES;
       if (sdk_lds_optin(ctx, (const void*)kern, LDSB)) return 1;

@@ -527,7 +527,7 @@ def test_affinity_block_plan_equals_the_range_plan(engine, N, P):
     Pm[5] = oecapa.l2_normalise((Pm[4] + 1e-4 * Pm[6])[None])[0]    # a near-duplicate pair (below fp32 resolution for some rows: compared between the plans only)
     E[:64] = oecapa.l2_normalise(Pm[np.arange(64) % 8] + 0.05 * _unit(64, 192, 3))
     out = {}
-    for name, var in (("ranges", 7), ("blocks", 8)):
+    for name, var in (("ranges", 7), ("blocks", 8), ("blocks2", 12), ("blocks3", 13)):      # 12 / 13 (round 5): 2 / 3 records per whole sweep
         engine.set_option("affinity_variant", var)
         try:
             out[name] = _score_gpu(engine, E, Pm, 1)
@@ -535,6 +535,8 @@ def test_affinity_block_plan_equals_the_range_plan(engine, N, P):
             engine.set_option("affinity_variant", 0)
     a, b = out["ranges"], out["blocks"]
     assert np.array_equal(a[0], b[0]) and np.array_equal(a[1], b[1])
+    for k in ("blocks2", "blocks3"):
+        assert np.array_equal(a[0], out[k][0]) and np.array_equal(a[1], out[k][1]), k
     En, Pn = a[3], a[4]
     step = 20_000
     for lo in range(0, N, step):

@@ -7,8 +7,8 @@ import torch
 sys.path.insert(0, str(Path(__file__).resolve().parent.parent))
 ops = importlib.import_module("speaker-diarization-toolkit_amd.ops")
 eng = ops.get_engine(0)
-VARIANTS = [("general", 0, 0, 0), ("rowcol default", 1, 0, 0), ("rowcol range plan (v7)", 1, 7, 0), ("rowcol block plan (v8)", 1, 8, 0),
-            ("rowcol 4 tiles/stage (v1)", 1, 1, 0), ("rowcol late DMA issue (v10)", 1, 10, 0)]
+VARIANTS = [("general", 0, 0, 0), ("rowcol default", 1, 0, 0), ("rowcol range plan (v7)", 1, 7, 0), ("rowcol block plan, 1 record (v8)", 1, 8, 0),
+            ("rowcol block plan, 2 records (v12)", 1, 12, 0), ("rowcol block plan, 3 records (v13)", 1, 13, 0)]
 shapes = [(100_000, 1000), (125_000, 10_000)] if len(sys.argv) < 2 else [tuple(int(x) for x in a.split("x")) for a in sys.argv[1:]]
 for N3, P3 in shapes:
     E3, E3b, r3 = eng.l2norm(torch.randn(N3, 192, device="cuda", generator=torch.Generator(device="cuda").manual_seed(3)))
