@@ -82,17 +82,20 @@ int sdk_stream_synchronize(sdk_ctx* ctx, void* stream);
  * (likewise for the ASP logit weights, EL_ASP_W2PACK), "asp_per_segment"
  * (1 default / 0 = one workgroup per (segment, 128 channels)), "h_kblocked" (1 default / 0 = sdk_ecapa_forward keeps the MFA output row-major
  * instead of K-blocked, SDK_GEMM_C_KBLOCKED below), "affinity_fast_path" / "affinity_variant" /
- * "affinity_whole_groups" / "affinity_boundary_penalty" (k = 1 affinity kernel selection and work split), "chol_pivot_rtol_ppb" / "chol_shift_ppb"
+ * "affinity_boundary_penalty" (k = 1 affinity kernel selection and work split), "chol_pivot_rtol_ppb" / "chol_shift_ppb"
  * (sdk_chol_inverse, below), "matvec_variant" (0 default: persistent row-group kernel / 1 = round 1's
  * kernel; sums differ in the last bits only), "gemm_variant" (see sdk_set_gemm_variant).  Results do not depend on them.
  * NOT a knob - a numerical contract: "precision" 0 (default: bf16 operands, bf16 layer-boundary storage; PCM -> score within ~4e-3 of
- * the fp32 model) / 1 (fp16 hi+lo planes, three MFMAs per product: within 1e-5, ~3x the GEMM time).  It selects the output format of
- * sdk_fbank (planes) and must match the weight blob's sdk_ecapa_desc.precision. */
+ * the fp32 model, ~9e-4 with the host's bias correction) / 1 (fp16 hi+lo planes, three MFMAs per product: within 1e-5, ~3x the GEMM time) /
+ * 2 (round 5: ONE fp16 plane - the default schedule with fp16 instead of bf16 storage and MFMA operands: ~5e-4, ~1.7e-4 bias-corrected, ~0.96x the
+ * default's throughput; ECAPA-TDNN forward only).  It selects the output format of sdk_fbank (bf16 / planes / fp16) and the element format the sweeps
+ * (sdk_se_gate_residual, sdk_asp_stats, sdk_asp_pool, sdk_asp_fused*, sdk_res2net_chain) read and write, and must match the weight blob's
+ * sdk_ecapa_desc.precision; sdk_conv_gemm takes the format per call (SDK_GEMM_F16). */
 int sdk_set_option(sdk_ctx* ctx, const char* name, int value);
 /* Diagnostics: "stamps" = device buffer [workgroups][64] of uint64 that the affinity kernel (tools/aff_timeline.py) and the
  * Res2Net chain (tools/res2net_timeline.py) fill with in-kernel wall-clock stamps; "gemm_clock" = EXACTLY [4096][2] uint64 {shader cycles, 100 MHz ticks} of each
  * conv_gemm256 workgroup's lifetime (bench.py: the clock the chip holds inside the dominant kernel; workgroups >= 4096 do not write);
- * "gemm_stamps" = EXACTLY [4096] uint64 wall-clock stamps of conv_gemm256 workgroup 0's tile phases (tools/gemm_timeline.py, gemm_kstep.py;
+ * "gemm_stamps" = EXACTLY [4096] uint64 wall-clock stamps of conv_gemm256 workgroup 0's tile phases (tools/gemm_timeline.py;
  * a buffer of its own - the clock probe never writes outside its [4096][2]).  NULL (default) = off. */
 int sdk_debug_set_ptr(sdk_ctx* ctx, const char* name, void* device_ptr);
 
@@ -361,8 +364,9 @@ int sdk_affinity_plan(int N, int P, int num_cu, int32_t* out5, int64_t* units);
 /* Host-only: the unit range [u0, u1) of workgroup `wg` under that plan and the record slot of its first portion.  The ranges can be balanced by
  * cost instead of unit count ("affinity_boundary_penalty" p: a group boundary inside a range counts as p stages; default 0 - measured, not a robust win). */
 int sdk_affinity_plan_range(int N, int P, int num_cu, int wg, int64_t* u0, int64_t* u1, int32_t* first_slot);
-/* Host-only (round 4): the BLOCK plan of the coarse pass for short sweeps (config #3; `affinity_variant` 8 - measured level with the default range plan
- * end to end, so not the default), for tests.  Unit of work = a block of 32 segments with its whole
+/* Host-only: the BLOCK plan of the coarse pass for short sweeps (config #3), for tests.  Since round 5 it is what sdk_affinity_topk takes where its cost
+ * model prefers it, with two records per whole sweep (`affinity_variant` 0 = that choice, 7 = always the range plan, 8 / 12 / 13 = the block plan
+ * wherever the shape fits with 1 / 2 / 3 records: the A/B pair the tests keep bit-identical).  Unit of work = a block of 32 segments with its whole
  * sweep; workgroup g owns blocks [g q, (g + 1) q), the leftover blocks are swept in `parts` stage ranges by waves with a free second slot.
  * sdk_affinity_block_plan: out6 = {1 = plan taken / 0 = the range plan stays (force != 0: taken whenever the shape fits), q, workgroups, stages per
  * sweep, parts per leftover block, leftover items}.  sdk_affinity_block_plan_wave: wave `wave` (0..7) of workgroup `wg`: out6 = {block of slot 0, block of

@@ -42,7 +42,6 @@ struct Geom {            // host-computed, identical on both sides
   int ngroups, nst, G, segs;   // segment groups, stages per group, workgroups, segments per group
   long long U;                 // units = ngroups * nst
   int pen;                     // cost of starting a portion in a NEW group, in stages (fragment reload + a first stage that waits for it)
-  int prio;                    // A/B: 1 = waves 4-7 at static priority 2, 2 = waves 0-3 (`affinity_variant` 5 / 6); not part of the work split
 };
 
 // Work ranges balanced by COST, not by units (round 3; timeline profiles/r03_aff_timeline_config3.txt: with equal unit counts a workgroup whose
@@ -122,19 +121,10 @@ __device__ __forceinline__ void insert_sorted(float x, float* m) {
 
 __device__ __forceinline__ float max3(float a, float b, float c) { return fmaxf(fmaxf(a, b), c); }
 
-// WAVES waves x SEGB blocks of 32 segments; TPS tiles per LDS stage; NSTAGE stages.
-// PIPE (round 3, A/B knob `affinity_variant` 3, NOT the default): the row/column-maxima arithmetic of tile t-1 issued in the shadow of tile t's
-// MFMAs.  Plain form: a tile is 24 MFMAs, then ~60 vector instructions that need the last MFMA's result.  PIPE carries the finished accumulators
-// to the next tile (across the stage barrier too; two register sets written alternately) and deals the 58 reduction operations out by hand, 2-3
-// behind every MFMA, each slice closed by a sched_barrier.  Same operations on the same values in the same tile order: records bit-identical
-// (tests/test_gpu_kernels.py::test_affinity_pipelined_variant_is_bit_identical).  Measured, interleaved A/B (tools/aff_bench.py,
-// profiles/r03_aff_pipelined_ab.txt): config #3 50.5 vs 48.4 us, 125k x 10k 398 vs 377 us - SLOWER by 4-6 %.  The two waves of a SIMD already
-// overlap one wave's vector phase with the other's MFMAs (MI355X_MICROARCH.md "Two waves per SIMD": moving work between them is zero-sum), and the
-// per-MFMA issue budget (8 cycles for the MFMA + 4 per vector instruction, both waves) has no room for the extra address arithmetic the 256-register
-// budget forces (DMA source offsets re-derived per stage instead of kept in 6 registers).  A 4-wave form with 128 segments per wave and 512 registers
-// (one wave per SIMD, each fragment read feeding 4 MFMAs) was built too: hipcc keeps the segment fragments in AGPRs and copies them out before every MFMA
-// (4 v_accvgpr_read per MFMA, 18 registers spilled): 63 us / 582 us, removed.
-template <int WAVES, int SEGB, int TPS, int NSTAGE, bool PIPE, bool HANDRD>
+// WAVES waves x SEGB blocks of 32 segments; TPS tiles per LDS stage; NSTAGE stages.  (Rounds 3-4 also built, measured level or behind and removed: the
+// reduction of tile t-1 dealt out by hand under tile t's MFMAs - 4-6 % slower, the two waves of a SIMD overlap those phases already -, static wave
+// priorities, hand-pipelined fragment reads in this kernel, 4 tiles per stage, a late ring refill; docs/rounds/r01-r04_design_history.md 5.11.)
+template <int WAVES, int SEGB, int TPS, int NSTAGE>
 __global__ __launch_bounds__(WAVES * 64, 2) void aff_rowcol_kernel(const bf16_t* __restrict__ Eb, const bf16_t* __restrict__ Pb,
                                                                int N, int P, Geom gm, float* __restrict__ stats,
                                                                int32_t* __restrict__ part_base, int32_t* __restrict__ part_cnt,
@@ -161,31 +151,21 @@ __global__ __launch_bounds__(WAVES * 64, 2) void aff_rowcol_kernel(const bf16_t*
   const int ntiles = (P + PT - 1) / PT;
 
   // DMA assignment: a stage is DMA_PER_STAGE wave-instructions of 1 KiB; wave w issues instructions w*DPW .. w*DPW+DPW-1
-  // PIPE has no registers to spare for the per-lane source offsets (they were spilled and re-read from scratch after every barrier - and a
-  // scratch read waits on vmcnt in order, i.e. for the DMAs in flight): there they are re-derived from the lane number at every issue (~25
-  // vector instructions per stage; the empty asm keeps the compiler from hoisting them out of the loop again).
   int drow[DPW], dsrc[DPW];
-  auto dma_geom = [&](int ln, int i, int& row, int& src) {
-    const int id = (wid * DPW + i) * 64 + ln;
-    row = id / 24;
-    const int pos = id - row * 24;
-    src = ((pos & ~7) | ((pos & 7) ^ ((row >> 1) & 7))) * 8;    // source chunk (elements)
-  };
-  if constexpr (!PIPE) {
 #pragma unroll
-    for (int i = 0; i < DPW; ++i) dma_geom(lane, i, drow[i], dsrc[i]);
+  for (int i = 0; i < DPW; ++i) {
+    const int id = (wid * DPW + i) * 64 + lane;
+    drow[i] = id / 24;
+    const int pos = id - drow[i] * 24;
+    dsrc[i] = ((pos & ~7) | ((pos & 7) ^ ((drow[i] >> 1) & 7))) * 8;    // source chunk (elements)
   }
   int s_issue = (int)(u0 % nst), k_issue = 0;
   auto issue = [&]() {                                               // next stage of the running sequence
     char* st = sP + (k_issue % NSTAGE) * STAGE_BYTES;
-    int ln = lane;
-    if constexpr (PIPE) asm volatile("" : "+v"(ln));
 #pragma unroll
     for (int i = 0; i < DPW; ++i) {
-      int row, src;
-      if constexpr (PIPE) dma_geom(ln, i, row, src);
-      else { row = drow[i]; src = dsrc[i]; }
-      int pr = s_issue * (TPS * PT) + row;
+      const int src = dsrc[i];
+      int pr = s_issue * (TPS * PT) + drow[i];
       pr = pr < P ? pr : P - 1;
       __builtin_amdgcn_global_load_lds((const void __attribute__((address_space(1)))*)(Pb + (int64_t)pr * D + src),
                                        (void __attribute__((address_space(3)))*)(st + (wid * DPW + i) * 1024), 16, 0, 0);
@@ -204,15 +184,6 @@ __global__ __launch_bounds__(WAVES * 64, 2) void aff_rowcol_kernel(const bf16_t*
   bf16x8 bfrag[SEGB][KS];
   float C[SEGB][16], tl[SEGB][4];
   int ltile = 0;
-  f32x16 accp[SEGB], accq[SEGB];         // PIPE: accp = the previous stage's last tile, not yet reduced (2 EMPTY = nothing pending: reducing it changes nothing)
-  int ptag = 0;
-  auto clear_pending = [&]() {
-#pragma unroll
-    for (int sb = 0; sb < SEGB; ++sb)
-#pragma unroll
-      for (int r = 0; r < 16; ++r) accp[sb][r] = 2.f * EMPTY;      // below every list entry: inserting it is a no-op
-    ptag = 0;
-  };
   auto reduce = [&](const f32x16* ac, int tag) {
 #pragma unroll
     for (int sb = 0; sb < SEGB; ++sb) {
@@ -239,7 +210,6 @@ __global__ __launch_bounds__(WAVES * 64, 2) void aff_rowcol_kernel(const bf16_t*
       for (int q = 0; q < 4; ++q) tl[sb][q] = EMPTY;
     }
     ltile = 0;
-    if constexpr (PIPE) clear_pending();
     if (tid == 0) {
       if (slot < MAXP) part_base[b * MAXP + slot] = s * TPS;    // (a 4th part cannot happen - plan_geometry, tests/test_cabi_cpu.py - and would
                                                                 //  not go unnoticed: part_cnt > MAXP sends the group's rows to the exact rescan)
@@ -266,11 +236,6 @@ __global__ __launch_bounds__(WAVES * 64, 2) void aff_rowcol_kernel(const bf16_t*
   };
 
   if (u0 >= u1) return;
-  // A/B knob `affinity_variant` 5: static priority for waves 4-7 (the younger wave of every SIMD).  The two waves of a SIMD run this loop in
-  // lockstep - both in their MFMA phase, then both in their reduction phase, during which the matrix pipe idles (65 % busy inside the stage
-  // loop, tools/aff_timeline.py).  With one of them always winning arbitration its vector phases fall under the other's MFMAs.
-  if (gm.prio == 1) { if (wid >= WAVES / 2) __builtin_amdgcn_s_setprio(2); }
-  else if (gm.prio == 2) { if (wid < WAVES / 2) __builtin_amdgcn_s_setprio(2); }
   constexpr int AHEAD = NSTAGE - 1;                // stages in flight
 #pragma unroll
   for (int a = 0; a < AHEAD; ++a)
@@ -289,60 +254,6 @@ __global__ __launch_bounds__(WAVES * 64, 2) void aff_rowcol_kernel(const bf16_t*
     }
   };
   const char* sq[4];
-  // PIPE: the MFMAs of `tile` into out[], the reduction of prev[] (tile - 1, tag ptg) between their issues.  The reduction is written as
-  // 29 single operations per segment block and dealt out by hand, 2-3 behind every MFMA, each slice closed by a sched_barrier: the compiler's own
-  // interleaving (sched_group_barrier over the whole tile) filled the first ten MFMA shadows and left 35 operations after the last MFMA.
-  auto pipe_tile = [&](const int tt, const int tile, f32x16* out, const f32x16* prev, const int ptg) {
-    float t[SEGB][8], nl[SEGB][4];
-    auto op = [&](const int sb, const int j) {       // j is a compile-time constant after unrolling
-      const f32x16& a = prev[sb];
-      float* c = C[sb];
-      float* m = tl[sb];
-      if (j < 16) c[j] = fmaxf(c[j], a[j]);
-      else if (j < 21) t[sb][j - 16] = max3(a[3 * (j - 16)], a[3 * (j - 16) + 1], a[3 * (j - 16) + 2]);
-      else if (j == 21) t[sb][5] = max3(t[sb][0], t[sb][1], t[sb][2]);
-      else if (j == 22) t[sb][6] = max3(t[sb][3], t[sb][4], a[15]);
-      else if (j == 23) t[sb][7] = fmaxf(t[sb][5], t[sb][6]);
-      else if (j == 24) t[sb][7] = __uint_as_float((__float_as_uint(t[sb][7]) & ~TMASK) | (uint32_t)ptg);
-      else if (j == 25) nl[sb][3] = __builtin_amdgcn_fmed3f(t[sb][7], m[2], m[3]);
-      else if (j == 26) nl[sb][2] = __builtin_amdgcn_fmed3f(t[sb][7], m[1], m[2]);
-      else if (j == 27) nl[sb][1] = __builtin_amdgcn_fmed3f(t[sb][7], m[0], m[1]);
-      else { nl[sb][0] = fmaxf(t[sb][7], m[0]); m[0] = nl[sb][0]; m[1] = nl[sb][1]; m[2] = nl[sb][2]; m[3] = nl[sb][3]; }
-    };
-    constexpr int NOPS = 29 * SEGB, NMF = KS * SEGB, AHEADR = 2;
-    bf16x8 a[KS];
-#pragma unroll
-    for (int ks = 0; ks < AHEADR; ++ks) a[ks] = *reinterpret_cast<const bf16x8*>(sq[ks & 3] + tt * TILE_BYTES + (ks >> 2) * 128);
-    __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-    for (int i = 0; i < NMF; ++i) {
-      const int ks = i / SEGB, sb = i % SEGB;
-      if (sb == 0 && ks + AHEADR < KS)
-        a[ks + AHEADR] = *reinterpret_cast<const bf16x8*>(sq[(ks + AHEADR) & 3] + tt * TILE_BYTES + ((ks + AHEADR) >> 2) * 128);
-      if (ks == 0) {
-        f32x16 z;
-#pragma unroll
-        for (int r = 0; r < 16; ++r) z[r] = 0.f;
-        out[sb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[ks], bfrag[sb][ks], z, 0, 0, 0);
-      } else {
-        out[sb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[ks], bfrag[sb][ks], out[sb], 0, 0, 0);
-      }
-      // operations [i NOPS / NMF, (i + 1) NOPS / NMF) of the flat list (block 0's 29, then block 1's ...)
-#pragma unroll
-      for (int o = i * NOPS / NMF; o < (i + 1) * NOPS / NMF; ++o) op(o / 29, o % 29);
-      __builtin_amdgcn_sched_barrier(0);
-    }
-    // pins: the reduction ends HERE (IR-level sinking would otherwise move it to its uses, past the next branch)
-#pragma unroll
-    for (int sb = 0; sb < SEGB; ++sb) {
-      float* c = C[sb];
-      asm volatile("" : "+v"(c[0]), "+v"(c[1]), "+v"(c[2]), "+v"(c[3]), "+v"(c[4]), "+v"(c[5]), "+v"(c[6]), "+v"(c[7]), "+v"(c[8]), "+v"(c[9]),
-                   "+v"(c[10]), "+v"(c[11]), "+v"(c[12]), "+v"(c[13]), "+v"(c[14]), "+v"(c[15]), "+v"(tl[sb][0]), "+v"(tl[sb][1]), "+v"(tl[sb][2]),
-                   "+v"(tl[sb][3]), "+v"(out[sb]));
-    }
-    __builtin_amdgcn_sched_barrier(0);
-    mask_partial(tile, out);
-  };
   int k = 0;
   long long u = u0;
   while (u < u1) {                                 // one portion = this workgroup's share of one group's sweep
@@ -368,62 +279,13 @@ __global__ __launch_bounds__(WAVES * 64, 2) void aff_rowcol_kernel(const bf16_t*
       }
       __builtin_amdgcn_s_barrier();                 // stage k landed for everyone; the buffer of stage k-1 is free
       stamp();
-      constexpr bool late_issue = false;            // (round 4 A/B, `affinity_variant` 10 then: the refill issued behind the first tile's MFMAs - 47.0 vs 47.1 us: no change, removed)
       if (u + AHEAD < u1) issue();
       // Fragment addresses: chunk c = 2 ks + h of this lane's row sits at 16 * ((c & ~7) | ((c & 7) ^ rsw)); its low three
       // bits depend only on ks & 3, so four per-lane offsets + compile-time immediates (tile, ks >> 2) cover all 12 reads of
       // every tile.  (Left to the compiler, the XOR was re-derived per read: ~50 of the ~118 vector instructions per tile.)
 #pragma unroll
       for (int q = 0; q < 4; ++q) sq[q] = sP + (k % NSTAGE) * STAGE_BYTES + aoff[q];
-      if constexpr (PIPE) {
-        // two named accumulator sets, written alternately (no register copies): tile 2 s -> accq while accp is reduced, tile 2 s + 1 -> accp
-        // while accq is reduced.  A stage exists only if its first tile does.
-        static_assert(!PIPE || TPS == 2, "the pipelined form alternates two accumulator sets");
-        const int tile0 = s * TPS;
-        pipe_tile(0, tile0, accq, accp, ptag);
-        const int tag0 = ltile++;
-        if (tile0 + 1 < ntiles) {                    // wave-uniform
-          pipe_tile(1, tile0 + 1, accp, accq, tag0);
-          ptag = ltile++;
-        } else {                                     // odd tile count: nothing follows in this sweep - reduce now, leave "nothing pending"
-          reduce(accq, tag0);
-          clear_pending();
-        }
-      } else if constexpr (HANDRD) {
-        static_assert(!HANDRD || (TPS == 2 && SEGB == 2), "TileStep<0 / 1> with two blocks");
-        // hand-pipelined fragment reads (TileStep above): A/B knob `affinity_variant` 11, its own instantiation - measured equal to the compiler's
-        // schedule (as a run-time branch inside the default instantiation it cost the DEFAULT path 30 %: 47 -> 61-66 us at config #3)
-        const uint32_t stage_off = (uint32_t)((k % NSTAGE) * STAGE_BYTES);
-        const uint32_t sqa[4] = {stage_off + (uint32_t)aoff[0], stage_off + (uint32_t)aoff[1], stage_off + (uint32_t)aoff[2], stage_off + (uint32_t)aoff[3]};
-        bf16x8 ring[RD];
-        tile_prologue<0>(sqa, ring);
-        const int tile0 = s * TPS;
-        const bool t1 = tile0 + 1 < ntiles;            // wave-uniform
-        {
-          f32x16 acc[2];
-#pragma unroll
-          for (int sb = 0; sb < 2; ++sb)
-#pragma unroll
-            for (int r = 0; r < 16; ++r) acc[sb][r] = 0.f;
-          if (t1) TileStep<0, 2, true, 0>::run(sqa, bfrag, acc, ring);
-          else TileStep<0, 2, false, 0>::run(sqa, bfrag, acc, ring);
-          if (late_issue && u + AHEAD < u1) issue();
-          mask_partial(tile0, acc);
-          reduce(acc, ltile);
-          ++ltile;
-        }
-        if (t1) {
-          f32x16 acc[2];
-#pragma unroll
-          for (int sb = 0; sb < 2; ++sb)
-#pragma unroll
-            for (int r = 0; r < 16; ++r) acc[sb][r] = 0.f;
-          TileStep<1, 2, false, 0>::run(sqa, bfrag, acc, ring);
-          mask_partial(tile0 + 1, acc);
-          reduce(acc, ltile);
-          ++ltile;
-        }
-      } else {
+      {
 #pragma unroll
         for (int tt = 0; tt < TPS; ++tt) {
           const int tile = s * TPS + tt;
@@ -448,7 +310,6 @@ __global__ __launch_bounds__(WAVES * 64, 2) void aff_rowcol_kernel(const bf16_t*
       ++s;
     }
     stamp();
-    if constexpr (PIPE) reduce(accp, ptag);         // drain the last tile
     end_portion(s == nst);
     if (s == nst) { ++b; s = 0; slot = 0; }         // the next portion starts a new group
   }
@@ -474,7 +335,6 @@ __global__ __launch_bounds__(WAVES * 64, 2) void aff_rowcol_kernel(const bf16_t*
 // The host picks this plan when its estimated cost (block-stages on the busiest SIMD) is under the range plan's (plan_blocks).
 struct BlockPlan {
   int q, G, nst, parts, items;      // main blocks per workgroup, workgroups, stages per sweep, parts per leftover block, leftover items
-  int prio;
   int main_parts;                   // records a WHOLE sweep writes (round 5): 1 = one record at the end; 2 / 3 = the row / column maxima are flushed and
                                     // reset at the stage boundaries p nst / main_parts, so the certificate is that of sweeps a half / a third as long
 };
@@ -579,7 +439,6 @@ __global__ __launch_bounds__(WAVES * 64, 2) void aff_rowcol_blocks_kernel(const 
       part_cnt[blk1] = cnt1;                                       // (every part of a leftover block writes the same count)
     }
   }
-  if (pl.prio == 1) { if (wid >= WAVES / 2) __builtin_amdgcn_s_setprio(2); }
   constexpr int AHEAD = NSTAGE - 1;
 #pragma unroll
   for (int a = 0; a < AHEAD; ++a)
@@ -703,7 +562,7 @@ bool plan_blocks(int N, int P, int tps, int num_cu, BlockPlan* out, bool force) 
   if (r > 0 && parts == 0) return false;
   if (r == 0) parts = 1;
   const long long items = r * parts;
-  out->q = q; out->G = G; out->nst = nst; out->parts = parts; out->items = (int)items; out->prio = 0; out->main_parts = 1;
+  out->q = q; out->G = G; out->nst = nst; out->parts = parts; out->items = (int)items; out->main_parts = 1;
   const long long per_wg = (items + G - 1) / G;                                   // leftover items in the fullest workgroup
   const double cost_blocks = (double)nst * (q / 4) + (double)((per_wg + 3) / 4) * ceil_div(nst, parts);
   const int ngroups = ceil_div(N, 512);
@@ -716,15 +575,10 @@ bool plan_blocks(int N, int P, int tps, int num_cu, BlockPlan* out, bool force) 
 // (i, j) = (c / 3, c % 3), the combinations c = (j & 3), (j & 3) + 4, (j & 3) + 8.  The live ones are gathered into one
 // list per row (identical on the 8 lanes) and scored two at a time with the shared dot routine.
 constexpr int MAXC = 8;                // candidates re-scored per row; more than that (rare) -> the row takes the rescan
-constexpr int INLINE_MAX_P = 0;        // rows the certificate cannot settle are scanned INSIDE the re-score kernel up to this many profiles.
-                                       // Measured at config #3 (P = 1000): re-score 25.7 -> 41-52 us (the few workgroups that own an uncertain row
-                                       // become a 15-us tail) against the 12 us of the two rescan launches it saves: off.
-
-// INLINE: the workgroup scans its own uncertain rows (typically none, ~0.1 % of rows) over all P right away - 32 lane groups
-// x P/32 profiles each - instead of queueing them for two more launches that cost ~12 us to settle ~100 rows at config #3.
+// (Scanning the uncertain rows inside this kernel instead of queueing them for the rescan was measured in round 3: the few workgroups that own one become a
+// 15-us tail - 25.7 -> 41-52 us against the 12 us of the two launches it saves - and was removed.)
 constexpr int RS_SLICE = 64, RS_ROWS = 4;   // the exact rescan's work item: RS_ROWS flagged rows x a slice of profiles (below)
 
-template <bool INLINE>
 __global__ __launch_bounds__(256) void aff_rowcol_rescore_kernel(const float* __restrict__ E, const float* __restrict__ Pm,
                                                                 const float* __restrict__ resid_e,
                                                                 const float* __restrict__ resid_p, int N, int P, int segs,
@@ -862,14 +716,6 @@ __global__ __launch_bounds__(256) void aff_rowcol_rescore_kernel(const float* __
     }
   }
   u = fmaxf(u, __shfl_xor(u, 4, 64));
-  __shared__ int fcount_s;
-  __shared__ int flist_s[32];
-  __shared__ float ls_s[32];
-  __shared__ int li_s[32];
-  if constexpr (INLINE) {
-    if (tid == 0) fcount_s = 0;
-    __syncthreads();
-  }
   if (live && j == 0) {
     // What was not re-scored: (a) entries outside the top-3 rows x top-3 columns: coarse <= u, exact <= u + eps;
     // (b) intersections pruned by best - 3 eps: exact < best - 2 eps; (c) intersections pruned by s1 - eps: exact < s1
@@ -878,51 +724,9 @@ __global__ __launch_bounds__(256) void aff_rowcol_rescore_kernel(const float* __
     const bool uncertain = M > MAXC || !(bs > outside) || np_raw > MAXP;   // (np_raw > MAXP: a part's record was dropped - cannot happen)
     row_best[row] = 0ull;                                            // the rescan's per-flagged-row keys (index < count <= N) ...
     if ((row & (RS_ROWS - 1)) == 0) quad_done[row / RS_ROWS] = 0;   // arrival counters of the rescan's row quads (index < count / RS_ROWS <= N / RS_ROWS)
-    if (uncertain) {
-      if constexpr (INLINE) flist_s[atomicAdd(&fcount_s, 1)] = row;
-      else flag_rows[atomicAdd(flag_count, 1)] = row;
-    }
-    if (!(INLINE && uncertain)) {       // INLINE: an uncertain row is written once, by the scan below (no two writers of one address)
-      idx[row] = bi;
-      score[row] = bs;
-    }
-  }
-  if constexpr (INLINE) {
-    __syncthreads();
-    const int nf = fcount_s;
-    if (nf > 0 && tid == 0) atomicAdd(flag_count, nf);             // reported only (n_rescanned)
-    const int g = tid >> 3;
-    for (int f = 0; f < nf; ++f) {                                  // workgroup-uniform
-      const int frow = flist_s[f];
-      float ef[24];
-      load_row24(E + (int64_t)frow * D, j, ef);
-      float fs = -INFINITY;
-      int fi = 0x7fffffff;
-      for (int p0 = g; p0 < P; p0 += 64) {                          // ascending per lane group, two rows in flight
-        const int pa = p0, pb2 = p0 + 32 < P ? p0 + 32 : p0;
-        f32x4 pv0[6], pv1[6];
-        load_prow(Pm + (int64_t)pa * D, j, pv0);
-        load_prow(Pm + (int64_t)pb2 * D, j, pv1);
-        const float sa = dot192_regs(ef, pv0);
-        const float sb2 = dot192_regs(ef, pv1);
-        if (better(sa, pa, fs, fi)) { fs = sa; fi = pa; }
-        if (better(sb2, pb2, fs, fi)) { fs = sb2; fi = pb2; }     // pb2 == pa past the end: no effect
-      }
-      if (j == 0) { ls_s[g] = fs; li_s[g] = fi; }
-      __syncthreads();
-      if (tid < 64) {
-        float s2 = tid < 32 ? ls_s[tid] : -INFINITY;
-        int i2 = tid < 32 ? li_s[tid] : 0x7fffffff;
-#pragma unroll
-        for (int o = 16; o > 0; o >>= 1) {
-          const float ts = __shfl_xor(s2, o, 64);
-          const int ti = __shfl_xor(i2, o, 64);
-          if (better(ts, ti, s2, i2)) { s2 = ts; i2 = ti; }
-        }
-        if (tid == 0) { idx[frow] = i2; score[frow] = s2; }
-      }
-      __syncthreads();
-    }
+    if (uncertain) flag_rows[atomicAdd(flag_count, 1)] = row;
+    idx[row] = bi;
+    score[row] = bs;
   }
 }
 
@@ -1068,7 +872,7 @@ size_t ws_layout(int N, int P, char* base, Ws* w) {
 }
 
 // Work decomposition of the coarse kernel (host side; the kernel derives each workgroup's range from it).
-Geom plan_geometry(int N, int P, int segs, int tps, long long max_wg, int whole_groups_mode = 0, int pen = 0) {
+Geom plan_geometry(int N, int P, int segs, int tps, long long max_wg, int pen = 0) {
   Geom gm;
   gm.segs = segs;
   gm.ngroups = ceil_div(N, segs);
@@ -1077,33 +881,22 @@ Geom plan_geometry(int N, int P, int segs, int tps, long long max_wg, int whole_
   long long G = max_wg;
   if (G > 2LL * gm.ngroups) G = 2LL * gm.ngroups;     // every range >= half a sweep: a group's sweep meets <= 3 workgroups (MAXP slots)
   if (G > gm.U) G = gm.U;
-  // Short sweeps (few profile stages): splitting a group's sweep over workgroups costs each of them a fragment reload, a
-  // ring refill and a record (~8 us at config #3, against 8 stages of ~4.5 us).  When the groups alone fill most of the
-  // chip, give every workgroup ONE whole group instead: fewer CUs busy, no parts.  Estimated in stage units.
-  if (whole_groups_mode && gm.ngroups <= max_wg && G > gm.ngroups) {
-    // measured at config #3 (100k x 1k, 2-tile stages): split 50.1 us vs whole 47.2 us => the split costs ~4.5 stages extra
-    const double split = (double)gm.U / (double)G + 3.5 /* reload + refill + record */ + 1.0 /* one stage of granularity */;
-    const double whole = (double)gm.nst;
-    if (whole <= split || whole_groups_mode == 2) G = gm.ngroups;     // mode 2 (A/B knob): whenever the groups fit
-  }
   gm.G = (int)G;
   // the boundary penalty needs every virtual range to hold at least one real unit (no empty workgroup inside a group's slot sequence):
   // floor(V / G) >= pen + 1; with G <= 2 groups that is nst >= pen + 2 - otherwise (very short sweeps) the plain split
   gm.pen = 0;
-  gm.prio = 0;
   if (pen > 0 && gm.nst >= pen + 2 && ((long long)gm.ngroups * (gm.nst + pen)) / G >= pen + 1) gm.pen = pen;
   return gm;
 }
 
-template <int WAVES, int SEGB, int TPS, int NSTAGE, bool PIPE = false, bool HANDRD = false>
+template <int WAVES, int SEGB, int TPS, int NSTAGE>
 int launch_coarse(sdk_ctx* ctx, const bf16_t* Eb, const bf16_t* Pb, int N, int P, const Ws& w, hipStream_t s, int wg_per_cu,
                   int* segs) {
   constexpr int SEGS = WAVES * SEGB * 32;
   constexpr int LDS = NSTAGE * TPS * TILE_BYTES;
   *segs = SEGS;
-  Geom gm = plan_geometry(N, P, SEGS, TPS, (long long)ctx->num_cu * wg_per_cu, ctx->aff_whole_groups, ctx->aff_boundary_pen);
-  gm.prio = ctx->aff_variant == 5 ? 1 : ctx->aff_variant == 6 ? 2 : 0;
-  auto kern = aff_rowcol_kernel<WAVES, SEGB, TPS, NSTAGE, PIPE, HANDRD>;
+  Geom gm = plan_geometry(N, P, SEGS, TPS, (long long)ctx->num_cu * wg_per_cu, ctx->aff_boundary_pen);
+  auto kern = aff_rowcol_kernel<WAVES, SEGB, TPS, NSTAGE>;
   if (sdk_lds_optin(ctx, (const void*)kern, LDS)) return 1;
   hipLaunchKernelGGL(kern, dim3(gm.G), dim3(WAVES * 64), LDS, s, Eb, Pb, N, P, gm, w.stats, w.part_base, w.part_cnt, w.flag_count,
                      (unsigned long long*)ctx->dbg_ptr);
@@ -1118,7 +911,7 @@ size_t aff_rowcol_workspace_bytes(int N, int P) { return ws_layout(N, P, nullptr
 // group, record slots per segment}, units = groups * stages.  Workgroup i sweeps units [i*units/wg, (i+1)*units/wg).
 extern "C" int sdk_affinity_plan(int N, int P, int num_cu, int32_t* out5, int64_t* units) {
   SDK_REQUIRE(N > 0 && P > 0 && num_cu > 0 && out5 && units, "sdk_affinity_plan: bad argument");
-  const Geom gm = plan_geometry(N, P, 8 * 2 * 32, 2, num_cu, 0, AFF_DEFAULT_PEN);       // the default variant: 8 waves x 2 blocks, 2 tiles per stage
+  const Geom gm = plan_geometry(N, P, 8 * 2 * 32, 2, num_cu, AFF_DEFAULT_PEN);       // the default variant: 8 waves x 2 blocks, 2 tiles per stage
   out5[0] = gm.ngroups; out5[1] = gm.nst; out5[2] = gm.G; out5[3] = gm.segs; out5[4] = MAXP;
   *units = gm.U;
   return 0;
@@ -1126,7 +919,7 @@ extern "C" int sdk_affinity_plan(int N, int P, int num_cu, int32_t* out5, int64_
 // Host-only: workgroup i's unit range [u0, u1) and the record slot of its first portion, under the default plan (tests replay the kernel's walk)
 extern "C" int sdk_affinity_plan_range(int N, int P, int num_cu, int wg, int64_t* u0, int64_t* u1, int32_t* first_slot) {
   SDK_REQUIRE(N > 0 && P > 0 && num_cu > 0 && u0 && u1 && first_slot, "sdk_affinity_plan_range: bad argument");
-  const Geom gm = plan_geometry(N, P, 8 * 2 * 32, 2, num_cu, 0, AFF_DEFAULT_PEN);
+  const Geom gm = plan_geometry(N, P, 8 * 2 * 32, 2, num_cu, AFF_DEFAULT_PEN);
   SDK_REQUIRE(wg >= 0 && wg < gm.G, "sdk_affinity_plan_range: workgroup %d of %d", wg, gm.G);
   long long a, b;
   geom_range(gm, wg, a, b);
@@ -1137,7 +930,7 @@ extern "C" int sdk_affinity_plan_range(int N, int P, int num_cu, int wg, int64_t
 // Host-only: the block plan of a shape (tests).  out6 = {1 if the plan is taken / 0 if the range plan stays, q, workgroups, stages, parts per leftover block, items}
 extern "C" int sdk_affinity_block_plan(int N, int P, int num_cu, int force, int32_t* out6) {
   SDK_REQUIRE(N > 0 && P > 0 && num_cu > 0 && out6, "sdk_affinity_block_plan: bad argument");
-  BlockPlan bp = {0, 0, 0, 0, 0, 0, 1};
+  BlockPlan bp = {0, 0, 0, 0, 0, 1};
   const bool ok = plan_blocks(N, P, 2, num_cu, &bp, force != 0);
   out6[0] = ok ? 1 : 0; out6[1] = bp.q; out6[2] = bp.G; out6[3] = bp.nst; out6[4] = bp.parts; out6[5] = bp.items;
   return 0;
@@ -1146,7 +939,7 @@ extern "C" int sdk_affinity_block_plan(int N, int P, int num_cu, int force, int3
 // record slot, parts of that block}
 extern "C" int sdk_affinity_block_plan_wave(int N, int P, int num_cu, int wg, int wave, int32_t* out6) {
   SDK_REQUIRE(N > 0 && P > 0 && num_cu > 0 && out6 && wave >= 0 && wave < 8, "sdk_affinity_block_plan_wave: bad argument");
-  BlockPlan bp = {0, 0, 0, 0, 0, 0, 1};
+  BlockPlan bp = {0, 0, 0, 0, 0, 1};
   SDK_REQUIRE(plan_blocks(N, P, 2, num_cu, &bp, true) && wg >= 0 && wg < bp.G, "sdk_affinity_block_plan_wave: the shape has no block plan, or workgroup %d out of range", wg);
   int b0, b1, e0, e1, s1, c1;
   block_slots(bp, wg, wave, b0, b1, e0, e1, s1, c1);
@@ -1168,43 +961,36 @@ int aff_rowcol_top1(sdk_ctx* ctx, const float* E, const uint16_t* Eb, const floa
     ProfScope ps(ctx, stream, SDK_K_AFF_COARSE, 2.0 * N * (double)Pn * D, 2.0 * ((double)N + Pn) * D + 64.0 * N);
     int rc;
     BlockPlan bp;
-    // `affinity_variant` 8 = the block plan whenever the shape fits (A/B, tests).  NOT the default: measured (profiles/r04_aff_block_plan_ab.txt) the
-    // coarse pass gains 6-9 % at config #3 (47.1 -> 42.7-44.1 us) and whole sweeps give weaker certificates (201 instead of 88 rows to rescan:
-    // +5.6 us), so end to end it is level (82.9-84.2 vs 81.4-82.4 us); config #4's shape is level either way.
-    const int av = ctx->aff_variant;                 // 8 / 12 / 13: the block plan with 1 / 2 / 3 records per whole sweep
-    if ((av == 8 || av == 12 || av == 13) && plan_blocks(N, Pn, 2, ctx->num_cu, &bp, true)) {
-      bp.main_parts = av == 8 ? 1 : av == 12 ? 2 : 3;
+    // Coarse-pass plan.  Default (round 5): the BLOCK plan with two records per whole sweep wherever its cost model takes it (short sweeps: config #3),
+    // else the range plan (long sweeps: config #4's shape, where it balances to the stage).  `affinity_variant`: 7 = always the range plan, 8 / 12 / 13
+    // = always the block plan (where the shape fits it) with 1 / 2 / 3 records per sweep - the A/B pair tests/test_gpu_kernels.py keeps bit-identical.
+    // Measured (profiles/r05_aff_block_plan_records.txt, interleaved): config #3 range 82.1 us (88 rows rescanned), blocks with 1 / 2 / 3 records
+    // 83.1 (201) / 78.9 (73) / 79.4 (40); 125k x 10k: 463.8 / 482.0 / 459.3 / 466.0.
+    const int av = ctx->aff_variant;
+    const bool want_blocks = av == 8 || av == 12 || av == 13 || av == 0;
+    if (want_blocks && plan_blocks(N, Pn, 2, ctx->num_cu, &bp, av != 0)) {
+      bp.main_parts = av == 8 ? 1 : av == 13 ? 3 : 2;
       if (bp.nst < 2 * bp.main_parts) bp.main_parts = 1;        // (a part is at least two stages)
       auto kern = aff_rowcol_blocks_kernel<8, 2, 4>;
       constexpr int LDSB = 4 * 2 * TILE_BYTES;
       if (sdk_lds_optin(ctx, (const void*)kern, LDSB)) return 1;
-      bp.prio = ctx->aff_variant == 5 ? 1 : 0;
       hipLaunchKernelGGL(kern, dim3(bp.G), dim3(512), LDSB, s, (const bf16_t*)Eb, (const bf16_t*)Pb, N, Pn, bp, w.stats, w.part_base, w.part_cnt, w.flag_count,
                          (unsigned long long*)ctx->dbg_ptr);
       segs = 32;
       rc = 0;
-    } else
-    switch (ctx->aff_variant) {
-      case 1: rc = launch_coarse<8, 2, 4, 3>(ctx, (const bf16_t*)Eb, (const bf16_t*)Pb, N, Pn, w, s, 1, &segs); break;
-      case 2: rc = launch_coarse<4, 2, 2, 3>(ctx, (const bf16_t*)Eb, (const bf16_t*)Pb, N, Pn, w, s, 2, &segs); break;
-      case 3: rc = launch_coarse<8, 2, 2, 4, true>(ctx, (const bf16_t*)Eb, (const bf16_t*)Pb, N, Pn, w, s, 1, &segs); break;
-      case 11: rc = launch_coarse<8, 2, 2, 4, false, true>(ctx, (const bf16_t*)Eb, (const bf16_t*)Pb, N, Pn, w, s, 1, &segs); break;
-      default: rc = launch_coarse<8, 2, 2, 4>(ctx, (const bf16_t*)Eb, (const bf16_t*)Pb, N, Pn, w, s, 1, &segs); break;
+    } else {
+      rc = launch_coarse<8, 2, 2, 4>(ctx, (const bf16_t*)Eb, (const bf16_t*)Pb, N, Pn, w, s, 1, &segs);
     }
     if (rc) return rc;
   }
   SDK_LAUNCH_CHECK();
   {
     ProfScope ps(ctx, stream, SDK_K_AFF_RESCORE, 0.0, 4.0 * N * D + 64.0 * N + 8.0 * N);
-    if (Pn <= INLINE_MAX_P)
-      hipLaunchKernelGGL(aff_rowcol_rescore_kernel<true>, dim3(ceil_div(N, 32)), dim3(256), 0, s, E, P, resid_e, resid_p, N, Pn, segs,
-                         w.stats, w.part_base, w.part_cnt, idx, score, w.flag_count, w.flag_rows, w.quad_done, w.row_best);
-    else
-      hipLaunchKernelGGL(aff_rowcol_rescore_kernel<false>, dim3(ceil_div(N, 32)), dim3(256), 0, s, E, P, resid_e, resid_p, N, Pn, segs,
-                         w.stats, w.part_base, w.part_cnt, idx, score, w.flag_count, w.flag_rows, w.quad_done, w.row_best);
+    hipLaunchKernelGGL(aff_rowcol_rescore_kernel, dim3(ceil_div(N, 32)), dim3(256), 0, s, E, P, resid_e, resid_p, N, Pn, segs,
+                       w.stats, w.part_base, w.part_cnt, idx, score, w.flag_count, w.flag_rows, w.quad_done, w.row_best);
   }
   SDK_LAUNCH_CHECK();
-  if (Pn > INLINE_MAX_P) {
+  {
     ProfScope ps(ctx, stream, SDK_K_AFF_RESCAN, 0.0, 0.0);
     hipLaunchKernelGGL(aff_rescan4_kernel, dim3(RS_GRID), dim3(256), 0, s, E, P, Pn, w.flag_count, w.flag_rows, w.row_best,
                        w.quad_done, idx, score);

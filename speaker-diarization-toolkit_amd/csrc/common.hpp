@@ -39,15 +39,12 @@ struct sdk_ctx {
   void* dbg_ptr = nullptr;         // diagnostics only: device buffer for the affinity kernel's time stamps (sdk_debug_set_ptr "stamps")
   void* gemm_clk_ptr = nullptr;    // diagnostics only: [4096][2] uint64 {shader cycles, 100 MHz ticks} of conv_gemm256_kernel ("gemm_clock")
   void* gemm_stamps_ptr = nullptr; // diagnostics only: [4096] uint64 phase stamps of conv_gemm256 workgroup 0 ("gemm_stamps"; tools/gemm_timeline.py)
-  int aff_whole_groups = 0;       // A/B knob: allow "one whole group per workgroup" when sweeps are short (affinity_rowcol.hip plan_geometry).
-                                  // Off: at config #3 it takes 2.3 us off the coarse pass (49.0 -> 46.7) and adds 3.8 us to the rescan (one part per
-                                  // group = a weaker certificate: 202 instead of 88 uncertain rows), 87.2 vs 84.9 us end to end
   int hp_gemm_variant = 0;        // A/B + test knob: 1 = the precise mode's GEMM always as the 128^2 register-staged kernel
   int matvec_variant = 0;         // A/B + test knob: 1 = round 1's affinity_matvec_kernel (one 32-row block per wave, a barrier per tile)
   int aff_boundary_pen = 0;       // k = 1 coarse pass: cost of a group boundary inside a workgroup's range, in stages (affinity_rowcol.hip Geom.pen; 0 = equal unit counts)
   int chol_pivot_rtol_ppb = 1000; // sdk_chol_inverse: a pivot <= this fraction (in 1e-9) of its diagonal entry sets the sticky not_spd flag (default 1e-6: cond(Y) > ~1e3)
   int chol_shift_ppb = 0;         // sdk_chol_inverse: shifted CholeskyQR, G + s I with s = this fraction (in 1e-9) of the mean diagonal entry (0 = off)
-  int aff_variant = 0;            // A/B knob: workgroup shape of the row/column kernel (see affinity_rowcol.hip)
+  int aff_variant = 0;            // A/B knob: coarse-pass plan of the row/column kernel (0 = cost model, 7 = range plan, 8 / 12 / 13 = block plan; affinity_rowcol.hip)
   std::vector<const void*> lds_optin;   // kernels of THIS context's device already opted in to > 64 KiB dynamic LDS
   std::vector<sdk_prof_rec> prof;
 };

@@ -125,7 +125,7 @@ extern "C" int sdk_set_option(sdk_ctx* ctx, const char* name, int value) {
   if (strcmp(name, "affinity_boundary_penalty") == 0) { ctx->aff_boundary_pen = value < 0 ? 0 : value; return 0; }
   if (strcmp(name, "matvec_variant") == 0) { ctx->matvec_variant = value; return 0; }
   if (strcmp(name, "hp_gemm_variant") == 0) { ctx->hp_gemm_variant = value; return 0; }
-  if (strcmp(name, "affinity_whole_groups") == 0) { ctx->aff_whole_groups = value; return 0; }
+  if (strcmp(name, "affinity_whole_groups") == 0) return 0;      // (round-3 knob, measured behind and removed in round 5: accepted and ignored)
   if (strcmp(name, "chol_pivot_rtol_ppb") == 0) { ctx->chol_pivot_rtol_ppb = value < 0 ? 0 : value; return 0; }
   if (strcmp(name, "chol_shift_ppb") == 0) { ctx->chol_shift_ppb = value < 0 ? 0 : value; return 0; }
   sdk_set_error("sdk_set_option: unknown option '%s'", name);

@@ -500,26 +500,10 @@ def test_affinity_rescan_is_deterministic_and_sliced(engine):
             assert np.array_equal(idx, ref[0]) and np.array_equal(sc, ref[1]), f"run {rep} differs"
 
 
-@pytest.mark.parametrize("N,P", [(5000, 1000), (2000, 1025), (3001, 31), (700, 2500)])
-def test_affinity_pipelined_variant_is_bit_identical(engine, N, P):
-    """`affinity_variant` 3 issues the row/column-maxima arithmetic of tile t - 1 between the MFMAs of tile t (carried over stage barriers and
-    drained at the end of a portion; odd tile counts take the "nothing pending" branch): same operations on the same values in the same
-    order, so indices, scores and the number of rescanned rows must equal the default kernel's exactly - partial last tile, odd and even
-    tile counts, P below one stage, sweeps split over workgroups."""
-    E, Pm = _unit(N, 192, N + P), _unit(P, 192, 7 * P + 1)
-    ref = _score_gpu(engine, E, Pm, 1)
-    engine.set_option("affinity_variant", 3)
-    try:
-        got = _score_gpu(engine, E, Pm, 1)
-    finally:
-        engine.set_option("affinity_variant", 0)
-    assert np.array_equal(got[0], ref[0]) and np.array_equal(got[1], ref[1]) and got[2] == ref[2]
-
-
 @pytest.mark.parametrize("N,P", [(100_000, 1000), (70_001, 333), (109_215, 1000), (131_000, 197), (98_303, 2049)])
 def test_affinity_block_plan_equals_the_range_plan(engine, N, P):
-    """Round 4: the coarse pass's BLOCK plan (every workgroup sweeps all stages once; blocks of 32 segments dealt to waves, leftover blocks swept in
-    parts; csrc/affinity_rowcol.hip) against the range plan on the same inputs: the exact pass certifies or rescans every row, so indices and
+    """The coarse pass's two plans - the BLOCK plan (every workgroup sweeps all stages once; blocks of 32 segments dealt to waves, leftover blocks swept in
+    parts; 1, 2 or 3 records per whole sweep; the default where its cost model takes it, round 5) and the RANGE plan (`affinity_variant` 7) - on the same inputs: the exact pass certifies or rescans every row, so indices and
     scores must agree bit for bit whatever the decomposition - near-duplicate profiles, exact ties and a partial last tile included - and both
     equal the fp64 scan of the GPU's own embeddings (IDs identical, scores within 1e-5)."""
     E, Pm = _unit(N, 192, N + P), _unit(P, 192, 7 * P + 1)

@@ -16,7 +16,7 @@ for N3, P3 in shapes:
     q3m = q3.max().reshape(1)
     ref = None
     for name, fast, var, wg in VARIANTS:
-        eng.set_option("affinity_fast_path", fast); eng.set_option("affinity_variant", var); eng.set_option("affinity_whole_groups", wg)
+        eng.set_option("affinity_fast_path", fast); eng.set_option("affinity_variant", var)
         idx, sc, cnt = eng.affinity_topk(E3, E3b, r3, Q3, Q3b, q3m, k=1, want_count=True)
         torch.cuda.synchronize()
         if ref is None:
@@ -32,7 +32,7 @@ for N3, P3 in shapes:
             same_i = bool(torch.equal(idx, ref[0])); same_s = bool(torch.equal(sc, ref[1]))
             nd = int((idx != ref[0]).sum())
             print(f"{N3}x{P3} {name}: idx identical {same_i} ({nd} differ), scores bit-identical {same_s}, rescanned {int(cnt.item())}", flush=True)
-    eng.set_option("affinity_fast_path", 1); eng.set_option("affinity_variant", 0); eng.set_option("affinity_whole_groups", 0)
+    eng.set_option("affinity_fast_path", 1); eng.set_option("affinity_variant", 0)
     nbad = 0
     for rep in range(30):                                  # the rescan's slices meet through atomics: the answer must not depend on who is last
         idx, sc = eng.affinity_topk(E3, E3b, r3, Q3, Q3b, q3m, k=1)[:2]
@@ -41,7 +41,7 @@ for N3, P3 in shapes:
     res = {n: [] for n, _, _, _ in VARIANTS}
     for rnd in range(5):
         for name, fast, var, wg in VARIANTS:
-            eng.set_option("affinity_fast_path", fast); eng.set_option("affinity_variant", var); eng.set_option("affinity_whole_groups", wg)
+            eng.set_option("affinity_fast_path", fast); eng.set_option("affinity_variant", var)
             for _ in range(2): eng.affinity_topk(E3, E3b, r3, Q3, Q3b, q3m, k=1)
             eng.profile_begin()
             for _ in range(10): eng.affinity_topk(E3, E3b, r3, Q3, Q3b, q3m, k=1)
@@ -53,4 +53,4 @@ for N3, P3 in shapes:
         tot = sum(med.values())
         print(f"{N3}x{P3} {name:24s} " + " ".join(f"{k.replace('affinity_', '')}={v:.1f}" for k, v in med.items()) +
               f" total={tot:.1f} us  coarse {2 * N3 * P3 * 192 / med['affinity_coarse'] / 1e6:.0f} TF  total {2 * N3 * P3 * 192 / tot / 1e6:.0f} TF", flush=True)
-eng.set_option("affinity_fast_path", 1); eng.set_option("affinity_variant", 0); eng.set_option("affinity_whole_groups", 0)
+eng.set_option("affinity_fast_path", 1); eng.set_option("affinity_variant", 0)
