@@ -633,7 +633,8 @@ def main() -> int:
                 """bytes leaving L2 per launch of aff_rowcol_kernel from the committed rocprofv3 --pmc pass at this shape (tools/pmc_any.sh tools/one_aff.py)"""
                 files = sorted((ROOT / "profiles").glob(f"*pmc_aff_{tag}.json"))
                 try:
-                    pm = json.loads(files[-1].read_text())["aff_rowcol_kernel"]
+                    pmj = json.loads(files[-1].read_text())
+                    pm = pmj.get("aff_rowcol_blocks_kernel") or pmj["aff_rowcol_kernel"]      # the coarse pass's plan at this shape (block plan at config #3 since round 5)
                     return round((2.0 * pm["FETCH_SIZE"] + pm["WRITE_SIZE"]) * 1024.0, 1), f"profiles/{files[-1].name}"
                 except Exception:  # noqa: BLE001
                     return None, None
@@ -658,7 +659,7 @@ def main() -> int:
                 return {"workload": label, "pairs_per_sec": round(N3 * P3 / (total_ms * 1e-3), 1), "ms_total": round(total_ms, 4),
                         "ms_coarse_mfma": round(coarse_ms, 4), "ms_exact_tail": round(total_ms - coarse_ms, 4),
                         "total_over_coarse": round(total_ms / coarse_ms, 3), "rows_rescanned": int(cnt.item()),
-                        "roofline": {"kernel": "aff_rowcol_kernel", "bound": "mfma", "achieved": round(fl / (coarse_ms * 1e-3) / 1e12, 2),
+                        "roofline": {"kernel": "aff_rowcol_blocks_kernel / aff_rowcol_kernel (coarse pass; the plan is chosen per shape)", "bound": "mfma", "achieved": round(fl / (coarse_ms * 1e-3) / 1e12, 2),
                                      "peak": PEAK_BF16_MFMA / 1e12, "unit": "TFLOP/s", "frac": round(fl / (coarse_ms * 1e-3) / PEAK_BF16_MFMA, 4),
                                      "traffic": aff_traffic(tag)[0] if tag else None, "traffic_source": aff_traffic(tag)[1] if tag else None,
                                      "algorithmic_bytes_per_launch": 2.0 * (N3 + P3) * 192 + 64.0 * N3,

@@ -48,7 +48,7 @@
 extern "C" {
 #endif
 
-#define SDK_ABI_VERSION 3   /* 2: sdk_ecapa_desc.precision (round 3); 3: sdk_fbank_windows + sdk_ingest_* (round 4) */
+#define SDK_ABI_VERSION 4   /* 2: sdk_ecapa_desc.precision (round 3); 3: sdk_fbank_windows + sdk_ingest_* (round 4); 4: precision 2, sdk_fbank_fmt, SDK_GEMM_F16, lazy ingest slots (round 5) */
 
 typedef struct sdk_ctx sdk_ctx;
 
@@ -88,9 +88,10 @@ int sdk_stream_synchronize(sdk_ctx* ctx, void* stream);
  * NOT a knob - a numerical contract: "precision" 0 (default: bf16 operands, bf16 layer-boundary storage; PCM -> score within ~4e-3 of
  * the fp32 model, ~9e-4 with the host's bias correction) / 1 (fp16 hi+lo planes, three MFMAs per product: within 1e-5, ~3x the GEMM time) /
  * 2 (round 5: ONE fp16 plane - the default schedule with fp16 instead of bf16 storage and MFMA operands: ~5e-4, ~1.7e-4 bias-corrected, ~0.96x the
- * default's throughput; ECAPA-TDNN forward only).  It selects the output format of sdk_fbank (bf16 / planes / fp16) and the element format the sweeps
- * (sdk_se_gate_residual, sdk_asp_stats, sdk_asp_pool, sdk_asp_fused*, sdk_res2net_chain) read and write, and must match the weight blob's
- * sdk_ecapa_desc.precision; sdk_conv_gemm takes the format per call (SDK_GEMM_F16). */
+ * default's throughput; ECAPA-TDNN forward only).  The OPTION is only the default of the entry points that have no format argument: the output
+ * format of sdk_fbank / sdk_fbank_windows (bf16 / planes / fp16; sdk_fbank_fmt takes it per call) and the element format the stand-alone sweeps
+ * (sdk_se_gate_residual, sdk_asp_stats, sdk_asp_pool, sdk_asp_fused*, sdk_res2net_chain) read and write.  The forwards take the contract from the
+ * weight blob's descriptor (sdk_ecapa_desc.precision), sdk_conv_gemm from its flags (SDK_GEMM_F16): per call, no shared state. */
 int sdk_set_option(sdk_ctx* ctx, const char* name, int value);
 /* Diagnostics: "stamps" = device buffer [workgroups][64] of uint64 that the affinity kernel (tools/aff_timeline.py) and the
  * Res2Net chain (tools/res2net_timeline.py) fill with in-kernel wall-clock stamps; "gemm_clock" = EXACTLY [4096][2] uint64 {shader cycles, 100 MHz ticks} of each
@@ -136,6 +137,13 @@ int sdk_fbank(sdk_ctx* ctx, const int16_t* pcm, int B, int S, const void* tabs,
  * samples at hop 1 s / window 2 s) never exist on the host and never cross PCIe.  n_samples < 2^31. */
 int sdk_fbank_windows(sdk_ctx* ctx, const int16_t* samples, int64_t n_samples, const int32_t* starts, int B, int S, const void* tabs,
                       uint16_t* feats, int ldf, void* ws, size_t ws_bytes, void* stream);
+/* Both with the output format as an ARGUMENT (precision 0 / 1 / 2, see sdk_set_option) instead of the context's "precision" option (round 5): a
+ * host that runs several numerical contracts on one device - two engines, two threads - then shares no mutable state through the library.
+ * sdk_ecapa_forward / sdk_xvector_forward take the contract from their descriptor alone; the features must have been written in that format. */
+int sdk_fbank_fmt(sdk_ctx* ctx, const int16_t* pcm, int B, int S, const void* tabs, uint16_t* feats, int ldf, void* ws, size_t ws_bytes, int precision,
+                  void* stream);
+int sdk_fbank_windows_fmt(sdk_ctx* ctx, const int16_t* samples, int64_t n_samples, const int32_t* starts, int B, int S, const void* tabs,
+                          uint16_t* feats, int ldf, void* ws, size_t ws_bytes, int precision, void* stream);
 
 /* ---- ingest: host audio -> HBM, staged through pinned memory on a copy stream of its own, `depth`-deep (2 = double-buffered) so that the
  *      upload of recording i + 1 runs under the forward pass of recording i.  A slot = pinned host buffers for int16 samples and

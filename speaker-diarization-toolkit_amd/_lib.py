@@ -65,7 +65,7 @@ KERNEL_FAMILIES = ["conv_gemm", "se_gate", "asp_stats", "rows_fc", "asp_pool", "
                    "affinity_coarse", "affinity_rescore", "affinity_rescan", "copy", "affinity_matvec", "conv_gemm256", "asp_fused", "res2net_chain", "resample",
                    "conv_gemm_hp"]
 
-ABI_VERSION = 3
+ABI_VERSION = 4
 GEMM_RELU = 1
 GEMM_TANH = 2
 GEMM_A_KBLOCKED = 4      # A read / C written as [cols / 64][M][64] (include/sdk_hip.h)
@@ -89,6 +89,8 @@ SIGNATURES = {
     "sdk_fbank_tables_fill": (_i, [_vp, _sz]),
     "sdk_fbank_workspace_bytes": (_sz, [_i, _i]),
     "sdk_fbank": (_i, [_vp, _vp, _i, _i, _vp, _vp, _i, _vp, _sz, _vp]),
+    "sdk_fbank_fmt": (_i, [_vp, _vp, _i, _i, _vp, _vp, _i, _vp, _sz, _i, _vp]),
+    "sdk_fbank_windows_fmt": (_i, [_vp, _vp, _i64, _vp, _i, _i, _vp, _vp, _i, _vp, _sz, _i, _vp]),
     "sdk_fbank_windows": (_i, [_vp, _vp, _i64, _vp, _i, _i, _vp, _vp, _i, _vp, _sz, _vp]),
     "sdk_ingest_create": (_i, [_vp, _i64, _i, _i, C.POINTER(_vp)]),
     "sdk_ingest_destroy": (_i, [_vp]),

@@ -57,6 +57,13 @@ int sdk_lds_optin(sdk_ctx* ctx, const void* func, int bytes);
 int asp_fused_launch(sdk_ctx* ctx, const uint16_t* ah, int64_t ldah, const uint16_t* w2, const uint16_t* w2p, const float* b2,
                      const uint16_t* h, int64_t ldh, int B, int T, int C, int A, float* pooled, void* stream, bool kblocked = false, bool f16 = false);
 
+// pool_se.hip: the sweeps with the 2-byte element format as an argument (f16: fp16 instead of bf16), for sdk_ecapa_forward
+int se_gate_residual_impl(sdk_ctx* ctx, const uint16_t* z, int64_t ldz, const uint16_t* x, int64_t ldx, const float* w1t, const float* b1, const float* w2t,
+                          const float* b2, uint16_t* out, int64_t ldo, int B, int T, int C, int Cse, const float* mean_in, void* ws, size_t ws_bytes,
+                          void* stream, bool f16);
+int asp_stats_impl(sdk_ctx* ctx, const uint16_t* h, int64_t ldh, int B, int T, int C, float* out_ctx, void* stream, bool f16);
+int asp_pool_impl(sdk_ctx* ctx, const float* logits, int64_t ldl, const uint16_t* h, int64_t ldh, int B, int T, int C, float* pooled, void* stream, bool f16);
+
 // res2net.hip: sdk_res2net_chain with the optional fragment-ordered weight copies (internal; sdk_ecapa_forward)
 int res2net_chain_launch(sdk_ctx* ctx, const uint16_t* U, int64_t ldu, uint16_t* R, int64_t ldr, const uint16_t* const* W,
                          const uint16_t* const* Wpk, const float* const* bias, const float* const* scale, const float* const* shift,

@@ -428,10 +428,11 @@ extern "C" size_t sdk_fbank_workspace_bytes(int B, int S) {
 }
 
 static int fbank_launch(sdk_ctx* ctx, const int16_t* pcm, const int32_t* starts, int64_t n_total, int B, int S, const void* tabs, uint16_t* feats,
-                        int ldf, void* ws, size_t ws_bytes, void* stream, const char* who) {
+                        int ldf, void* ws, size_t ws_bytes, int precision, void* stream, const char* who) {
   SDK_REQUIRE(ctx && pcm && tabs && feats && ws, "%s: null argument", who);
   SDK_REQUIRE(B > 0 && S > 0, "%s: empty batch (B=%d S=%d)", who, B, S);
-  const bool hp = ctx->precision == 1;
+  SDK_REQUIRE(precision >= 0 && precision <= 2, "%s: precision=%d must be 0 (bf16), 1 (fp16 hi | lo planes) or 2 (one fp16 plane)", who, precision);
+  const bool hp = precision == 1;
   if (hp) SDK_REQUIRE((ldf >> 1) >= NMEL && ldf % 16 == 0, "%s: precise mode writes planes: ldf=%d must be >= 160 and a multiple of 16", who, ldf);
   SDK_REQUIRE(ldf >= NMEL && ldf % 8 == 0, "%s: ldf=%d must be >= 80 and a multiple of 8", who, ldf);
   SDK_REQUIRE(ws_bytes >= sdk_fbank_workspace_bytes(B, S), "%s: workspace too small", who);
@@ -446,7 +447,7 @@ static int fbank_launch(sdk_ctx* ctx, const int16_t* pcm, const int32_t* starts,
   }
   SDK_LAUNCH_CHECK();
   ProfScope ps2(ctx, stream, SDK_K_FBANK_NORM, 3.0 * B * T * NMEL, 4.0 * B * T * NMEL + 2.0 * B * T * ldf);
-  const bool f16 = ctx->precision == 2;                  // one fp16 plane, the default mode's [B*T, ldf] layout
+  const bool f16 = precision == 2;                       // one fp16 plane, the default mode's [B*T, ldf] layout
   void (*norm_lds)(const float*, int, bf16_t*, int) = hp ? fbank_norm_lds_kernel<true> : f16 ? fbank_norm_lds_kernel<false, true> : fbank_norm_lds_kernel<false>;
   void (*norm)(const float*, int, bf16_t*, int) = hp ? fbank_norm_kernel<true> : f16 ? fbank_norm_kernel<false, true> : fbank_norm_kernel<false>;
   if (T <= NORM_LDS_MAX_T) {
@@ -462,7 +463,15 @@ static int fbank_launch(sdk_ctx* ctx, const int16_t* pcm, const int32_t* starts,
 
 extern "C" int sdk_fbank(sdk_ctx* ctx, const int16_t* pcm, int B, int S, const void* tabs, uint16_t* feats, int ldf,
                          void* ws, size_t ws_bytes, void* stream) {
-  return fbank_launch(ctx, pcm, nullptr, 0, B, S, tabs, feats, ldf, ws, ws_bytes, stream, "sdk_fbank");
+  SDK_REQUIRE(ctx, "sdk_fbank: null context");
+  return fbank_launch(ctx, pcm, nullptr, 0, B, S, tabs, feats, ldf, ws, ws_bytes, ctx->precision, stream, "sdk_fbank");
+}
+
+// The same with the output format as an ARGUMENT instead of the context's "precision" option (round 5): hosts that run several numerical
+// contracts on one device - two engines, two threads - share no mutable state through the library this way.
+extern "C" int sdk_fbank_fmt(sdk_ctx* ctx, const int16_t* pcm, int B, int S, const void* tabs, uint16_t* feats, int ldf,
+                             void* ws, size_t ws_bytes, int precision, void* stream) {
+  return fbank_launch(ctx, pcm, nullptr, 0, B, S, tabs, feats, ldf, ws, ws_bytes, precision, stream, "sdk_fbank_fmt");
 }
 
 // Windows cut ON THE DEVICE: the recording is resident once ([n_samples] s16) and window b is the S samples from starts[b] (device int32 table).
@@ -472,5 +481,13 @@ extern "C" int sdk_fbank_windows(sdk_ctx* ctx, const int16_t* samples, int64_t n
                                  uint16_t* feats, int ldf, void* ws, size_t ws_bytes, void* stream) {
   SDK_REQUIRE(starts, "sdk_fbank_windows: null start table");
   SDK_REQUIRE(n_samples > 0 && n_samples < (1ll << 31), "sdk_fbank_windows: n_samples=%lld must be in [1, 2^31)", (long long)n_samples);
-  return fbank_launch(ctx, samples, starts, n_samples, B, S, tabs, feats, ldf, ws, ws_bytes, stream, "sdk_fbank_windows");
+  SDK_REQUIRE(ctx, "sdk_fbank_windows: null context");
+  return fbank_launch(ctx, samples, starts, n_samples, B, S, tabs, feats, ldf, ws, ws_bytes, ctx->precision, stream, "sdk_fbank_windows");
+}
+
+extern "C" int sdk_fbank_windows_fmt(sdk_ctx* ctx, const int16_t* samples, int64_t n_samples, const int32_t* starts, int B, int S, const void* tabs,
+                                     uint16_t* feats, int ldf, void* ws, size_t ws_bytes, int precision, void* stream) {
+  SDK_REQUIRE(starts, "sdk_fbank_windows_fmt: null start table");
+  SDK_REQUIRE(n_samples > 0 && n_samples < (1ll << 31), "sdk_fbank_windows_fmt: n_samples=%lld must be in [1, 2^31)", (long long)n_samples);
+  return fbank_launch(ctx, samples, starts, n_samples, B, S, tabs, feats, ldf, ws, ws_bytes, precision, stream, "sdk_fbank_windows_fmt");
 }

@@ -833,16 +833,16 @@ extern "C" size_t sdk_se_workspace_bytes(int B, int C, int Cse) {
   return B > 0 ? ((size_t)B * C * 2 + (size_t)B * Cse) * sizeof(float) : 0;
 }
 
-extern "C" int sdk_se_gate_residual(sdk_ctx* ctx, const uint16_t* z, int64_t ldz, const uint16_t* x, int64_t ldx,
-                                    const float* w1t, const float* b1, const float* w2t, const float* b2,
-                                    uint16_t* out, int64_t ldo, int B, int T, int C, int Cse, const float* mean_in,
-                                    void* ws, size_t ws_bytes, void* stream) {
+// (sdk_ecapa_forward passes the blob's format; the exported wrapper below takes the context's "precision" option)
+int se_gate_residual_impl(sdk_ctx* ctx, const uint16_t* z, int64_t ldz, const uint16_t* x, int64_t ldx,
+                          const float* w1t, const float* b1, const float* w2t, const float* b2,
+                          uint16_t* out, int64_t ldo, int B, int T, int C, int Cse, const float* mean_in,
+                          void* ws, size_t ws_bytes, void* stream, bool f16) {
   SDK_REQUIRE(ctx && z && x && w1t && b1 && w2t && b2 && out, "sdk_se_gate_residual: null argument");
   SDK_REQUIRE(B > 0 && T > 0, "sdk_se_gate_residual: empty batch");
   SDK_REQUIRE(C % 8 == 0 && C / 8 <= NT && NT % (C / 8) == 0, "sdk_se_gate_residual: C=%d unsupported (need C/8 | 256)", C);
   SDK_REQUIRE(Cse > 0 && Cse <= NT && NT % Cse == 0 && Cse <= C, "sdk_se_gate_residual: Cse=%d unsupported (need Cse | 256)", Cse);
   SDK_REQUIRE(ldz % 8 == 0 && ldx % 8 == 0 && ldo % 8 == 0, "sdk_se_gate_residual: row strides must be multiples of 8");
-  const bool f16 = ctx->precision == 2;                     // the context's storage format (sdk_set_option "precision" 2: fp16 activations)
   if (ws && ws_bytes >= sdk_se_workspace_bytes(B, C, Cse)) {
     // split schedule: channel means (one sweep of z) -> the two gate FCs batched over all segments on the
     // matrix pipe (weights read once per 32 segments instead of once per segment) -> gate*z + x sweep
@@ -877,15 +877,26 @@ extern "C" int sdk_se_gate_residual(sdk_ctx* ctx, const uint16_t* z, int64_t ldz
   return 0;
 }
 
-extern "C" int sdk_asp_stats(sdk_ctx* ctx, const uint16_t* h, int64_t ldh, int B, int T, int C, float* out_ctx,
-                             void* stream) {
+extern "C" int sdk_se_gate_residual(sdk_ctx* ctx, const uint16_t* z, int64_t ldz, const uint16_t* x, int64_t ldx,
+                                    const float* w1t, const float* b1, const float* w2t, const float* b2,
+                                    uint16_t* out, int64_t ldo, int B, int T, int C, int Cse, const float* mean_in,
+                                    void* ws, size_t ws_bytes, void* stream) {
+  return se_gate_residual_impl(ctx, z, ldz, x, ldx, w1t, b1, w2t, b2, out, ldo, B, T, C, Cse, mean_in, ws, ws_bytes, stream, ctx && ctx->precision == 2);
+}
+
+int asp_stats_impl(sdk_ctx* ctx, const uint16_t* h, int64_t ldh, int B, int T, int C, float* out_ctx, void* stream, bool f16) {
   SDK_REQUIRE(ctx && h && out_ctx, "sdk_asp_stats: null argument");
   SDK_REQUIRE(B > 0 && T > 0 && C % 8 == 0 && ldh % 8 == 0, "sdk_asp_stats: bad shape (C=%d ldh=%lld)", C, (long long)ldh);
   ProfScope ps(ctx, stream, SDK_K_ASP_STATS, 3.0 * B * T * C, 2.0 * B * T * C);
-  hipLaunchKernelGGL(ctx->precision == 2 ? asp_stats_kernel<true> : asp_stats_kernel<false>, dim3(B, ceil_div(C, 1024)), dim3(NT), 0, (hipStream_t)stream, (const bf16_t*)h,
+  hipLaunchKernelGGL(f16 ? asp_stats_kernel<true> : asp_stats_kernel<false>, dim3(B, ceil_div(C, 1024)), dim3(NT), 0, (hipStream_t)stream, (const bf16_t*)h,
                      ldh, T, C, out_ctx);
   SDK_LAUNCH_CHECK();
   return 0;
+}
+
+extern "C" int sdk_asp_stats(sdk_ctx* ctx, const uint16_t* h, int64_t ldh, int B, int T, int C, float* out_ctx,
+                             void* stream) {
+  return asp_stats_impl(ctx, h, ldh, B, T, C, out_ctx, stream, ctx && ctx->precision == 2);
 }
 
 extern "C" int sdk_rows_fc(sdk_ctx* ctx, const float* in, int64_t ldin, const float* in_scale, const float* in_shift,
@@ -921,15 +932,20 @@ extern "C" int sdk_rows_fc(sdk_ctx* ctx, const float* in, int64_t ldin, const fl
   return 0;
 }
 
-extern "C" int sdk_asp_pool(sdk_ctx* ctx, const float* logits, int64_t ldl, const uint16_t* h, int64_t ldh, int B,
-                            int T, int C, float* pooled, void* stream) {
+int asp_pool_impl(sdk_ctx* ctx, const float* logits, int64_t ldl, const uint16_t* h, int64_t ldh, int B,
+                  int T, int C, float* pooled, void* stream, bool f16) {
   SDK_REQUIRE(ctx && logits && h && pooled, "sdk_asp_pool: null argument");
   SDK_REQUIRE(B > 0 && T > 0 && C % 64 == 0, "sdk_asp_pool: C=%d must be a multiple of 64", C);
   ProfScope ps(ctx, stream, SDK_K_ASP_POOL, 8.0 * B * T * C, 6.0 * B * T * C);
-  hipLaunchKernelGGL(ctx->precision == 2 ? asp_pool_kernel<true> : asp_pool_kernel<false>, dim3(B, C / 64), dim3(NT), 0, (hipStream_t)stream, logits, ldl,
+  hipLaunchKernelGGL(f16 ? asp_pool_kernel<true> : asp_pool_kernel<false>, dim3(B, C / 64), dim3(NT), 0, (hipStream_t)stream, logits, ldl,
                      (const bf16_t*)h, ldh, T, C, pooled);
   SDK_LAUNCH_CHECK();
   return 0;
+}
+
+extern "C" int sdk_asp_pool(sdk_ctx* ctx, const float* logits, int64_t ldl, const uint16_t* h, int64_t ldh, int B,
+                            int T, int C, float* pooled, void* stream) {
+  return asp_pool_impl(ctx, logits, ldl, h, ldh, B, T, C, pooled, stream, ctx && ctx->precision == 2);
 }
 
 extern "C" int sdk_asp_fused_max_frames(void) { return 224; }

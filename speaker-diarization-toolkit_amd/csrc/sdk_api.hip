@@ -383,8 +383,8 @@ static int ecapa_forward_impl(sdk_ctx* ctx, const void* wblob, const sdk_ecapa_d
   SDK_REQUIRE(B > 0 && T > 0, "sdk_ecapa_forward: empty batch (B=%d T=%d)", B, T);
   SDK_REQUIRE((int64_t)B * T < (1ll << 31), "sdk_ecapa_forward: B*T overflows int32; split the batch");
   SDK_REQUIRE(ldf >= d->n_mels_padded && ldf % 8 == 0, "sdk_ecapa_forward: ldf=%d < padded mel width %d", ldf, d->n_mels_padded);
-  SDK_REQUIRE(d->precision == ctx->precision, "sdk_ecapa_forward: the weight blob was packed for precision %d but the context runs precision %d "
-              "(sdk_set_option \"precision\"; features and weights must be in the same format)", d->precision, ctx->precision);
+  // The numerical contract is the DESCRIPTOR's (per call): features must be in that format (sdk_fbank_fmt with the same precision).  The context's
+  // "precision" option plays no part here since round 5 - two engines with different contracts on one device share no mutable state.
   int maxhalo = d->kernel0 / 2;
   for (int i = 0; i < d->n_blocks; ++i) maxhalo = d->dilation[i] > maxhalo ? d->dilation[i] : maxhalo;
   SDK_REQUIRE(T > maxhalo, "sdk_ecapa_forward: segments of %d frames are shorter than the receptive halo %d", T, maxhalo);
@@ -408,8 +408,8 @@ static int ecapa_forward_impl(sdk_ctx* ctx, const void* wblob, const sdk_ecapa_d
   const int M = B * T, C = d->channels, Cm = d->mfa_channels, S = d->sub_channels, A = d->attn_channels;
   hipStream_t st = (hipStream_t)stream;
   // precision 2 (round 5): the same schedule with every 2-byte tensor - features, weights, activations - in fp16 instead of bf16 (11 significand
-  // bits: 7 x closer to the fp32 model at one MFMA per product, profiles/r05_fp16_decision.txt); the sweeps take the format from the context
-  // (checked equal to the descriptor's above), the GEMMs from their flag, the two internal launches from their argument
+  // bits: 7 x closer to the fp32 model at one MFMA per product, profiles/r05_fp16_decision.txt); every stage takes the
+  // format per call: the GEMMs from their flag, the sweeps and the two fused launches from an argument of their internal entry
   const bool f16 = d->precision == 2;
   const uint32_t fmt = f16 ? SDK_GEMM_F16 : 0u;
 
@@ -442,7 +442,7 @@ static int ecapa_forward_impl(sdk_ctx* ctx, const void* wblob, const sdk_ecapa_d
   for (int i = 1; i <= d->n_blocks; ++i) {
     const int base = EL_BLOCK_BASE(i), dil = d->dilation[i - 1];
     if (calib)
-      if (int rc = sdk_asp_stats(ctx, xin, ldx, B, T, C, calib + calib_offset(d, B, i - 1, 0), stream)) return rc;
+      if (int rc = asp_stats_impl(ctx, xin, ldx, B, T, C, calib + calib_offset(d, B, i - 1, 0), stream, f16)) return rc;
     if (int rc = tdnn(xin, ldx, C, 1, 1, base + EL_TDNN1, C, w.U, C, nullptr, 0, nullptr, 0)) return rc;
     // Res2Net: chunk 0 passes through, chunk c>=1 = TDNN(chunk c + y_{c-1})
     const uint16_t* r2out = w.R;
@@ -472,21 +472,21 @@ static int ecapa_forward_impl(sdk_ctx* ctx, const void* wblob, const sdk_ecapa_d
         uint16_t* Sout = more ? ((j & 1) ? w.Sb : w.Sa) : nullptr;
         const uint16_t* X2 = more ? w.U + (int64_t)S * (j + 2) : nullptr;
         if (calib)
-          if (int rc = sdk_asp_stats(ctx, Ain, lda, B, T, S, calib + calib_offset(d, B, i - 1, 1 + j), stream)) return rc;
+          if (int rc = asp_stats_impl(ctx, Ain, lda, B, T, S, calib + calib_offset(d, B, i - 1, 1 + j), stream, f16)) return rc;
         if (int rc = tdnn(Ain, lda, S, 3, dil, base + EL_RES2NET(j), S, w.R + (int64_t)S * (j + 1), C, X2, C, Sout, S)) return rc;
       }
     }
     if (calib)
-      if (int rc = sdk_asp_stats(ctx, r2out, C, B, T, C, calib + calib_offset(d, B, i - 1, d->scale), stream)) return rc;
+      if (int rc = asp_stats_impl(ctx, r2out, C, B, T, C, calib + calib_offset(d, B, i - 1, d->scale), stream, f16)) return rc;
     // the SE squeeze (per-segment channel means of z) comes out of the tdnn2 epilogue where the shape allows it
     const bool fuse_se = sdk_conv_gemm_stats_fusable(M, C, T) != 0;
     if (int rc = tdnn(r2out, C, C, 1, 1, base + EL_TDNN2, C, w.Z, C, nullptr, 0, nullptr, 0, fuse_se ? 1 : 0)) return rc;
     if (fuse_se)
       if (int rc = sdk_colstats_finish(ctx, w.stats, M, C, T, 1, w.mean, stream)) return rc;
     uint16_t* slab = w.CAT + (int64_t)C * (i - 1);
-    if (int rc = sdk_se_gate_residual(ctx, w.Z, C, xin, ldx, P32(base + EL_SE_W1T), P32(base + EL_SE_B1), P32(base + EL_SE_W2T),
-                                      P32(base + EL_SE_B2), slab, Cm, B, T, C, d->se_channels, fuse_se ? w.mean : nullptr, w.se,
-                                      sdk_se_workspace_bytes(B, C, d->se_channels), stream)) return rc;
+    if (int rc = se_gate_residual_impl(ctx, w.Z, C, xin, ldx, P32(base + EL_SE_W1T), P32(base + EL_SE_B1), P32(base + EL_SE_W2T),
+                                       P32(base + EL_SE_B2), slab, Cm, B, T, C, d->se_channels, fuse_se ? w.mean : nullptr, w.se,
+                                       sdk_se_workspace_bytes(B, C, d->se_channels), stream, f16)) return rc;
     xin = slab;
     ldx = Cm;
   }
@@ -496,17 +496,17 @@ static int ecapa_forward_impl(sdk_ctx* ctx, const void* wblob, const sdk_ecapa_d
   // the MFA epilogue where the shape allows it, else from a separate sweep of h
   const bool fuse_ctx = sdk_conv_gemm_stats_fusable(M, Cm, T) != 0;
   if (calib)
-    if (int rc = sdk_asp_stats(ctx, w.CAT, Cm, B, T, Cm, calib + calib_offset(d, B, d->n_blocks, 0), stream)) return rc;
+    if (int rc = asp_stats_impl(ctx, w.CAT, Cm, B, T, Cm, calib + calib_offset(d, B, d->n_blocks, 0), stream, f16)) return rc;
   // h [M, Cm] is the widest activation and is read twice, both times in 64- / 32-channel pieces of its 6-KB rows (the skinny attention-hidden GEMM,
   // the per-segment ASP slabs): where those two are its only readers it is written K-BLOCKED, [Cm / 64][M][64] (sdk_hip.h SDK_GEMM_C_KBLOCKED)
   const bool h_kb = !ctx->no_h_kblocked && !calib && fuse_ctx && A == 128 && sdk_asp_kblocked_ok(ctx, T, Cm) != 0;
   if (int rc = tdnn(w.CAT, Cm, Cm, 1, 1, tb + EL_MFA, Cm, w.H, Cm, nullptr, 0, nullptr, 0, fuse_ctx ? 2 : 0, h_kb ? SDK_GEMM_C_KBLOCKED : 0)) return rc;
   if (calib)
-    if (int rc = sdk_asp_stats(ctx, w.H, Cm, B, T, Cm, calib + calib_offset(d, B, d->n_blocks, 1), stream)) return rc;
+    if (int rc = asp_stats_impl(ctx, w.H, Cm, B, T, Cm, calib + calib_offset(d, B, d->n_blocks, 1), stream, f16)) return rc;
   if (fuse_ctx) {
     if (int rc = sdk_colstats_finish(ctx, w.stats, M, Cm, T, 2, w.ctx, stream)) return rc;
   } else {
-    if (int rc = sdk_asp_stats(ctx, w.H, Cm, B, T, Cm, w.ctx, stream)) return rc;
+    if (int rc = asp_stats_impl(ctx, w.H, Cm, B, T, Cm, w.ctx, stream, f16)) return rc;
   }
   if (int rc = sdk_rows_fc(ctx, w.ctx, 2 * Cm, nullptr, nullptr, P32(tb + EL_ASP_WMS_T), P32(tb + EL_ASP_B), w.ubias, A, B, 2 * Cm, A, 0, stream)) return rc;
   {
@@ -524,7 +524,7 @@ static int ecapa_forward_impl(sdk_ctx* ctx, const void* wblob, const sdk_ecapa_d
       g.A = w.AH; g.lda = A; g.W = P16(tb + EL_ASP_W2); g.C32 = w.logits; g.ldc32 = Cm; g.bias = P32(tb + EL_ASP_B2);
       g.M = M; g.N = Cm; g.Cin = A; g.taps = 1; g.dil = 1; g.T = T; g.flags = fmt;
       if (int rc = sdk_conv_gemm(ctx, &g, stream)) return rc;
-      if (int rc = sdk_asp_pool(ctx, w.logits, Cm, w.H, Cm, B, T, Cm, w.pooled, stream)) return rc;
+      if (int rc = asp_pool_impl(ctx, w.logits, Cm, w.H, Cm, B, T, Cm, w.pooled, stream, f16)) return rc;
     }
   }
   return sdk_rows_fc(ctx, w.pooled, 2 * Cm, P32(tb + EL_ASPBN_SCALE), P32(tb + EL_ASPBN_SHIFT), P32(tb + EL_FC_WT),
@@ -579,8 +579,7 @@ extern "C" int sdk_xvector_forward(sdk_ctx* ctx, const void* wblob, const sdk_xv
   SDK_REQUIRE(ctx && wblob && feats && ws && emb, "sdk_xvector_forward: null argument");
   if (int rc = check_xdesc(d)) return rc;
   const bool hp = d->off[62] == 1;
-  SDK_REQUIRE(ctx->precision == (hp ? 1 : 0), "sdk_xvector_forward: the weight blob was packed for precision %d, the context runs precision %d "
-              "(sdk_set_option \"precision\")", hp ? 1 : 0, ctx->precision);
+  // (the blob's precision decides, per call; the features must be in its format: bf16 for 0, fp16 hi | lo planes for 1)
   SDK_REQUIRE(B > 0 && T > 0 && (int64_t)B * T < (1ll << 31), "sdk_xvector_forward: bad batch (B=%d T=%d)", B, T);
   if (hp) SDK_REQUIRE(ldf % 16 == 0 && (ldf >> 1) >= d->n_feats && d->first_tap_pack == 0 && d->n_feats % 32 == 0,
                       "sdk_xvector_forward: precise mode reads fp16 planes [B*T, ldf] with the lo plane ldf/2 columns to the right: ldf=%d, n_feats=%d (a multiple of 32, no tap packing)", ldf, d->n_feats);
@@ -627,7 +626,7 @@ extern "C" int sdk_xvector_forward(sdk_ctx* ctx, const void* wblob, const sdk_xv
       in = out;
       ldin = d->cout[l];
     }
-    if (int rc = sdk_asp_stats(ctx, in, ldin, B, T, Cl, stats, stream)) return rc;
+    if (int rc = asp_stats_impl(ctx, in, ldin, B, T, Cl, stats, stream, false)) return rc;
   }
   return sdk_rows_fc(ctx, stats, 2 * Cl, nullptr, nullptr, (const float*)(wb + d->off[60]), (const float*)(wb + d->off[61]), emb, d->embed_dim, B, 2 * Cl,
                      d->embed_dim, 0, stream);

@@ -167,20 +167,18 @@ class LiteEngine:
 
     # ---------------------------------------------------------------- the path (device buffers in, device buffers out)
     def fbank(self, pcm_dev: DevBuf, B: int, S: int) -> DevBuf:
-        check(self.lib.sdk_set_option(self.ctx, b"precision", 0), "sdk_set_option")
         T = num_frames(S)
         feats = self._buf("feats", B * T * N_MELS_PADDED * 2)
         ws = self._buf("fbank_ws", self.lib.sdk_fbank_workspace_bytes(B, S))
-        check(self.lib.sdk_fbank(self.ctx, pcm_dev.ptr, B, S, self._tables().ptr, feats.ptr, N_MELS_PADDED, ws.ptr, ws.nbytes, None), "sdk_fbank")
+        check(self.lib.sdk_fbank_fmt(self.ctx, pcm_dev.ptr, B, S, self._tables().ptr, feats.ptr, N_MELS_PADDED, ws.ptr, ws.nbytes, 0, None), "sdk_fbank")   # this path serves the default contract
         return feats
 
     def fbank_windows(self, samples_ptr: int, n_samples: int, starts_ptr: int, B: int, S: int) -> DevBuf:
         """fbank with the windows cut on the device from a resident recording (sdk_fbank_windows; pointers from the ingest slots)."""
-        check(self.lib.sdk_set_option(self.ctx, b"precision", 0), "sdk_set_option")
         T = num_frames(S)
         feats = self._buf("feats", B * T * N_MELS_PADDED * 2)
         ws = self._buf("fbank_ws", self.lib.sdk_fbank_workspace_bytes(B, S))
-        check(self.lib.sdk_fbank_windows(self.ctx, samples_ptr, n_samples, starts_ptr, B, S, self._tables().ptr, feats.ptr, N_MELS_PADDED, ws.ptr, ws.nbytes, None),
+        check(self.lib.sdk_fbank_windows_fmt(self.ctx, samples_ptr, n_samples, starts_ptr, B, S, self._tables().ptr, feats.ptr, N_MELS_PADDED, ws.ptr, ws.nbytes, 0, None),
               "sdk_fbank_windows")
         return feats
 
@@ -239,7 +237,6 @@ class LiteEngine:
         return out
 
     def forward(self, feats: DevBuf, B: int, T: int) -> DevBuf:
-        check(self.lib.sdk_set_option(self.ctx, b"precision", 0), "sdk_set_option")      # this path serves the default contract only: never inherit the context's last setting
         emb = self._buf("emb", B * self.cfg.embed_dim * 4)
         if self._xv is not None:
             blob, d = self._xv

@@ -201,8 +201,7 @@ class Engine:
         count (the chip holds a ~5 % lower clock on fp16 products: profiles/r05_gemm_f16_probe.txt)."""
         if precision not in (0, 1, 2):
             raise SdkError(f"precision must be 0, 1 or 2, got {precision}")
-        self.set_option("precision", precision)
-        self.precision = precision
+        self.precision = precision          # (every call names its format: the library context holds no per-engine state)
         self._wblob = self._desc = None
         self._graphs.clear()
 
@@ -253,16 +252,10 @@ class Engine:
         return self.resample_s16(torch.from_numpy(np.ascontiguousarray(x)).to(self.device), rate_in, rate_out).cpu().numpy()
 
     # ------------------------------------------------------------------ k1
-    def _sync_precision(self) -> None:
-        """The library context is shared by every Engine of a device (one per process and GPU): make it agree with THIS engine's numerical
-        contract before a call whose format depends on it (a host-side store, no device work)."""
-        check(self.lib.sdk_set_option(self.ctx, b"precision", self.precision), "sdk_set_option")
-
     def fbank(self, pcm: torch.Tensor, ldf: Optional[int] = None) -> torch.Tensor:
         """pcm [B, S] int16 (device) -> feats [B*T, ldf] bf16 (channels >= 80 are zero); in precise mode fp16 planes
         [B*T, 2 x 96]: hi values in columns [0, 96), lo values (times 2^11) in [96, 192)."""
         _need(pcm, torch.int16, "pcm")
-        self._sync_precision()
         pcm = pcm.contiguous()
         B, S = pcm.shape
         T = num_frames(S)
@@ -271,21 +264,20 @@ class Engine:
         feats = torch.empty((B * T, ldf), dtype=torch.bfloat16 if self.precision == 0 else torch.float16, device=self.device)
         wsb = self.lib.sdk_fbank_workspace_bytes(B, S)
         ws = self._scratch_bytes("fbank", wsb)
-        check(self.lib.sdk_fbank(self.ctx, pcm.data_ptr(), B, S, self.fbank_tables().data_ptr(), feats.data_ptr(), ldf,
-                                 ws.data_ptr(), ws.numel(), _stream()), "sdk_fbank")
+        check(self.lib.sdk_fbank_fmt(self.ctx, pcm.data_ptr(), B, S, self.fbank_tables().data_ptr(), feats.data_ptr(), ldf,
+                                     ws.data_ptr(), ws.numel(), self.precision, _stream()), "sdk_fbank")
         return feats
 
     def fbank_windows(self, samples_ptr: int, n_samples: int, starts_ptr: int, B: int, S: int, ldf: Optional[int] = None) -> torch.Tensor:
         """fbank with the windows cut on the device (sdk_fbank_windows): samples_ptr -> int16 [n_samples] resident recording, starts_ptr -> int32 [B]
         first samples; same features as fbank() on the materialised [B, S] windows, bit for bit."""
-        self._sync_precision()
         T = num_frames(S)
         if ldf is None:
             ldf = 2 * N_MELS_PADDED_HP if self.precision == 1 else N_MELS_PADDED
         feats = torch.empty((B * T, ldf), dtype=torch.bfloat16 if self.precision == 0 else torch.float16, device=self.device)
         ws = self._scratch_bytes("fbank", self.lib.sdk_fbank_workspace_bytes(B, S))
-        check(self.lib.sdk_fbank_windows(self.ctx, samples_ptr, n_samples, starts_ptr, B, S, self.fbank_tables().data_ptr(), feats.data_ptr(), ldf,
-                                         ws.data_ptr(), ws.numel(), _stream()), "sdk_fbank_windows")
+        check(self.lib.sdk_fbank_windows_fmt(self.ctx, samples_ptr, n_samples, starts_ptr, B, S, self.fbank_tables().data_ptr(), feats.data_ptr(), ldf,
+                                             ws.data_ptr(), ws.numel(), self.precision, _stream()), "sdk_fbank_windows")
         return feats
 
     def ingest(self):
@@ -345,7 +337,6 @@ class Engine:
     def ecapa_forward(self, feats: torch.Tensor, B: int, T: int) -> torch.Tensor:
         """feats [B*T, ldf] bf16 (precise mode: fp16 planes) -> raw embeddings [B, 192] fp32."""
         _need(feats, torch.bfloat16 if self.precision == 0 else torch.float16, "feats")
-        self._sync_precision()
         if feats.shape[0] != B * T or feats.stride(1) != 1:
             raise SdkError(f"feats must be [B*T={B * T}, ldf] row-major, got {tuple(feats.shape)}")
         d = self.desc

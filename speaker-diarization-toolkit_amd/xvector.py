@@ -236,7 +236,6 @@ class XVector:
         from ._lib import check
         from .ops import _stream
         lib = self.eng.lib
-        check(lib.sdk_set_option(self.eng.ctx, b"precision", self.precision), "sdk_set_option")
         ws = self.eng._scratch_bytes("xvector", lib.sdk_xvector_workspace_bytes(C.byref(self.desc), B, T))
         emb = torch.empty((B, self.cfg.embed_dim), dtype=torch.float32, device=self.eng.device)
         check(lib.sdk_xvector_forward(self.eng.ctx, self.blob.data_ptr(), C.byref(self.desc), feats.data_ptr(), feats.stride(0), B, T,

@@ -26,7 +26,7 @@ def test_library_exports_every_declared_symbol():
     for n in names:
         assert hasattr(lib, n), f"{n} declared in include/sdk_hip.h but not exported by libsdk_hip.so"
     assert sorted(LIB.SIGNATURES) == names, "host binding (_lib.SIGNATURES) out of sync with the header"
-    assert lib.sdk_abi_version() == 3
+    assert lib.sdk_abi_version() == 4
 
 
 def test_struct_layouts_match_header():

@@ -217,7 +217,7 @@ def test_backend_in_precise_mode_end_to_end(tmp_path, monkeypatch):
     cand = [{"id": "a", "embeddings": {"mi355x": [{"id": "emb-a", "external_id": rec["external_id"], "model_version": rec["model_version"]}]}}]
     rows1 = be1.identify_speaker(tmp_path / "a.wav", cand)
     assert be1.engine().precision == 1 and rows1 and rows1[0]["speaker_id"] == "a" and rows1[0]["similarity"] > 0.95
-    # (every Backend owns its Engine; the library context they share is re-synchronised per call: ops.Engine._sync_precision)
+    # (every Backend owns its Engine; each call names its format - sdk_fbank_fmt, the blob descriptor - so the shared library context holds no per-engine state)
     monkeypatch.setenv("SDK_PRECISION", "0")
     be0 = B.Backend()
     assert be0.model_version == be1.model_version

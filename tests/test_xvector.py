@@ -100,18 +100,23 @@ def test_xvector_pcm_to_assignment(engine):
     torch.cuda.synchronize()
     oidx, osc = oscoring.affinity_topk(E.cpu().numpy(), Pn.cpu().numpy(), 1)
     assert np.array_equal(idx.cpu().numpy(), oidx) and np.abs(sc.cpu().numpy() - osc).max() <= 1e-5
-    # a blob packed for one numerical contract is refused by a context running the other (the library call itself: XVector.forward always
-    # makes the context agree with its blob first)
+    # the numerical contract is the BLOB's, per call (round 5): the context's "precision" option - mutable state shared by
+    # every engine of a device - plays no part in the forward, so another engine (or thread) that set it cannot change this one's results
     L = sub("_lib")
-    ws = torch.empty(engine.lib.sdk_xvector_workspace_bytes(C.byref(xv.desc), 1, 201), dtype=torch.uint8, device="cuda")
-    out = torch.empty(1, 192, device="cuda")
-    engine.set_option("precision", 1)
-    try:
-        with pytest.raises(L.SdkError, match="packed for precision 0"):
-            L.check(engine.lib.sdk_xvector_forward(engine.ctx, xv.blob.data_ptr(), C.byref(xv.desc), torch.zeros(201, 192, dtype=torch.float16, device="cuda").data_ptr(),
-                                                   192, 1, 201, ws.data_ptr(), ws.numel(), out.data_ptr(), None), "sdk_xvector_forward")
-    finally:
-        engine.set_option("precision", 0)
+    ws = torch.empty(engine.lib.sdk_xvector_workspace_bytes(C.byref(xv.desc), 2, 201), dtype=torch.uint8, device="cuda")
+    feats = engine.fbank(pcm[:2].contiguous())
+    outs = []
+    for opt in (0, 1):
+        engine.set_option("precision", opt)
+        try:
+            out = torch.empty(2, 192, device="cuda")
+            L.check(engine.lib.sdk_xvector_forward(engine.ctx, xv.blob.data_ptr(), C.byref(xv.desc), feats.data_ptr(), feats.stride(0), 2, 201, ws.data_ptr(), ws.numel(),
+                                                   out.data_ptr(), None), "sdk_xvector_forward")
+            torch.cuda.synchronize()
+            outs.append(out)
+        finally:
+            engine.set_option("precision", 0)
+    assert torch.equal(outs[0], outs[1])
 
 
 def test_backend_model_selection_metadata(monkeypatch):
