@@ -532,13 +532,16 @@ def main() -> int:
         for label, rows in (("bench_shard", B), ("config4_shard", 125_000)):
             src = torch.empty((rows, 192), dtype=torch.float32, device=dev).normal_()
             dst = torch.empty((world * rows, 192), dtype=torch.float32, device=dev)
-            ms = timed(lambda: sdist._gather_into(dst, src), 10)
+            ms = timed(lambda: sdist._gather_into(dst, src, mode="auto"), 10)
+            ms_direct = timed(lambda: sdist._gather_into(dst, src, mode="direct"), 10)     # the same exchange as world - 1 pairwise transfers (dist._gather_direct)
             recv = (world - 1) * rows * 192 * 4
             exchange[label] = {"rows_per_rank": rows, "ms": round(ms, 4), "bytes_received_per_rank": recv,
-                               "recv_GBps_per_rank": round(recv / (ms * 1e-3) / 1e9, 1)}
+                               "recv_GBps_per_rank": round(recv / (ms * 1e-3) / 1e9, 1),
+                               "ms_direct_pairwise": round(ms_direct, 4), "recv_GBps_per_rank_direct": round(recv / (ms_direct * 1e-3) / 1e9, 1)}
             del src, dst
-        exchange["note"] = ("torch.distributed all_gather_into_tensor (backend nccl = RCCL over xGMI); xGMI is point to point, 7 links x ~153 GB/s "
-                            "per GPU: direct-exchange floor for the config #4 shard at 8 GPUs = 672 MB / 1071 GB/s = 0.63 ms")
+        exchange["note"] = ("ms: torch.distributed all_gather_into_tensor (backend nccl = RCCL over xGMI, RCCL's own algorithm); ms_direct_pairwise: the same exchange as "
+                            "world - 1 send / receive pairs in one batch (SDK_ALLGATHER=direct); xGMI is point to point, 7 links x ~153 GB/s per GPU: direct-exchange "
+                            "floor for the config #4 shard at 8 GPUs = 672 MB / 1071 GB/s = 0.63 ms, a ring 4.4 ms; the step itself uses $SDK_ALLGATHER (default auto)")
 
         # config #4: 125 000 segments per GPU (1 M at 8) vs 10 000 replicated profiles: affinity + argmax per shard, no data-path
         # collective (profiles are replicated), then the all-gather of the real 96 MB embedding shard for the clustering stage

@@ -419,6 +419,9 @@ int sdk_affinity_matvec(sdk_ctx* ctx, const uint16_t* Eb, int N, int d, int row0
  *   sdk_allgather       : ONE RCCL all-gather of equal shards (bytes_per_rank each) on the caller's communicator (an ncclComm_t passed as
  *                         void*) and stream: the [N/G, 192] embedding exchange over xGMI.  RCCL is resolved at first use (the copy already in
  *                         the process, else librccl.so.1); the library does not link it.
+ *   sdk_allgather_direct: the same exchange as world - 1 PAIRWISE ncclSend / ncclRecv transfers in one RCCL group: on fully connected point-to-point
+ *                         xGMI (7 links per GPU) every transfer takes its pair's direct link and all run at once (floor 0.63 ms for 8 x 96 MB),
+ *                         whatever algorithm ncclAllGather itself would choose for the size (a ring: 4.4 ms).  Same bytes in `out`.
  *   sdk_laplacian_topk  : top-k eigenpairs of S = D^-1/2 A D^-1/2, A = max(E E^T, 0), by row-sharded subspace iteration (the loop of
  *                         cluster.spectral_cluster: degrees, CholeskyQR2, n_iter x [V all-gather, recomputed-affinity mat-vec, scaling,
  *                         CholeskyQR2], Ritz with a device-side k x k Jacobi eigh): never synchronises with the host.
@@ -428,6 +431,7 @@ int sdk_affinity_matvec(sdk_ctx* ctx, const uint16_t* Eb, int N, int d, int row0
  *                         comm NULL: single GPU (rows == N).  comm != NULL: every rank owns N / world rows (equal shards) and calls with the
  *                         same arguments; collectives: all-gather of D^-1/2 and of V per iteration, all-reduce of the k x k Gram matrices. */
 int sdk_allgather(sdk_ctx* ctx, const void* shard, void* out, size_t bytes_per_rank, void* comm, void* stream);
+int sdk_allgather_direct(sdk_ctx* ctx, const void* shard, void* out, size_t bytes_per_rank, void* comm, void* stream);
 size_t sdk_laplacian_topk_workspace_bytes(int N, int k);
 int sdk_laplacian_topk(sdk_ctx* ctx, const uint16_t* Eb_all, int N, int row0, int rows, int k, int n_iter, float* V, float* eigvals,
                        int32_t* not_spd, void* ws, size_t ws_bytes, void* comm, int world, void* stream);

@@ -136,6 +136,7 @@ SIGNATURES = {
     "sdk_affinity_matvec_plan": (_i, [_i, _i, _i, _vp, _vp]),
     "sdk_affinity_matvec": (_i, [_vp, _vp, _i, _i, _i, _i, _vp, _vp, _i, _vp, _vp, _sz, _vp]),
     "sdk_allgather": (_i, [_vp, _vp, _vp, _sz, _vp, _vp]),
+    "sdk_allgather_direct": (_i, [_vp, _vp, _vp, _sz, _vp, _vp]),
     "sdk_laplacian_topk_workspace_bytes": (_sz, [_i, _i]),
     "sdk_laplacian_topk": (_i, [_vp, _vp, _i, _i, _i, _i, _i, _vp, _vp, _vp, _vp, _sz, _vp, _i, _vp]),
     "sdk_rows_gram_workspace_bytes": (_sz, [_i, _i]),

@@ -16,12 +16,18 @@ namespace {
 
 typedef int (*nccl_allgather_t)(const void*, void*, size_t, int, void*, hipStream_t);
 typedef int (*nccl_allreduce_t)(const void*, void*, size_t, int, int, void*, hipStream_t);
+typedef int (*nccl_sendrecv_t)(const void*, size_t, int, int, void*, hipStream_t);      // ncclSend (const buffer) / ncclRecv (same shape, buffer written)
+typedef int (*nccl_group_t)(void);
+typedef int (*nccl_count_t)(void*, int*);
 typedef const char* (*nccl_errstr_t)(int);
 constexpr int NCCL_CHAR = 0, NCCL_FLOAT32 = 7, NCCL_SUM = 0;
 
 struct Rccl {
   nccl_allgather_t all_gather = nullptr;
   nccl_allreduce_t all_reduce = nullptr;
+  nccl_sendrecv_t send = nullptr, recv = nullptr;
+  nccl_group_t group_start = nullptr, group_end = nullptr;
+  nccl_count_t comm_count = nullptr, comm_rank = nullptr;
   nccl_errstr_t errstr = nullptr;
   bool tried = false;
 };
@@ -39,6 +45,12 @@ int rccl_resolve() {
     if (h) {
       g_rccl.all_gather = (nccl_allgather_t)dlsym(h, "ncclAllGather");
       g_rccl.all_reduce = (nccl_allreduce_t)dlsym(h, "ncclAllReduce");
+      g_rccl.send = (nccl_sendrecv_t)dlsym(h, "ncclSend");
+      g_rccl.recv = (nccl_sendrecv_t)dlsym(h, "ncclRecv");
+      g_rccl.group_start = (nccl_group_t)dlsym(h, "ncclGroupStart");
+      g_rccl.group_end = (nccl_group_t)dlsym(h, "ncclGroupEnd");
+      g_rccl.comm_count = (nccl_count_t)dlsym(h, "ncclCommCount");
+      g_rccl.comm_rank = (nccl_count_t)dlsym(h, "ncclCommUserRank");
       g_rccl.errstr = (nccl_errstr_t)dlsym(h, "ncclGetErrorString");
     }
   }
@@ -177,6 +189,41 @@ extern "C" int sdk_allgather(sdk_ctx* ctx, const void* shard, void* out, size_t 
   SDK_REQUIRE(bytes_per_rank > 0, "sdk_allgather: empty shard");
   if (rccl_resolve()) return 1;
   SDK_NCCL_OK(g_rccl.all_gather(shard, out, bytes_per_rank, NCCL_CHAR, comm, (hipStream_t)stream));
+  return 0;
+}
+
+// The same exchange as world - 1 PAIRWISE transfers in one RCCL group (every rank sends its shard to every peer and receives every peer's):
+// on a node whose GPUs are fully connected by point-to-point xGMI links (MI355X: 7 links x ~153 GB/s per GPU) each transfer takes the direct link
+// of its pair and all seven run at once - the form SURVEY.md 5 / 8(e) asks for (floor 0.63 ms for 8 x 96-MB shards), whatever algorithm the
+// library's own ncclAllGather would pick for the message size (a ring over the same links is 7 hops of one link each: 4.4 ms).  Same result as
+// sdk_allgather, byte for byte.  Unmeasured on a multi-GPU node (none has been available to this build): bench.py --gpus N times both forms.
+extern "C" int sdk_allgather_direct(sdk_ctx* ctx, const void* shard, void* out, size_t bytes_per_rank, void* comm, void* stream) {
+  SDK_REQUIRE(ctx && shard && out && comm, "sdk_allgather_direct: null argument (comm is the caller's ncclComm_t)");
+  SDK_REQUIRE(bytes_per_rank > 0, "sdk_allgather_direct: empty shard");
+  if (rccl_resolve()) return 1;
+  SDK_REQUIRE(g_rccl.send && g_rccl.recv && g_rccl.group_start && g_rccl.group_end && g_rccl.comm_count && g_rccl.comm_rank,
+              "sdk_allgather_direct: this RCCL has no ncclSend / ncclRecv / ncclGroup* / ncclCommCount / ncclCommUserRank");
+  int world = 0, rank = -1;
+  SDK_NCCL_OK(g_rccl.comm_count(comm, &world));
+  SDK_NCCL_OK(g_rccl.comm_rank(comm, &rank));
+  SDK_REQUIRE(world >= 1 && rank >= 0 && rank < world, "sdk_allgather_direct: communicator reports rank %d of %d", rank, world);
+  hipStream_t s = (hipStream_t)stream;
+  char* o = (char*)out;
+  if ((const char*)shard != o + (size_t)rank * bytes_per_rank)
+    SDK_HIP_OK(hipMemcpyAsync(o + (size_t)rank * bytes_per_rank, shard, bytes_per_rank, hipMemcpyDeviceToDevice, s));
+  if (world == 1) return 0;
+  SDK_NCCL_OK(g_rccl.group_start());
+  int rc = 0;
+  for (int d = 1; d < world && !rc; ++d) {                   // peer at distance d: every pair (i, i + d) is scheduled by both ends in the same group
+    const int to = (rank + d) % world, from = (rank - d + world) % world;
+    rc = g_rccl.send(shard, bytes_per_rank, NCCL_CHAR, to, comm, s);
+    if (!rc) rc = g_rccl.recv(o + (size_t)from * bytes_per_rank, bytes_per_rank, NCCL_CHAR, from, comm, s);
+  }
+  const int rc_end = g_rccl.group_end();
+  if (rc || rc_end) {
+    sdk_set_error("sdk_allgather_direct: RCCL error %d (%s)", rc ? rc : rc_end, g_rccl.errstr ? g_rccl.errstr(rc ? rc : rc_end) : "?");
+    return 1;
+  }
   return 0;
 }
 

@@ -35,6 +35,16 @@ def _worker(rank, world, port, n_total, out_dir):
     lo1, hi1 = D.shard_range(1)                       # rank 0 owns the only row, rank 1 an empty shard
     g2 = D.all_gather_rows(full[lo1:hi1].clone(), 1)
     ok = ok and torch.equal(g2, full[:1])
+    # the pairwise form of the exchange ($SDK_ALLGATHER=direct: world - 1 send / receive pairs in one batch) gathers the same bytes
+    os.environ["SDK_ALLGATHER"] = "direct"
+    ok = ok and D.allgather_mode() == "direct" and torch.equal(D.all_gather_rows(full[lo:hi].clone(), n_total), full)
+    ok = ok and torch.equal(D.all_gather_rows(full[lo1:hi1].clone(), 1), full[:1])
+    os.environ["SDK_ALLGATHER"] = "auto"
+    w = max(h - l for l, h in D.shard_bounds(n_total, world))
+    pad = torch.zeros(w, 192); pad[:hi - lo] = full[lo:hi]
+    a, b = torch.empty(world * w, 192), torch.empty(world * w, 192)
+    D._gather_into(a, pad, mode="auto"); D._gather_into(b, pad, mode="direct")
+    ok = ok and torch.equal(a, b)
     open(os.path.join(out_dir, f"rank{rank}.ok" if ok else f"rank{rank}.bad"), "w").close()
     dist.destroy_process_group()
 
@@ -51,13 +61,13 @@ def test_shard_bounds_cover_rows_exactly():
     assert D.shard_bounds(1_000_000, 8)[3] == (375_000, 500_000)     # config #4: 125k segments per GPU
 
 
-def test_all_gather_rows_world2_gloo(tmp_path):
-    world = 2
+@pytest.mark.parametrize("world", [2, 3])
+def test_all_gather_rows_world2_gloo(tmp_path, world):
     for n_total in (11, 64):
         d = tmp_path / f"n{n_total}"
         d.mkdir()
         mp.spawn(_worker, args=(world, _free_port(), n_total, str(d)), nprocs=world, join=True)
-        assert sorted(os.listdir(d)) == ["rank0.ok", "rank1.ok"]
+        assert sorted(os.listdir(d)) == [f"rank{r}.ok" for r in range(world)]
 
 
 def _cluster_worker(rank, world, port, out_dir):

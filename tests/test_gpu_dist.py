@@ -170,6 +170,10 @@ def _c_abi_rccl_worker(rank, world, port, out_dir):
     torch.cuda.synchronize()
     rep["allgather_equal"] = bool(torch.equal(out, x))
     rep["allgather_null_comm_refused"] = eng.lib.sdk_allgather(eng.ctx, x.data_ptr(), out.data_ptr(), x.numel() * 4, None, st) != 0
+    out2 = torch.zeros_like(x)                                     # the pairwise form (one rank: its own shard lands in its slot; the send / receive
+    _lib.check(eng.lib.sdk_allgather_direct(eng.ctx, x.data_ptr(), out2.data_ptr(), x.numel() * 4, comm, st), "sdk_allgather_direct")   # loop needs peers:
+    torch.cuda.synchronize()                                       # multi-rank behaviour is covered by the gloo tests of dist._gather_direct only)
+    rep["allgather_direct_equal"] = bool(torch.equal(out2, x))
     N, k = 1536, 5
     E, _ = ospec.vmf_mixture(N, 192, k, seed=4, noise=0.6)
     _, Eb, _ = eng.l2norm(torch.from_numpy(E).cuda())
@@ -192,5 +196,5 @@ def test_c_abi_collectives_on_a_raw_rccl_communicator(tmp_path):
     mp.spawn(_c_abi_rccl_worker, args=(1, _free_port(), str(tmp_path)), nprocs=1, join=True)
     rep = json.loads((tmp_path / "cabi.json").read_text())
     print("\nC-ABI collectives on a raw RCCL communicator:", rep)
-    assert rep["allgather_equal"] and rep["allgather_null_comm_refused"] and rep["laplacian_equal"]
+    assert rep["allgather_equal"] and rep["allgather_direct_equal"] and rep["allgather_null_comm_refused"] and rep["laplacian_equal"]
     assert rep["eigs"][0] > 0.99 and all(a >= b for a, b in zip(rep["eigs"], rep["eigs"][1:]))
