@@ -13,6 +13,8 @@
 // Range: |x| <= 65504 (fp16), saturating - activations behind BatchNorm / log-mel features are O(10).
 #include <stdlib.h>
 
+#include <type_traits>
+
 #include "common.hpp"
 #include "ecapa_layout.h"
 #include "hp.hpp"
@@ -47,6 +49,7 @@ struct HpParams {
   uint16_t* S; int64_t lds, s_lo;
   int M, N, Cin, taps, dil, T;
   uint32_t flags;
+  int half_tail;                     // 256^2 kernel: compute a mostly idle last round as half tiles (default 1; hp_gemm_variant 2 = off)
 };
 
 __device__ __forceinline__ int swz(int row) { return (-(row >> 2)) & 3; }
@@ -263,7 +266,13 @@ __global__ __launch_bounds__(NT2, 2) void conv_gemm_hp256_kernel(HpParams p) {
   const int nch = nbn >> 2, mg_full = nbm >> 3;
   const int full_units = mg_full * nch, R = full_units >> 3, rem_units = full_units - 8 * R;
   const int gm_tail = nbm & 7, tail_tiles = gm_tail * nbn;
-  const int nrounds = unit_order ? R + (rem_units + (tail_tiles + 31) / 32 + 7) / 8 : (ntiles + G - 1) / G;
+  // HALF-TILE TAIL as in conv_gemm256_kernel (round 5): where the whole rounds leave a mostly idle last round (the K = 1024 layers: 12 x 256 + 72 tiles)
+  // the left-over bottom rows are computed as 128 x 256 half tiles, at most one per workgroup - same K order per element, results bit-identical;
+  // hp_gemm_variant 2 switches it off (A/B, tests)
+  const int mt0 = unit_order && (8 * R) % nch == 0 ? ((8 * R) / nch) * 8 : 0;
+  const int n_half_m = 2 * (nbm - mt0), half_cap = 32 / nbn;
+  const bool half_tail = unit_order && p.half_tail && (8 * R) % nch == 0 && R > 0 && mt0 < nbm && n_half_m <= 8 * half_cap;
+  const int nrounds = unit_order ? (half_tail ? R : R + (rem_units + (tail_tiles + 31) / 32 + 7) / 8) : (ntiles + G - 1) / G;
   auto tile_coords = [&](int i, int& tm0, int& tn0) -> bool {
     if (unit_order) {
       int u;
@@ -314,29 +323,31 @@ __global__ __launch_bounds__(NT2, 2) void conv_gemm_hp256_kernel(HpParams p) {
   int aseg0 = 0, atl0 = 0;
   uint32_t woff;
   const size_t astride = (size_t)8 * (size_t)p.lda * 2u;
-  auto setup_dma = [&](int tm0, int tn0) {
-    const int row = 32 * wu + rin;
+  auto setup_dma = [&](int tm0, int tn0, auto ap_c) {
+    constexpr int AP = decltype(ap_c)::value;                             // A pieces per wave: 4 (whole tile: rows [32 w, 32 w + 32)) or 2 (half tile: rows [16 w, 16 w + 16))
+    const int row = 8 * AP * wu + rin;
     if constexpr (TAPS) {
       const int mm = min(tm0 + row, p.M - 1);
       aseg0 = (mm / p.T) * p.T;
       atl0 = mm - aseg0;
     } else {
       arow0 = tm0 + row;
-      interior = tm0 + BM2 <= p.M;
+      interior = tm0 + 32 * AP <= p.M;
       aoff0 = ((uint32_t)min(arow0, p.M - 1) * (uint32_t)p.lda + kch + a_pl) * 2u;
     }
-    woff = ((uint32_t)(tn0 + row) * (uint32_t)Ktot + kch + w_pl) * 2u;
+    woff = ((uint32_t)(tn0 + 32 * wu + rin) * (uint32_t)Ktot + kch + w_pl) * 2u;
   };
-  auto issue = [&](int t, int stage) {
+  auto issue = [&](int t, int stage, auto ap_c) {
+    constexpr int AP = decltype(ap_c)::value;
     const int j = t / ksteps_per_tap;
     const int kc = (t - j * ksteps_per_tap) * BK;
-    char* sA = smem + stage * HSTAGE + (32 * wu) * 128;
-    char* sB = sA + BM2 * 128;
+    char* sA = smem + stage * HSTAGE + (8 * AP * wu) * 128;
+    char* sB = smem + stage * HSTAGE + BM2 * 128 + (32 * wu) * 128;
     const char* abase = reinterpret_cast<const char*>(p.A + kc);
     if constexpr (TAPS) {
       const int off = (j - half) * p.dil;
 #pragma unroll
-      for (int i = 0; i < 4; ++i) {
+      for (int i = 0; i < AP; ++i) {
         int tl = atl0 + 8 * i, sb = aseg0;
         if (tl >= p.T) { tl -= p.T; sb += p.T; }
         const uint32_t src = (uint32_t)min(sb + reflect_idx(tl + off, p.T), p.M - 1);
@@ -344,11 +355,11 @@ __global__ __launch_bounds__(NT2, 2) void conv_gemm_hp256_kernel(HpParams p) {
       }
     } else if (interior) {
 #pragma unroll
-      for (int i = 0; i < 4; ++i)
+      for (int i = 0; i < AP; ++i)
         __builtin_amdgcn_global_load_lds((gptr_t)(abase + i * astride + (size_t)aoff0), (lptr_t)(sA + i * 1024), 16, 0, 0);
     } else {
 #pragma unroll
-      for (int i = 0; i < 4; ++i) {
+      for (int i = 0; i < AP; ++i) {
         const uint32_t o = ((uint32_t)min(arow0 + 8 * i, p.M - 1) * (uint32_t)p.lda + kch + a_pl) * 2u;
         __builtin_amdgcn_global_load_lds((gptr_t)(abase + (size_t)o), (lptr_t)(sA + i * 1024), 16, 0, 0);
       }
@@ -367,11 +378,17 @@ __global__ __launch_bounds__(NT2, 2) void conv_gemm_hp256_kernel(HpParams p) {
   const bool relu = p.flags & SDK_GEMM_RELU;
   const float winv = *p.winv;
   float* par = reinterpret_cast<float*>(smem + HLDS);
+  constexpr std::integral_constant<int, 4> kWhole{};
+  constexpr std::integral_constant<int, 2> kHalf{};
+  auto ldB = [&](const char* st, f16x8* dst, uint32_t coff) {
+#pragma unroll
+    for (int ni = 0; ni < 4; ++ni) dst[ni] = *reinterpret_cast<const f16x8*>(st + b_base + ni * 2048 + coff);
+  };
 
   for (int rnd = 0; rnd < nrounds; ++rnd) {
     int m0, n0;
     if (!tile_coords(rnd, m0, n0)) continue;
-    setup_dma(m0, n0);
+    setup_dma(m0, n0, kWhole);
     float pb = 0.f, psc = 1.f, psh = 0.f;
     if (tid < BN2) {
       if (p.bias) pb = p.bias[n0 + tid];
@@ -384,10 +401,6 @@ __global__ __launch_bounds__(NT2, 2) void conv_gemm_hp256_kernel(HpParams p) {
       for (int ni = 0; ni < 4; ++ni) acc[mi][ni] = f32x4{0.f, 0.f, 0.f, 0.f};
 
     f16x8 b0[4], b1[4], a0[4], a1[4];
-    auto ldB = [&](const char* st, f16x8* dst, uint32_t coff) {
-#pragma unroll
-      for (int ni = 0; ni < 4; ++ni) dst[ni] = *reinterpret_cast<const f16x8*>(st + b_base + ni * 2048 + coff);
-    };
     auto ldA = [&](const char* st, f16x8* dst, int mh, uint32_t coff) {
 #pragma unroll
       for (int mi = 0; mi < 4; ++mi) dst[mi] = *reinterpret_cast<const f16x8*>(st + a_base + (mh * 4 + mi) * 2048 + coff);
@@ -403,9 +416,9 @@ __global__ __launch_bounds__(NT2, 2) void conv_gemm_hp256_kernel(HpParams p) {
       __builtin_amdgcn_s_setprio(0);
     };
 
-    issue(0, 0);
+    issue(0, 0, kWhole);
     if (nk > 1) {
-      issue(1, 1);
+      issue(1, 1, kWhole);
       asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
     } else {
       asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
@@ -454,7 +467,7 @@ __global__ __launch_bounds__(NT2, 2) void conv_gemm_hp256_kernel(HpParams p) {
       if (t + 1 < nk) {
         asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");     // own reads of this stage done, own DMA of step t + 1 landed
         __builtin_amdgcn_s_barrier();
-        if (dma_early && t + 2 < nk) issue(t + 2, t & 1);
+        if (dma_early && t + 2 < nk) issue(t + 2, t & 1, kWhole);
         const char* sn = smem + ((t + 1) & 1) * HSTAGE;
         ldB(sn, b0, c0);
         ldA(sn, a0, 0, c0);
@@ -463,7 +476,7 @@ __global__ __launch_bounds__(NT2, 2) void conv_gemm_hp256_kernel(HpParams p) {
       mma_half(a1, b1, 1, 0);                           // P5: Ah[1] . Wl
       mma_half(a1, b1, 1, 1);
       __builtin_amdgcn_sched_barrier(0);
-      if (!dma_early && t + 2 < nk) issue(t + 2, t & 1);
+      if (!dma_early && t + 2 < nk) issue(t + 2, t & 1, kWhole);
     }
 
     // ------------------------------------------------------------------ epilogue: fp32 in the accumulators, hi plane then lo plane through the image
@@ -528,6 +541,145 @@ __global__ __launch_bounds__(NT2, 2) void conv_gemm_hp256_kernel(HpParams p) {
       }
     }
     lds_barrier();                                      // the image is free: the next tile's DMA may overwrite it
+  }
+
+  // ------------------------------------------------------------------ half-tile tail: at most one 128 x 256 tile per workgroup (XCD x takes half row
+  // blocks x, x + 8, ...: the nbn column tiles of a block share its A rows in one L2)
+  if (half_tail && slot / nbn < half_cap && (slot / nbn) * 8 + xcd < n_half_m) {
+    const int hq = slot / nbn;
+    const int m0 = mt0 * BM2 + (hq * 8 + xcd) * 128, n0 = (slot - hq * nbn) * BN2;
+    if (m0 < p.M) {
+      setup_dma(m0, n0, kHalf);
+      float pb = 0.f, psc = 1.f, psh = 0.f;
+      if (tid < BN2) {
+        if (p.bias) pb = p.bias[n0 + tid];
+        if (p.scale) { psc = p.scale[n0 + tid]; psh = p.shift[n0 + tid]; }
+      }
+      f32x4 acc[4][4];
+#pragma unroll
+      for (int mi = 0; mi < 4; ++mi)
+#pragma unroll
+        for (int ni = 0; ni < 4; ++ni) acc[mi][ni] = f32x4{0.f, 0.f, 0.f, 0.f};
+      f16x8 b0[4], b1[4], a0[4], a1[4];
+      const uint32_t a_base_h = (wm * 64 + fr) * 128;          // waves 2 (M) x 4 (N), 64 x 64 each
+      auto ldAh = [&](const char* st, f16x8* dst, uint32_t coff) {
+#pragma unroll
+        for (int mi = 0; mi < 4; ++mi) dst[mi] = *reinterpret_cast<const f16x8*>(st + a_base_h + mi * 2048 + coff);
+      };
+      auto mma_h = [&](const f16x8* af, const f16x8* bf, int part) {
+        __builtin_amdgcn_s_setprio(1);
+#pragma unroll
+        for (int mi = 2 * part; mi < 2 * part + 2; ++mi)
+#pragma unroll
+          for (int ni = 0; ni < 4; ++ni)
+            acc[mi][ni] = __builtin_amdgcn_mfma_f32_16x16x32_f16(bf[ni], af[mi], acc[mi][ni], 0, 0, 0);
+        __builtin_amdgcn_s_setprio(0);
+      };
+      issue(0, 0, kHalf);
+      if (nk > 1) {
+        issue(1, 1, kHalf);
+        asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
+      } else {
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      }
+      if (tid < BN2) { par[tid] = pb; par[BN2 + tid] = psc; par[2 * BN2 + tid] = psh; }
+      __builtin_amdgcn_s_barrier();
+      ldB(smem, b0, c0);
+      ldAh(smem, a0, c0);
+      for (int t = 0; t < nk; ++t) {                       // the whole tile's three product terms, one row half: Ah.Wh, Al.(Wh 2^-11), Ah.Wl
+        const char* st = smem + (t & 1) * HSTAGE;
+        __builtin_amdgcn_sched_barrier(0);
+        mma_h(a0, b0, 0);                                 // Ah . Wh
+        __builtin_amdgcn_sched_barrier(0);
+        ldB(st, b1, c1);
+        ldAh(st, a1, c1);
+        __builtin_amdgcn_sched_barrier(0);
+        mma_h(a0, b0, 1);
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int ni = 0; ni < 4; ++ni) b0[ni] = b0[ni] * (_Float16)(1.0f / HP_LOSCALE);     // Wh -> Wh 2^-11 in place (exact)
+        __builtin_amdgcn_sched_barrier(0);
+        mma_h(a1, b0, 0);                                 // Al . Wh 2^-11
+        mma_h(a1, b0, 1);
+        __builtin_amdgcn_sched_barrier(0);
+        mma_h(a0, b1, 0);                                 // Ah . Wl
+        __builtin_amdgcn_sched_barrier(0);
+        if (t + 1 < nk) {
+          asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+          __builtin_amdgcn_s_barrier();
+          if (dma_early && t + 2 < nk) issue(t + 2, t & 1, kHalf);
+        }
+        __builtin_amdgcn_sched_barrier(0);
+        mma_h(a0, b1, 1);                                 // (a0 = Ah of THIS step: still needed; the next step's fragments are read after it)
+        __builtin_amdgcn_sched_barrier(0);
+        if (t + 1 < nk) {
+          const char* sn = smem + ((t + 1) & 1) * HSTAGE;
+          ldB(sn, b0, c0);
+          ldAh(sn, a0, c0);
+        }
+        if (!dma_early && t + 2 < nk) issue(t + 2, t & 1, kHalf);
+      }
+      f32x4 qb[4], qs[4], qt[4];
+#pragma unroll
+      for (int ni = 0; ni < 4; ++ni) {
+        const int c = wn * 64 + ni * 16 + fq * 4;
+        qb[ni] = *reinterpret_cast<const f32x4*>(par + c);
+        qs[ni] = *reinterpret_cast<const f32x4*>(par + BN2 + c);
+        qt[ni] = *reinterpret_cast<const f32x4*>(par + 2 * BN2 + c);
+      }
+#pragma unroll
+      for (int mi = 0; mi < 4; ++mi)
+#pragma unroll
+        for (int ni = 0; ni < 4; ++ni) {
+          f32x4 v = acc[mi][ni] * winv + qb[ni];
+          if (relu) {
+#pragma unroll
+            for (int e = 0; e < 4; ++e) v[e] = fmaxf(v[e], 0.f);
+          }
+          v = v * qs[ni] + qt[ni];
+#pragma unroll
+          for (int e = 0; e < 4; ++e) v[e] = fminf(fmaxf(v[e], -HP_MAX), HP_MAX);
+          acc[mi][ni] = v;
+        }
+#pragma unroll
+      for (int plane = 0; plane < 2; ++plane) {
+        lds_barrier();
+#pragma unroll
+        for (int mi = 0; mi < 4; ++mi) {
+          const int row = wm * 64 + mi * 16 + fr;
+          char* rowp = smem + row * (BN2 * 2);
+#pragma unroll
+          for (int ni = 0; ni < 4; ++ni) {
+            const f32x4 v = acc[mi][ni];
+            _Float16 h[4];
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+              const _Float16 hi = (_Float16)v[e];
+              h[e] = plane == 0 ? hi : (_Float16)((v[e] - (float)hi) * HP_LOSCALE);
+            }
+            uint2 pk;
+            pk.x = (uint32_t)__builtin_bit_cast(uint16_t, h[0]) | ((uint32_t)__builtin_bit_cast(uint16_t, h[1]) << 16);
+            pk.y = (uint32_t)__builtin_bit_cast(uint16_t, h[2]) | ((uint32_t)__builtin_bit_cast(uint16_t, h[3]) << 16);
+            const int u8 = (wn * 16 + ni * 4 + fq) ^ (fr << 1);
+            *reinterpret_cast<uint2*>(rowp + u8 * 8) = pk;
+          }
+        }
+        lds_barrier();
+        {
+          const int r0 = tid >> 5, cc = tid & 31;
+          const char* src = smem + r0 * (BN2 * 2) + ((cc ^ (r0 & 15)) << 4);
+          uint16_t* dst = p.C + (int64_t)(m0 + r0) * p.ldc + n0 + cc * 8 + (plane ? p.c_lo : 0);
+          const int rows_left = p.M - m0 - r0;
+#pragma unroll
+          for (int i = 0; i < 8; ++i) {
+            if (16 * i < rows_left) {
+              const u32x4 v = *reinterpret_cast<const u32x4*>(src + i * 16 * (BN2 * 2));
+              __builtin_nontemporal_store(v, reinterpret_cast<u32x4*>(dst + (int64_t)(16 * i) * p.ldc));
+            }
+          }
+        }
+      }
+    }
   }
 }
 
@@ -674,6 +826,7 @@ extern "C" int sdk_conv_gemm_hp(sdk_ctx* ctx, const sdk_conv_gemm_hp_args* a, vo
   p.bias = a->bias; p.scale = a->scale; p.shift = a->shift; p.ubias = a->ubias; p.ldub = a->ldub;
   p.X2 = a->X2; p.ldx2 = a->ldx2; p.x2_lo = a->x2_lo; p.S = a->S; p.lds = a->lds; p.s_lo = a->s_lo;
   p.M = a->M; p.N = a->N; p.Cin = a->Cin; p.taps = a->taps; p.dil = a->dil; p.T = a->T; p.flags = a->flags;
+  p.half_tail = ctx->hp_gemm_variant != 2;
   const double kk = (double)a->taps * a->Cin;
   ProfScope ps(ctx, stream, SDK_K_CONV_GEMM_HP, 3 * 2.0 * a->M * a->N * kk,
                4.0 * a->M * a->Cin + 4.0 * a->N * kk + (a->C ? 4.0 : 0.0) * a->M * a->N + (a->C32 ? 4.0 : 0.0) * a->M * a->N + (a->S ? 8.0 : 0.0) * a->M * a->N);

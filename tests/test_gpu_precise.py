@@ -113,6 +113,34 @@ def test_conv_gemm_hp_256_tile_kernel(precise, M, T, N, Cin, taps, dil):
     assert float((out[0] - out[1]).abs().max()) <= 3e-6 * float(want.abs().max())
 
 
+@pytest.mark.parametrize("M,T,N,Cin,taps,dil", [(40200, 201, 1024, 64, 1, 1), (20100, 201, 1024, 96, 3, 2), (66000, 200, 1024, 32, 1, 1), (40200, 201, 2048, 32, 1, 1)])
+def test_conv_gemm_hp_half_tile_tail_is_bit_identical(precise, M, T, N, Cin, taps, dil):
+    """Round 5: the precise GEMM's 256^2 kernel computes a mostly idle last tile round as 128 x 256 half tiles (as conv_gemm256_kernel does): the
+    same three product terms in the same K order per element, so both planes must equal the whole-tile schedule's (hp_gemm_variant 2 = half
+    tiles off) bit for bit - taps across segment boundaries, an edge half tile, and a shape the rule leaves alone (N = 2048)."""
+    eng = precise
+    g = torch.Generator().manual_seed(M + N + Cin + taps)
+    a = torch.randn(M, Cin, generator=g) * 2.0
+    w = torch.randn(N, taps * Cin, generator=g) * 0.04
+    bias, sc, sh = torch.randn(N, generator=g), torch.rand(N, generator=g) + 0.5, torch.randn(N, generator=g)
+    Ap = OPS.Engine.to_planes(a).cuda()
+    Wd = torch.from_numpy(WP.hp_weight_planes(w.numpy()).view(np.int16)).cuda()
+    out = {}
+    for variant in (0, 2):
+        eng.set_option("hp_gemm_variant", variant)
+        try:
+            out[variant] = eng.conv_gemm_hp(Ap, Wd, N, Cin, taps=taps, dil=dil, T=T, bias=bias.cuda(), scale=sc.cuda(), shift=sh.cuda(), relu=True)[0]
+            torch.cuda.synchronize()
+        finally:
+            eng.set_option("hp_gemm_variant", 0)
+    assert torch.equal(out[0].view(torch.int16), out[2].view(torch.int16))
+    if taps == 1:      # and against float64 on a sample of rows from the tail region
+        rows = torch.arange(M - 300, M)
+        want = torch.relu(OPS.Engine.from_planes(Ap[rows].cpu()).double() @ torch.from_numpy(WP.hp_planes_to_f64(WP.hp_weight_planes(w.numpy()), N, Cin)).T + bias.double()) * sc.double() + sh.double()
+        got = OPS.Engine.from_planes(out[0][rows].cpu()).double()
+        assert float((got - want).abs().max()) <= 1e-5 * float(want.abs().max())
+
+
 def test_conv_gemm_hp_epilogue_and_residual_sum(precise):
     eng = precise
     M, T, N, Cin = 402, 201, 128, 128
