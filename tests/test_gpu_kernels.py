@@ -779,14 +779,15 @@ def test_conv_gemm_fused_column_stats(engine, M, T, N, Cin, mode):
 
 @pytest.mark.parametrize("M,T,N,Cin,taps,dil,mode,pack", [(40200, 201, 1024, 128, 1, 1, 1, 0), (20100, 201, 1024, 64, 1, 1, 2, 0), (66000, 200, 1024, 192, 3, 2, 2, 0),
                                                           (201000, 201, 1024, 256, 1, 1, 2, 0), (201000, 201, 1024, 80, 5, 1, 0, 80), (50250, 201, 1024, 64, 1, 1, 1, 0),
-                                                          (40200, 201, 2048, 64, 1, 1, 0, 0)])
+                                                          (40200, 201, 2048, 64, 1, 1, 0, 0), (33600, 200, 2048, 64, 1, 1, 1, 0), (99200, 200, 3072, 64, 1, 1, 2, 0)])
 def test_conv_gemm_half_tile_tail_is_bit_identical(engine, M, T, N, Cin, taps, dil, mode, pack):
     """Round 5: where the whole rounds of the 256^2 kernel leave a last round that is mostly idle (the forward's K = 1024
     layers: 3144 tiles = 12 x 256 + 72), the left-over rows are computed as 128 x 256 half tiles, at most one per workgroup, instead of a 13th
     round of whole tiles.  Same K order per output element, same rows in the same order per column-statistics partial: output and statistics
     must equal the whole-tile schedule's (gemm_variant 8194 = tune bit 9: half tiles off) bit for bit - random operands, ReLU + BN epilogue,
-    conv taps, blk0's packed taps, an edge half tile that is partly / wholly outside the matrix, and a shape where the rule does not apply
-    (N = 2048: the left-over does not fit as half tiles)."""
+    conv taps, blk0's packed taps, an edge half tile that is partly / wholly outside the matrix, a shape where the rule does not apply
+    (N = 2048, 60 half row blocks left over: they do not fit), and wider layers where it does (N = 2048 with 8 half row blocks left: every XCD
+    takes one block's eight column tiles; N = 3072 with 8: one block's twelve column tiles per XCD)."""
     g = torch.Generator().manual_seed(M + N + taps)
     lda = Cin
     A = dev(bf16_round(torch.randn(M, lda, generator=g)), torch.bfloat16)
