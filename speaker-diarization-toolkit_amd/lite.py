@@ -206,6 +206,8 @@ class LiteEngine:
                 for S in order:
                     rows, local = sub[S]
                     Bs = len(local)
+                    if Bs == 0:
+                        continue
                     Es, idxs, scs = [], [], []
                     for a in range(0, Bs, step):
                         b = min(step, Bs - a)

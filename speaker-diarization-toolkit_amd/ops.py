@@ -309,6 +309,8 @@ class Engine:
                 for S in order:
                     rows, local = sub[S]
                     Bs = len(local)
+                    if Bs == 0:                                        # an empty table: its (empty) result is made below
+                        continue
                     parts = []
                     for a in range(0, Bs, step):
                         b = min(step, Bs - a)

@@ -138,6 +138,8 @@ def test_ingest_edge_cases(engine, tmp_path, monkeypatch):
     """Empty tables, a recording shorter than a window (one zero-padded window), a recording too short to analyse (the error the CLI prints), and a
     window table far larger than the staging slots' first size (they grow)."""
     assert engine.embed_from_host(_recording(1.0, 2), {}) == {}
+    empty = engine.embed_from_host(_recording(3.0, 2), {32000: np.array([0], np.int32), 8000: np.zeros((0,), np.int32)})      # one bucket without windows
+    assert empty[8000][0].shape == (0, 192) and empty[32000][0].shape == (1, 192)
     with pytest.raises(SdkError, match="empty batch|null argument"):
         engine.fbank_windows(1, 100, 1, 0, 32000)
     short = _recording(1.2, 4)                                     # 19 200 samples < one 2-s window
