@@ -375,6 +375,35 @@ def test_profile_pack_miss_publish_hit(tmp_path, monkeypatch):
     assert len(off) == 0 and not off.from_pack and off.pack_ref is None and len(off.skipped) == 41
 
 
+def test_profile_pack_hit_makes_the_links_once_and_checks_its_blob(tmp_path, monkeypatch):
+    """a pack built by a caller that did not link (link=False) must not leave the per-speaker links unmade for ever - the first hit
+    with link=True runs the cheap pass once and records it in the side table; and a pack whose blob no longer matches its crc32 (a torn or
+    overwritten file of the right size) is not served: the loader falls back to the per-embedding files."""
+    import json
+    monkeypatch.setenv("SPEAKERS_EMBEDDINGS_DIR", str(tmp_path))
+    vecs, cands = _enrol(24)
+    kw = dict(model_prefix="mi355x-", model_version="mi355x-ecapa1024-x")
+    miss = store.load_profile_batch(cands, "mi355x", link=False, **kw)
+    assert not miss.linked and not (tmp_path / "embeddings" / "spk00003").exists()
+    npy = store.publish_pack(miss, *_fake_norm(miss.matrix))
+    side = npy.with_suffix(".json")
+    assert json.loads(side.read_text())["linked"] is False and isinstance(json.loads(side.read_text())["crc32"], int)
+    hit0 = store.load_profile_batch(cands, "mi355x", link=False, **kw)
+    assert hit0.from_pack and not (tmp_path / "embeddings" / "spk00003").exists()                      # a reader that does not link leaves it so
+    hit1 = store.load_profile_batch(cands, "mi355x", link=True, **kw)
+    assert hit1.from_pack and (tmp_path / "embeddings" / "spk00003" / "emb-3.npy").exists() and json.loads(side.read_text())["linked"] is True
+    assert np.array_equal(np.load(tmp_path / "embeddings" / "spk00003" / "emb-3.npy"), vecs[3])
+    calls = []
+    monkeypatch.setattr(store, "adopt", lambda *a, **k: calls.append(a))
+    assert store.load_profile_batch(cands, "mi355x", link=True, **kw).from_pack and calls == []       # once per pack
+    # same size, other bytes: refused by the checksum
+    blob = np.load(npy)
+    blob[100] ^= 0xFF
+    np.save(npy, blob)
+    fallback = store.load_profile_batch(cands, "mi355x", link=False, **kw)
+    assert not fallback.from_pack and len(fallback) == 24 and np.array_equal(fallback.matrix, vecs)
+
+
 def test_profile_pack_goes_stale_with_the_candidate_set(tmp_path, monkeypatch):
     monkeypatch.setenv("SPEAKERS_EMBEDDINGS_DIR", str(tmp_path))
     vecs, cands = _enrol(20)
