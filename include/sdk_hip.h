@@ -255,6 +255,8 @@ int sdk_se_gate_residual(sdk_ctx* ctx, const uint16_t* z, int64_t ldz, const uin
  *   sdk_asp_pool  : softmax over t of logits[b,t,c] -> weighted mean / std of h -> pooled[b, 0:C | C:2C]
  */
 int sdk_asp_stats(sdk_ctx* ctx, const uint16_t* h, int64_t ldh, int B, int T, int C, float* out_ctx, void* stream);
+/* the same with the element format of h as an argument (0: bf16, 2: fp16) instead of the context's default - per call, like sdk_fbank_fmt */
+int sdk_asp_stats_fmt(sdk_ctx* ctx, const uint16_t* h, int64_t ldh, int B, int T, int C, float* out_ctx, int precision, void* stream);
 int sdk_rows_fc(sdk_ctx* ctx, const float* in, int64_t ldin, const float* in_scale, const float* in_shift,
                 const float* wt, const float* bias, float* out, int64_t ldout,
                 int B, int Cin, int Nout, int act, void* stream);
@@ -329,7 +331,9 @@ int sdk_ecapa_forward_calib(sdk_ctx* ctx, const void* wblob, const sdk_ecapa_des
  *      transposed), off[61] = FC bias.  cout[] are multiples of 128 (pad a 1500-wide layer to 1536 with zero weights).
  *      off[62] = numerical contract of the blob: -1 / 0 = bf16 operands (default mode); 1 = PRECISE mode (round 4): W slots are sdk_conv_gemm_hp
  *      weight slots (header + fp16 hi / lo planes), feats are fp16 planes [B*T, ldf] (lo plane ldf/2 columns to the right, n_feats = 96 padded
- *      mel channels, no tap packing), the layers run on sdk_conv_gemm_hp and the pooling on the planes; must equal the context's "precision". */
+ *      mel channels, no tap packing), the layers run on sdk_conv_gemm_hp and the pooling on the planes; 2 = ONE fp16 plane
+ *      (round 5): the default layout with fp16 bits in the W slots and in feats (sdk_fbank_fmt(..., 2, ...)), sdk_conv_gemm with SDK_GEMM_F16.
+ *      The blob decides per call; the context's "precision" option is not consulted. */
 typedef struct sdk_xvector_desc {
   int32_t n_frame_layers, n_feats, embed_dim, first_tap_pack;
   int32_t kernel[8], dilation[8], cin[8], cout[8];

@@ -2,7 +2,8 @@
 
 TEST INFRASTRUCTURE - see oracle/__init__.py.  **Parity unpinned** (the reference has no embedding model; backends.yaml:22-31).  Restates the
 published architecture (Snyder et al. 2018): frame layers  conv (reflect "same") -> ReLU -> BatchNorm(eval)  with bf16 GEMM operands and
-bf16 layer-boundary storage (mode "bf16") or no rounding (mode "fp32"), statistics pooling (mean | sqrt(max(var, 1e-12)) over frames, fp32
+bf16 layer-boundary storage (mode "bf16"), the same with fp16 operands and storage (mode "fp16": the single-plane precision 2), or no
+rounding (mode "fp32"), statistics pooling (mean | sqrt(max(var, 1e-12)) over frames, fp32
 as the GPU sweep computes it from the stored tensor), embedding layer in fp32.
 """
 from __future__ import annotations
@@ -14,7 +15,8 @@ from .ecapa import BN_EPS, _bf16, reflect_index
 
 def xvector_embed(weights, feats, kernels=(5, 3, 3, 1, 1), dilations=(1, 2, 3, 1, 1), mode="bf16", acc=torch.float64):
     """feats [B, T, n_feats] fp32 -> [B, embed_dim] fp32."""
-    q = _bf16 if mode == "bf16" else (lambda t: t)
+    assert mode in ("bf16", "fp16", "fp32")
+    q = _bf16 if mode == "bf16" else (lambda t: t.half().float()) if mode == "fp16" else (lambda t: t)
     x = q(torch.as_tensor(feats, dtype=torch.float32))
     B, T, _ = x.shape
     t = torch.arange(T)

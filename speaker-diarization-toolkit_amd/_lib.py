@@ -112,6 +112,7 @@ SIGNATURES = {
     "sdk_se_workspace_bytes": (_sz, [_i, _i, _i]),
     "sdk_se_gate_residual": (_i, [_vp, _vp, _i64, _vp, _i64, _vp, _vp, _vp, _vp, _vp, _i64, _i, _i, _i, _i, _vp, _vp, _sz, _vp]),
     "sdk_asp_stats": (_i, [_vp, _vp, _i64, _i, _i, _i, _vp, _vp]),
+    "sdk_asp_stats_fmt": (_i, [_vp, _vp, _i64, _i, _i, _i, _vp, _i, _vp]),
     "sdk_rows_fc": (_i, [_vp, _vp, _i64, _vp, _vp, _vp, _vp, _vp, _i64, _i, _i, _i, _i, _vp]),
     "sdk_asp_pool": (_i, [_vp, _vp, _i64, _vp, _i64, _i, _i, _i, _vp, _vp]),
     "sdk_asp_fused_max_frames": (_i, []),

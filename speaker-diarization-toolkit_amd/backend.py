@@ -28,7 +28,7 @@ Environment:
                       the set: one file mapped, no per-embedding I/O); SDK_PROFILE_PACK_MIN (16): smallest set that is packed
   SDK_PRECISION       0 (default: bf16 operands) / 1 (precise mode: fp16 hi+lo planes, within 1e-5,
                       ~3.6x the step time) / 2 (one fp16 plane: the default mode's kernels with fp16 storage and operands, within ~1e-4 with the
-                      bias correction, ~1.04x the step time; ECAPA-TDNN only).  All modes embed into the SAME space (they differ from each other at
+                      bias correction, ~1.04x the step time; both families).  All modes embed into the SAME space (they differ from each other at
                       the 4e-3 level), so model_version does not depend on it
 """
 from __future__ import annotations
@@ -188,8 +188,6 @@ class Backend(EmbeddingBackend):
             if self.model == "xvector":
                 from .xvector import XVector
                 prec = int(os.environ.get("SDK_PRECISION", "0"))
-                if prec == 2:
-                    raise ValueError("SDK_PRECISION=2 (one fp16 plane) is built for the ECAPA-TDNN family; SDK_MODEL=xvector serves precision 0 and 1")
                 self._engine = Engine(dev)               # front end, k3, k4; its ECAPA weights are never packed (lazy)
                 if prec:
                     self._engine.set_precision(prec)

@@ -899,6 +899,11 @@ extern "C" int sdk_asp_stats(sdk_ctx* ctx, const uint16_t* h, int64_t ldh, int B
   return asp_stats_impl(ctx, h, ldh, B, T, C, out_ctx, stream, ctx && ctx->precision == 2);
 }
 
+extern "C" int sdk_asp_stats_fmt(sdk_ctx* ctx, const uint16_t* h, int64_t ldh, int B, int T, int C, float* out_ctx, int precision, void* stream) {
+  SDK_REQUIRE(precision == 0 || precision == 2, "sdk_asp_stats_fmt: precision=%d (0: bf16 elements, 2: fp16 elements)", precision);
+  return asp_stats_impl(ctx, h, ldh, B, T, C, out_ctx, stream, precision == 2);
+}
+
 extern "C" int sdk_rows_fc(sdk_ctx* ctx, const float* in, int64_t ldin, const float* in_scale, const float* in_shift,
                            const float* wt, const float* bias, float* out, int64_t ldout, int B, int Cin, int Nout,
                            int act, void* stream) {

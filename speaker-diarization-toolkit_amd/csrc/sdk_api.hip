@@ -545,7 +545,7 @@ int check_xdesc(const sdk_xvector_desc* d) {
     if (l > 0) SDK_REQUIRE(d->cin[l] == d->cout[l - 1] && d->cin[l] % 64 == 0, "xvector desc: layer %d cin=%d does not follow cout=%d", l, d->cin[l], d->cout[l - 1]);
     for (int q = 0; q < 4; ++q) SDK_REQUIRE(d->off[4 * l + q] >= 0, "xvector desc: slot %d of layer %d missing", q, l);
   }
-  SDK_REQUIRE(d->off[62] == -1 || d->off[62] == 0 || d->off[62] == 1, "xvector desc: off[62] (precision of the blob) must be -1 / 0 (bf16 operands) or 1 (fp16 planes)");
+  SDK_REQUIRE(d->off[62] >= -1 && d->off[62] <= 2, "xvector desc: off[62] (precision of the blob) must be -1 / 0 (bf16 operands), 1 (fp16 hi + lo planes) or 2 (one fp16 plane)");
   if (d->off[62] == 1)
     SDK_REQUIRE(d->cin[0] == d->n_feats && d->n_feats % 32 == 0 && d->first_tap_pack == 0, "xvector desc: a precise-mode blob reads %d feature channels (a multiple of 32, no tap packing)", d->n_feats);
   else
@@ -578,8 +578,8 @@ extern "C" int sdk_xvector_forward(sdk_ctx* ctx, const void* wblob, const sdk_xv
                                    void* ws, size_t ws_bytes, float* emb, void* stream) {
   SDK_REQUIRE(ctx && wblob && feats && ws && emb, "sdk_xvector_forward: null argument");
   if (int rc = check_xdesc(d)) return rc;
-  const bool hp = d->off[62] == 1;
-  // (the blob's precision decides, per call; the features must be in its format: bf16 for 0, fp16 hi | lo planes for 1)
+  const bool hp = d->off[62] == 1, f16 = d->off[62] == 2;
+  // (the blob's precision decides, per call; the features must be in its format: bf16 for 0, fp16 hi | lo planes for 1, one fp16 plane for 2)
   SDK_REQUIRE(B > 0 && T > 0 && (int64_t)B * T < (1ll << 31), "sdk_xvector_forward: bad batch (B=%d T=%d)", B, T);
   if (hp) SDK_REQUIRE(ldf % 16 == 0 && (ldf >> 1) >= d->n_feats && d->first_tap_pack == 0 && d->n_feats % 32 == 0,
                       "sdk_xvector_forward: precise mode reads fp16 planes [B*T, ldf] with the lo plane ldf/2 columns to the right: ldf=%d, n_feats=%d (a multiple of 32, no tap packing)", ldf, d->n_feats);
@@ -620,13 +620,13 @@ extern "C" int sdk_xvector_forward(sdk_ctx* ctx, const void* wblob, const sdk_xv
       memset(&g, 0, sizeof(g));
       g.A = in; g.lda = ldin; g.W = (const uint16_t*)(wb + d->off[4 * l]); g.C = out; g.ldc = d->cout[l];
       g.bias = (const float*)(wb + d->off[4 * l + 1]); g.scale = (const float*)(wb + d->off[4 * l + 2]); g.shift = (const float*)(wb + d->off[4 * l + 3]);
-      g.M = M; g.N = d->cout[l]; g.Cin = d->cin[l]; g.taps = d->kernel[l]; g.dil = d->dilation[l]; g.T = T; g.flags = SDK_GEMM_RELU;
+      g.M = M; g.N = d->cout[l]; g.Cin = d->cin[l]; g.taps = d->kernel[l]; g.dil = d->dilation[l]; g.T = T; g.flags = SDK_GEMM_RELU | (f16 ? SDK_GEMM_F16 : 0u);
       if (l == 0 && d->first_tap_pack) g.tap_pack = d->first_tap_pack;
       if (int rc = sdk_conv_gemm(ctx, &g, stream)) return rc;
       in = out;
       ldin = d->cout[l];
     }
-    if (int rc = asp_stats_impl(ctx, in, ldin, B, T, Cl, stats, stream, false)) return rc;
+    if (int rc = asp_stats_impl(ctx, in, ldin, B, T, Cl, stats, stream, f16)) return rc;
   }
   return sdk_rows_fc(ctx, stats, 2 * Cl, nullptr, nullptr, (const float*)(wb + d->off[60]), (const float*)(wb + d->off[61]), emb, d->embed_dim, B, 2 * Cl,
                      d->embed_dim, 0, stream);

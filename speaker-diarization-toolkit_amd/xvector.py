@@ -21,7 +21,7 @@ from typing import Dict, Tuple
 import numpy as np
 
 from .weights import bn_affine
-from .weights_pack import ALIGN, N_MELS_PADDED_HP, bf16_bits_to_f32, conv_weight_kmajor, conv_weight_kmajor_f32, f32_to_bf16_bits, hp_weight_planes
+from .weights_pack import ALIGN, N_MELS_PADDED_HP, bf16_bits_to_f32, conv_weight_kmajor, conv_weight_kmajor_f32, f32_to_bf16_bits, hp_weight_planes, round16
 
 
 @dataclass(frozen=True)
@@ -83,12 +83,13 @@ def pack_weights(weights: Dict[str, np.ndarray], cfg: XVectorConfig = DEFAULT_XV
     """-> (blob uint8, XVectorDesc).  Channel counts are padded to multiples of 128 with zero weights / bias, BN scale 1, shift 0 (a padded
     channel is exactly 0 after ReLU; its pooled mean is 0, its std the 1e-6 floor, and the embedding layer's weights for it are zero).
     precision 1: the precise mode's blob (off[62] = 1): every frame layer's weights as a power-of-two-scaled fp16 hi + lo plane slot
-    (weights_pack.hp_weight_planes), the first layer over the 96 padded mel channels of the plane-format features, no tap packing."""
+    (weights_pack.hp_weight_planes), the first layer over the 96 padded mel channels of the plane-format features, no tap packing.
+    precision 2: the default layout with fp16 bits in the weight slots (off[62] = 2; features from sdk_fbank_fmt(..., 2, ...))."""
     for k, s in param_shapes(cfg).items():
         if k not in weights or tuple(weights[k].shape) != s:
             raise ValueError(f"x-vector weight {k}: expected shape {s}, got {None if k not in weights else tuple(weights[k].shape)}")
-    if precision not in (0, 1):
-        raise ValueError(f"precision must be 0 or 1, got {precision}")
+    if precision not in (0, 1, 2):
+        raise ValueError(f"precision must be 0, 1 or 2, got {precision}")
     pc = cfg.padded_channels()
     cin_real = (cfg.n_feats,) + cfg.channels[:-1]
     n_in = N_MELS_PADDED_HP if precision == 1 else cfg.n_feats
@@ -116,7 +117,7 @@ def pack_weights(weights: Dict[str, np.ndarray], cfg: XVectorConfig = DEFAULT_XV
         if precision == 1:
             wk = hp_weight_planes(conv_weight_kmajor_f32(w))                    # 256-byte header + fp16 hi / lo planes of 2^s W, [cout, k * cin] each
         else:
-            wk = conv_weight_kmajor(w)                                          # bf16 bits [cout, k * cin]
+            wk = conv_weight_kmajor(w, precision=precision)                     # bf16 (precision 2: fp16) bits [cout, k * cin]
             if l == 0 and d.first_tap_pack:
                 kp = (wk.shape[1] + 63) // 64 * 64
                 wp = np.zeros((wk.shape[0], kp), np.uint16)
@@ -142,13 +143,15 @@ def pack_weights(weights: Dict[str, np.ndarray], cfg: XVectorConfig = DEFAULT_XV
     return blob, d
 
 
-def bias_corrections(weights: Dict[str, np.ndarray], means: Dict[int, np.ndarray], cfg: XVectorConfig = DEFAULT_XVECTOR) -> Dict[str, np.ndarray]:
-    """frame layer l -> corrected fp32 bias  b + (W - bf16(W)) . mu_l  (float64 inside; every tap sees the same channel means) - the same
-    post-training bias correction of the bf16 weight rounding the ECAPA-TDNN family gets (weights_pack.bias_corrections)."""
+def bias_corrections(weights: Dict[str, np.ndarray], means: Dict[int, np.ndarray], cfg: XVectorConfig = DEFAULT_XVECTOR,
+                     precision: int = 0) -> Dict[str, np.ndarray]:
+    """frame layer l -> corrected fp32 bias  b + (W - round16(W)) . mu_l  (float64 inside; every tap sees the same channel means; round16 =
+    bf16 for precision 0, fp16 for precision 2) - the same post-training bias correction of the weight rounding the ECAPA-TDNN family gets
+    (weights_pack.bias_corrections)."""
     out = {}
     for l, mu in means.items():
         w = weights[f"frame{l}.conv.w"].astype(np.float64)
-        dw = w - bf16_bits_to_f32(f32_to_bf16_bits(w.astype(np.float32))).astype(np.float64)
+        dw = w - round16(w.astype(np.float32), precision).astype(np.float64)
         corr = np.tensordot(dw.sum(axis=2), np.asarray(mu, np.float64)[:dw.shape[1]], axes=([1], [0]))
         out[f"frame{l}.conv.b"] = (weights[f"frame{l}.conv.b"].astype(np.float64) + corr).astype(np.float32)
     return out
@@ -156,11 +159,12 @@ def bias_corrections(weights: Dict[str, np.ndarray], means: Dict[int, np.ndarray
 
 def calibration_means(lib, ctx, d: "XVectorDesc", cfg: XVectorConfig, blob_ptr: int, feats_ptr: int, ldf: int, B: int, T: int, alloc, download,
                       stream) -> Dict[int, np.ndarray]:
-    """Per-channel means of the INPUT of frame layers 1..L-1 of a default-mode blob: the layers run one at a time through sdk_conv_gemm, the
-    per-segment channel means come from sdk_asp_stats - C-ABI calls only, so ops.Engine (torch tensors) and lite.LiteEngine (sdk_device_malloc)
+    """Per-channel means of the INPUT of frame layers 1..L-1 of a single-plane blob (off[62] = 0 or 2): the layers run one at a time through
+    sdk_conv_gemm, the per-segment channel means come from sdk_asp_stats_fmt in the blob's element format - C-ABI calls only, so ops.Engine (torch tensors) and lite.LiteEngine (sdk_device_malloc)
     run the identical sequence and get identical means.  alloc(nbytes) -> device pointer (kept alive by the caller); download(ptr, n_floats)
     -> float32 host array (synchronising)."""
-    from ._lib import ConvGemmArgs, GEMM_RELU, check
+    from ._lib import ConvGemmArgs, GEMM_F16, GEMM_RELU, check
+    fmt = 2 if int(d.off[62]) == 2 else 0
     means: Dict[int, np.ndarray] = {}
     x, ldx = feats_ptr, ldf
     M = B * T
@@ -172,11 +176,11 @@ def calibration_means(lib, ctx, d: "XVectorDesc", cfg: XVectorConfig, blob_ptr: 
         g.C, g.ldc = out, cout
         g.bias, g.scale, g.shift = blob_ptr + int(d.off[4 * l + 1]), blob_ptr + int(d.off[4 * l + 2]), blob_ptr + int(d.off[4 * l + 3])
         g.M, g.N, g.Cin, g.taps, g.dil, g.T = M, cout, d.cin[l], d.kernel[l], d.dilation[l], T
-        g.flags = GEMM_RELU
+        g.flags = GEMM_RELU | (GEMM_F16 if fmt == 2 else 0)
         g.tap_pack = d.first_tap_pack if l == 0 else 0
         check(lib.sdk_conv_gemm(ctx, C.byref(g), stream), "sdk_conv_gemm")
         st = alloc(B * 2 * cout * 4)
-        check(lib.sdk_asp_stats(ctx, out, cout, B, T, cout, st, stream), "sdk_asp_stats")
+        check(lib.sdk_asp_stats_fmt(ctx, out, cout, B, T, cout, st, fmt, stream), "sdk_asp_stats_fmt")
         stats = download(st, B * 2 * cout).reshape(B, 2 * cout)                  # mean | std per segment
         means[l + 1] = stats[:, :cout].astype(np.float64).mean(axis=0)[:cfg.channels[l]]
         x, ldx = out, cout
@@ -185,10 +189,11 @@ def calibration_means(lib, ctx, d: "XVectorDesc", cfg: XVectorConfig, blob_ptr: 
 
 class XVector:
     """Resident x-vector extractor on an ops.Engine (device blob + descriptor); embed_pcm mirrors Engine.embed_pcm.
-    bias_correction (default: $SDK_BIAS_CORRECTION, on): default mode only - fold the constant part of the bf16 weight-rounding error of frame
+    bias_correction (default: $SDK_BIAS_CORRECTION, on): single-plane modes (0: bf16, 2: fp16) - fold the constant part of the weight-rounding error of frame
     layers 1.. into their biases, from ONE calibration pass on the engine's built-in synthetic audio (the layer inputs' channel means are
     measured on the GPU with the library's own kernels; layer 0 needs none: its input is mean-normalised).  precision 1: the precise mode
-    (fp16 hi+lo planes, three MFMAs per product) - the engine must run precision 1 too (Engine.set_precision), which XVector does itself."""
+    (fp16 hi+lo planes, three MFMAs per product); precision 2: one fp16 plane.  The engine's front end must write that format
+    (Engine.set_precision), which XVector does itself."""
 
     def __init__(self, engine, weights: Dict[str, np.ndarray] = None, cfg: XVectorConfig = DEFAULT_XVECTOR, seed: int = 0,
                  bias_correction=None, precision: int = 0):
@@ -196,13 +201,13 @@ class XVector:
         import torch
         self.eng, self.cfg, self.precision = engine, cfg, int(precision)
         self.weights = dict(weights if weights is not None else synthetic_weights(seed, cfg))
-        self.bias_correction = ((os.environ.get("SDK_BIAS_CORRECTION", "1") != "0") if bias_correction is None else bool(bias_correction)) and self.precision == 0
+        self.bias_correction = ((os.environ.get("SDK_BIAS_CORRECTION", "1") != "0") if bias_correction is None else bool(bias_correction)) and self.precision in (0, 2)
         blob, self.desc = pack_weights(self.weights, cfg, precision=self.precision)
         self.blob = torch.from_numpy(blob).to(engine.device)
         self._effective = self.weights
         if self.bias_correction:
-            self._effective = dict(self.weights, **bias_corrections(self.weights, self._calibrate(), cfg))
-            blob, self.desc = pack_weights(self._effective, cfg)
+            self._effective = dict(self.weights, **bias_corrections(self.weights, self._calibrate(), cfg, precision=self.precision))
+            blob, self.desc = pack_weights(self._effective, cfg, precision=self.precision)
             self.blob = torch.from_numpy(blob).to(engine.device)
 
     def effective_weights(self) -> Dict[str, np.ndarray]:
@@ -215,6 +220,8 @@ class XVector:
         from .ops import _stream, num_frames
         from .weights_pack import calibration_pcm
         eng = self.eng
+        if eng.precision != self.precision:
+            eng.set_precision(self.precision)                   # the calibration features in the blob's element format
         pcm = torch.from_numpy(calibration_pcm()).to(eng.device)
         B, S = pcm.shape
         feats = eng.fbank(pcm)

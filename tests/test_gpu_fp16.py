@@ -202,7 +202,7 @@ def test_pcm_to_score_fp16_mode_against_the_fp32_oracle(fp16, fp16_corrected):
 
 def test_backend_in_fp16_mode_end_to_end(tmp_path, monkeypatch):
     """SDK_PRECISION=2 through the plug-in API: enroll and identify; the vector is found by the default mode too (same embedding space);
-    the x-vector family refuses the mode with a readable message."""
+    the x-vector family serves the mode too (tests/test_xvector.py has its parity test)."""
     monkeypatch.setenv("SPEAKERS_EMBEDDINGS_DIR", str(tmp_path))
     wav, B = sub("wav"), sub("backend")
     t = np.arange(16000 * 6) / 16000.0
@@ -223,5 +223,9 @@ def test_backend_in_fp16_mode_end_to_end(tmp_path, monkeypatch):
     assert be0.model_version == be2.model_version and rows0[0]["speaker_id"] == "a" and abs(rows0[0]["similarity"] - rows2[0]["similarity"]) < 2e-2
     monkeypatch.setenv("SDK_PRECISION", "2")
     monkeypatch.setenv("SDK_MODEL", "xvector")
-    with pytest.raises(ValueError, match="ECAPA-TDNN"):
-        B.Backend().engine()
+    bx = B.Backend()
+    recx = bx.enroll_speaker(tmp_path / "a.wav")
+    candx = [{"id": "a", "embeddings": {"mi355x": [{"id": "emb-x", "external_id": recx["external_id"], "model_version": recx["model_version"]}]}}]
+    rowsx = bx.identify_speaker(tmp_path / "a.wav", candx)
+    assert bx.numerics() == {"precision": 2, "bias_correction": True} and bx.engine().precision == 2
+    assert rowsx and rowsx[0]["speaker_id"] == "a" and rowsx[0]["similarity"] > 0.95 and recx["model_version"].startswith("mi355x-xvector512-")

@@ -229,6 +229,44 @@ def test_xvector_bias_correction_is_the_bf16_model_of_its_effective_weights_and_
 
 
 @pytest.mark.gpu
+def test_xvector_fp16_mode_is_the_11_bit_model_and_5x_closer_to_fp32(engine):
+    """Precision 2 for the second family (round 5): the default layout and kernels with one fp16 plane (off[62] = 2, SDK_GEMM_F16 per layer,
+    sdk_asp_stats_fmt, features from sdk_fbank_fmt(..., 2)).  Plain weights: the forward is the oracle's fp16 layer-boundary model (the bf16 test's
+    tolerance scaled by 2^-3: 8 -> 11 significand bits).  Corrected: the fp16 model of its effective weights; PCM -> score deviation from the fp32
+    model well below the corrected bf16 default's."""
+    import importlib, sys
+    from conftest import ROOT
+    from oracle import fbank as ofbank
+    sys.path.insert(0, str(ROOT))
+    bench = importlib.import_module("bench")
+    w = XV.synthetic_weights(0)
+    eng = sub("ops").Engine(0, bias_correction=False)              # an engine of its own: the shared one stays in its format
+    plain = XV.XVector(eng, w, bias_correction=False, precision=2)
+    corr = XV.XVector(eng, w, bias_correction=True, precision=2)
+    bf = XV.XVector(engine, w, bias_correction=True)
+    assert int(plain.desc.off[62]) == 2 and plain.desc.first_tap_pack == 80
+    eff = corr.effective_weights()
+    assert sorted(k for k in w if not np.array_equal(eff[k], w[k])) == [f"frame{l}.conv.b" for l in (1, 2, 3, 4)]
+    pcm = bench.synth_pcm(48, seed=2)
+    feats = torch.from_numpy(ofbank.fbank(pcm))
+    P = bench.unit_rows(100, 192, seed=1).astype(np.float64)
+    dpcm = torch.from_numpy(pcm).cuda()
+    Ep, Ec = plain.embed_pcm(dpcm)[0].cpu(), corr.embed_pcm(dpcm)[0].cpu()
+    assert eng.precision == 2 and engine.precision == 0
+    Eb = bf.embed_pcm(dpcm)[0].cpu()
+    for E, ww in ((Ep, w), (Ec, eff)):
+        want = torch.from_numpy(oecapa.l2_normalise(oxv.xvector_embed(ww, feats, mode="fp16").numpy()))
+        assert (_cos(E, want) > 1 - 2e-5 / 8).all(), float((1 - _cos(E, want)).max())
+    E32 = oecapa.l2_normalise(oxv.xvector_embed(w, feats, mode="fp32").numpy()).astype(np.float64)
+    dev = {n: float(np.abs(E.numpy().astype(np.float64) @ P.T - E32 @ P.T).max()) for n, E in (("fp16_plain", Ep), ("fp16_corrected", Ec), ("bf16_corrected", Eb))}
+    print("\nx-vector PCM -> score deviation from the fp32 model (48 segments x 100 profiles):", dev)
+    assert dev["fp16_corrected"] < 0.25 * dev["bf16_corrected"] and dev["fp16_plain"] < 0.25 * dev["bf16_corrected"] * 4, dev
+    # the format travels with the blob: the forward does not consult the context's default
+    f2 = eng.fbank(dpcm[:2].contiguous())
+    assert torch.equal(plain.forward(f2, 2, 201), plain.forward(f2, 2, 201))
+
+
+@pytest.mark.gpu
 def test_xvector_precise_mode_meets_1e5(engine):
     """the x-vector family in the precise mode (fp16 hi+lo planes, three MFMAs per product, sdk_conv_gemm_hp per frame layer,
     pooling on the planes): PCM -> cosine score within north_star's 1e-5 of the un-rounded model (float64 accumulation), IDs identical."""
