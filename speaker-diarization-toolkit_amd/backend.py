@@ -154,7 +154,7 @@ class Backend(EmbeddingBackend):
         from .lite import LiteEngine
         dev = int(os.environ.get("SDK_DEVICE", os.environ.get("LOCAL_RANK", "0")))
         if int(os.environ.get("SDK_PRECISION", "0")):
-            raise ValueError("SDK_NO_TORCH=1 serves the default numerical contract only (SDK_PRECISION=1 needs the torch engine)")
+            raise ValueError(f"SDK_NO_TORCH=1 serves the default numerical contract only (SDK_PRECISION={os.environ['SDK_PRECISION']} needs the torch engine)")
         if self.model == "xvector":
             eng = LiteEngine(dev)
             eng.load_xvector(self._host_weights())
