@@ -19,7 +19,8 @@ Environment:
   SDK_WINDOW_S / SDK_HOP_S   analysis window / hop in seconds (default 2.0 / 1.0)
   SDK_NO_TORCH        1: the torch-free host path (lite.py) for enroll / identify / verify: same library calls, numpy on the host, device memory
                       from sdk_device_malloc - a warm-cache CLI process reaches its first row without the 0.8-s `import torch`.  The packed
-                      weights come from the on-disk cache; a missing entry is built once in a child process (through the torch engine)
+                      weights come from the on-disk cache; a missing entry is built once in a child process (through the torch engine).
+                      Serves SDK_PRECISION 0 and 2 (the precise mode needs the torch engine)
   SDK_BIAS_CORRECTION 1 (default) / 0: fold the constant part of the bf16 weight-rounding error into the layer biases (one calibration pass at the
                       first load of a weight set, cached): scores within ~8e-4 of the fp32 model instead of ~4e-3, no run-time cost
   SDK_CALIBRATION_WAV a 16 kHz mono s16 WAVE file whose two-second windows replace the built-in synthetic calibration audio of the bias correction
@@ -153,13 +154,14 @@ class Backend(EmbeddingBackend):
         calibration pass, store) - this process must not import torch itself (one HIP runtime per process)."""
         from .lite import LiteEngine
         dev = int(os.environ.get("SDK_DEVICE", os.environ.get("LOCAL_RANK", "0")))
-        if int(os.environ.get("SDK_PRECISION", "0")):
-            raise ValueError(f"SDK_NO_TORCH=1 serves the default numerical contract only (SDK_PRECISION={os.environ['SDK_PRECISION']} needs the torch engine)")
+        prec = int(os.environ.get("SDK_PRECISION", "0"))
+        if prec not in (0, 2):
+            raise ValueError(f"SDK_NO_TORCH=1 serves the single-plane contracts (SDK_PRECISION=0 or 2); SDK_PRECISION={prec} needs the torch engine")
         if self.model == "xvector":
-            eng = LiteEngine(dev)
+            eng = LiteEngine(dev, precision=prec)
             eng.load_xvector(self._host_weights())
             return eng
-        eng = LiteEngine(dev, cache_key=self._cache_key())
+        eng = LiteEngine(dev, cache_key=self._cache_key(), precision=prec)
         if not eng.has_cached_weights():
             import subprocess
             root = str(Path(__file__).resolve().parent.parent)

@@ -74,7 +74,10 @@ class LiteEngine:
     """Resident state of one process on one GPU: context, fbank tables, weight blob, growing scratch buffers."""
 
     def __init__(self, device: int = 0, cache_key: Optional[str] = None, cfg: EcapaConfig = DEFAULT_CONFIG,
-                 bias_correction: Optional[bool] = None):
+                 bias_correction: Optional[bool] = None, precision: int = 0):
+        if precision not in (0, 2):
+            raise SdkError(f"the torch-free engine serves the single-plane contracts (precision 0: bf16, 2: fp16), got {precision}")
+        self.precision = int(precision)
         self.lib = _lib.load_library()
         self.ctx = _lib.get_ctx(device)
         self.cfg = cfg
@@ -108,7 +111,7 @@ class LiteEngine:
 
     def cache_entry_name(self):
         from .weights_pack import calibration_tag
-        return ("0c" + calibration_tag()) if self.bias_correction else 0
+        return (f"{self.precision}c" + calibration_tag()) if self.bias_correction else self.precision
 
     def has_cached_weights(self) -> bool:
         """True only if the entry LOADS: meta present, blob present, size / offset table / SHA-256 good (weights_cache.load_blob) - a meta file whose
@@ -142,7 +145,7 @@ class LiteEngine:
         (xvector.calibration_means: library calls only), so both host paths hold bit-identical blobs."""
         from . import xvector
         from .weights_pack import calibration_pcm
-        blob, desc = xvector.pack_weights(weights)
+        blob, desc = xvector.pack_weights(weights, precision=self.precision)
         dev = DevBuf(self, blob.size).upload(blob)
         if self.bias_correction:
             pcm = calibration_pcm()
@@ -158,7 +161,7 @@ class LiteEngine:
                 return next(k for k in keep if k.ptr == ptr).download(np.float32, (n_floats,))
             means = xvector.calibration_means(self.lib, self.ctx, desc, xvector.DEFAULT_XVECTOR, dev.ptr, feats.ptr, N_MELS_PADDED, B, num_frames(S),
                                               alloc, download, None)
-            blob, desc = xvector.pack_weights(dict(weights, **xvector.bias_corrections(weights, means)))
+            blob, desc = xvector.pack_weights(dict(weights, **xvector.bias_corrections(weights, means, precision=self.precision)), precision=self.precision)
             dev.free()
             dev = DevBuf(self, blob.size).upload(blob)
             for k in keep:
@@ -170,7 +173,7 @@ class LiteEngine:
         T = num_frames(S)
         feats = self._buf("feats", B * T * N_MELS_PADDED * 2)
         ws = self._buf("fbank_ws", self.lib.sdk_fbank_workspace_bytes(B, S))
-        check(self.lib.sdk_fbank_fmt(self.ctx, pcm_dev.ptr, B, S, self._tables().ptr, feats.ptr, N_MELS_PADDED, ws.ptr, ws.nbytes, 0, None), "sdk_fbank")   # this path serves the default contract
+        check(self.lib.sdk_fbank_fmt(self.ctx, pcm_dev.ptr, B, S, self._tables().ptr, feats.ptr, N_MELS_PADDED, ws.ptr, ws.nbytes, self.precision, None), "sdk_fbank")
         return feats
 
     def fbank_windows(self, samples_ptr: int, n_samples: int, starts_ptr: int, B: int, S: int) -> DevBuf:
@@ -178,7 +181,7 @@ class LiteEngine:
         T = num_frames(S)
         feats = self._buf("feats", B * T * N_MELS_PADDED * 2)
         ws = self._buf("fbank_ws", self.lib.sdk_fbank_workspace_bytes(B, S))
-        check(self.lib.sdk_fbank_windows_fmt(self.ctx, samples_ptr, n_samples, starts_ptr, B, S, self._tables().ptr, feats.ptr, N_MELS_PADDED, ws.ptr, ws.nbytes, 0, None),
+        check(self.lib.sdk_fbank_windows_fmt(self.ctx, samples_ptr, n_samples, starts_ptr, B, S, self._tables().ptr, feats.ptr, N_MELS_PADDED, ws.ptr, ws.nbytes, self.precision, None),
               "sdk_fbank_windows")
         return feats
 

@@ -62,16 +62,16 @@ def test_lite_import_chain_is_torch_free():
     assert r.returncode == 0 and r.stdout.strip() == "False", (r.stdout, r.stderr[-500:])
 
 
-def test_lite_needs_the_default_contract(monkeypatch):
+def test_lite_serves_the_single_plane_contracts_only(monkeypatch):
     monkeypatch.setenv("SDK_NO_TORCH", "1")
     monkeypatch.setenv("SDK_PRECISION", "1")
-    with pytest.raises(ValueError, match="SDK_PRECISION"):
+    with pytest.raises(ValueError, match="SDK_PRECISION=1"):
         sub("backend").Backend()._lite_engine()
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("model,bias_correction", [("ecapa", "1"), ("ecapa", "0"), ("xvector", "1")])
-def test_lite_rows_equal_the_torch_engine(tmp_path, model, bias_correction):
+@pytest.mark.parametrize("model,bias_correction,precision", [("ecapa", "1", "0"), ("ecapa", "0", "0"), ("xvector", "1", "0"), ("ecapa", "1", "2"), ("xvector", "1", "2")])
+def test_lite_rows_equal_the_torch_engine(tmp_path, model, bias_correction, precision):
     from test_gpu_backend_e2e import _voice
     wav = sub("wav")
     wav.write_wav_s16(tmp_path / "enroll_alice.wav", _voice(10, 6.0, 140.0))
@@ -84,20 +84,20 @@ def test_lite_rows_equal_the_torch_engine(tmp_path, model, bias_correction):
     (tmp_path / "meeting48k.wav").write_bytes(b"RIFF" + struct.pack("<I", 36 + len(pcm)) + b"WAVEfmt " + struct.pack("<IHHIIHH", 16, 1, 2, 48000, 48000 * 4, 4, 16)
                                               + b"data" + struct.pack("<I", len(pcm)) + pcm)
     cache = tmp_path / "cache"
-    base = {"SDK_MODEL": model, "SDK_CACHE_DIR": str(cache), "SDK_BIAS_CORRECTION": bias_correction}     # "1" = the shipped default (cache entry "p0c")
+    base = {"SDK_MODEL": model, "SDK_CACHE_DIR": str(cache), "SDK_BIAS_CORRECTION": bias_correction, "SDK_PRECISION": precision}     # "1", "0" = the shipped default (cache entry "p0c"); precision 2 = one fp16 plane ("p2c")
     lite_cold = _run_child(tmp_path, dict(base, SDK_NO_TORCH="1", TAG="lite_cold"))       # empty cache: a grandchild builds the entry (ecapa)
     ref = _run_child(tmp_path, dict(base, TAG="torch"))
     lite_warm = _run_child(tmp_path, dict(base, SDK_NO_TORCH="1", TAG="lite_warm"))
     assert lite_cold["torch"] is False and lite_warm["torch"] is False and ref["torch"] is True
     assert lite_cold["model_version"] == ref["model_version"] == lite_warm["model_version"]
     if model == "ecapa":
-        assert lite_warm["cache_hit"] is True and any(cache.glob("*.p0c.npy" if bias_correction == "1" else "*.p0.npy"))
-        assert not any(cache.glob("*.p0.npy" if bias_correction == "1" else "*.p0c.npy"))
+        assert lite_warm["cache_hit"] is True and any(cache.glob(f"*.p{precision}c.npy" if bias_correction == "1" else f"*.p{precision}.npy"))
+        assert not any(cache.glob(f"*.p{precision}.npy" if bias_correction == "1" else f"*.p{precision}c.npy"))
     for got in (lite_cold, lite_warm):
         # same kernels on the same inputs: stored vectors, scores and rows are the torch engine's, bit for bit
         assert got["vecs"] == ref["vecs"]
         assert got["rows"] == ref["rows"] and got["verify"] == ref["verify"] and got["mappings"] == ref["mappings"]
-    if model == "ecapa" and bias_correction == "1":
+    if model == "ecapa" and bias_correction == "1" and precision == "0":
         # a recording longer than a staging slot may be goes through the ring in pieces (ingest.plan_chunks; here 4.1-s pieces of an 8-s file):
         # both host paths cut the same pieces, so their rows agree bit for bit again, and the decisions are those of the one-piece run
         ch = {"SDK_INGEST_CHUNK": "65536"}
