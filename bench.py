@@ -126,6 +126,60 @@ def cpu_baseline(pcm: np.ndarray, P: np.ndarray, budget_s: float = 18.0):
                             "cgroup share of the socket (16 hardware threads of a much larger part), not by the sgemm calls; a reported baseline, not a tuned CPU implementation"}, emb
 
 
+class BoardPower:
+    """Board power / shader clock of this process's device while a leg runs, from the amdgpu driver's hwmon files (plain sysfs reads on a thread: no
+    HIP call, nothing on the stream).  The evidence next to `roofline.frac`: the dominant GEMM runs at the board's power cap (DESIGN.md section 5,
+    profiles/r05_power_probe.json).  None where the files are not readable."""
+
+    def __init__(self, dev: int):
+        import glob
+        self.dir = None
+        try:
+            pr = torch.cuda.get_device_properties(dev)
+            bdf = f"{pr.pci_domain_id:04x}:{pr.pci_bus_id:02x}:{pr.pci_device_id:02x}.0"
+            hits = glob.glob(f"/sys/bus/pci/devices/{bdf}/hwmon/hwmon*")
+            self.dir = hits[0] if hits else None
+        except Exception:  # noqa: BLE001
+            self.dir = None
+        self.rows, self._stop, self._th = [], False, None
+
+    def _rd(self, name):
+        try:
+            return int(open(f"{self.dir}/{name}").read().split()[0])
+        except Exception:  # noqa: BLE001
+            return None
+
+    def start(self, skip_s: float = 0.0):
+        if self.dir is None:
+            return
+        import threading
+
+        def run():
+            t0 = time.perf_counter()
+            while not self._stop:
+                if time.perf_counter() - t0 >= skip_s:
+                    p = self._rd("power1_average")
+                    p = self._rd("power1_input") if p is None else p
+                    self.rows.append((p, self._rd("freq1_input")))
+                time.sleep(0.05)
+        self._th = threading.Thread(target=run, daemon=True)
+        self._th.start()
+
+    def stop(self):
+        if self.dir is None or self._th is None:
+            return None
+        self._stop = True
+        self._th.join()
+        pw = [r[0] / 1e6 for r in self.rows if r[0]]
+        ck = [r[1] / 1e6 for r in self.rows if r[1]]
+        cap = self._rd("power1_cap")
+        if not pw:
+            return None
+        return {"mean_W": round(sum(pw) / len(pw), 1), "max_W": round(max(pw), 1), "cap_W": None if cap is None else round(cap / 1e6, 1),
+                "sclk_mean_mhz": round(sum(ck) / len(ck)) if ck else None, "samples": len(pw),
+                "source": "amdgpu hwmon power1_average / freq1_input of this device, sampled every 50 ms over the leg (first 0.5 s skipped)"}
+
+
 def measure_gemm_clock(eng, step):
     """Shader clock held inside conv_gemm256_kernel: diagnostic stamps (s_memtime / s_memrealtime of every workgroup's first wave)
     written to a side buffer during one extra, untimed step; median over workgroups of the largest launch."""
@@ -751,15 +805,19 @@ def main() -> int:
             # the driver's utilisation sampler) can see whether the 20-step headline holds
             c0 = measure_gemm_clock(eng, step)
             torch.cuda.synchronize()
+            power = BoardPower(dev)
             ts = time.perf_counter()
             n_sus = 200
+            power.start(skip_s=0.5)
             for _ in range(n_sus):
                 step()
             torch.cuda.synchronize()
             sus = time.perf_counter() - ts
+            pw = power.stop()
             c1 = measure_gemm_clock(eng, step)
             out["sustained"] = {"steps": n_sus, "seconds": round(sus, 3), "value": round(B * n_sus / sus, 1), "ms_per_step": round(sus / n_sus * 1e3, 3),
-                                "ratio_to_headline": round((B * n_sus / sus) / value, 4), "in_kernel_clock_mhz_before": c0, "in_kernel_clock_mhz_after": c1}
+                                "ratio_to_headline": round((B * n_sus / sus) / value, 4), "in_kernel_clock_mhz_before": c0, "in_kernel_clock_mhz_after": c1,
+                                "board_power": pw}
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"], e_ref = cpu_baseline(pcm_host, P_host)
             # PCM -> score deviation of the GPU path from the fp32 oracle on the baseline's sample (>= 64 segments when the host is
