@@ -36,13 +36,15 @@ if mode == "step":
     eng = ops.get_engine(0)
     pcm = torch.from_numpy(bench.synth_pcm(1000, seed=0)).cuda()
     f = lambda: eng.embed_pcm(pcm)
-elif mode in ("gemm", "gemm_zeros", "gemm_k1024", "vendor", "vendor_k1024"):
+elif mode in ("gemm", "gemm_zeros", "gemm_k1024", "vendor", "vendor_k1024", "vendor_zeros", "gemm_a_zero", "gemm_w_zero"):
     eng = ops.get_engine(0)
     M = 201000
     N = K = 1024 if mode.endswith("k1024") else 3072
     A = torch.empty(M, K, device="cuda", dtype=torch.bfloat16).normal_(0, 0.5); W = (torch.randn(N, K, device="cuda") * 0.05).bfloat16()
-    if mode == "gemm_zeros":
-        A.zero_(); W.zero_()
+    if mode in ("gemm_zeros", "vendor_zeros", "gemm_a_zero"):
+        A.zero_()
+    if mode in ("gemm_zeros", "vendor_zeros", "gemm_w_zero"):
+        W.zero_()
     if mode.startswith("vendor"):
         Wt = W.t(); out = torch.empty(M, N, device="cuda", dtype=torch.bfloat16)
         f = lambda: torch.matmul(A, Wt, out=out)             # hipBLASLt, no epilogue: the yardstick of profiles/r05_vendor_sustained.txt
@@ -88,7 +90,7 @@ def summarise(rows):
     return {"samples": len(rows), "cap_W": rows[0]["cap_W"] if rows else None, "power_mean_W": round(sum(pw) / max(len(pw), 1), 1), "power_max_W": round(max(pw), 1) if pw else None,
             "sclk_mean_MHz": round(sum(r["sclk_MHz"] for r in rows) / max(len(rows), 1)), "mclk_mean_MHz": round(sum(r["mclk_MHz"] for r in rows) / max(len(rows), 1)),
             "temp_max_C": max((r["temp_C"] for r in rows), default=None)}
-for mode, secs in (("idle", 2.0), ("step", 12.0), ("gemm", 8.0), ("vendor", 8.0), ("gemm_k1024", 8.0), ("vendor_k1024", 8.0), ("gemm_zeros", 6.0), ("hbm", 6.0), ("idle", 2.0)):
+for mode, secs in (("idle", 2.0), ("step", 12.0), ("gemm", 8.0), ("vendor", 8.0), ("gemm_k1024", 8.0), ("vendor_k1024", 8.0), ("gemm_zeros", 6.0), ("hbm", 6.0), ("idle", 2.0)) if len(sys.argv) < 2 else (("idle", 2.0), ("step", 6.0)) + tuple((m, 6.0) for m in sys.argv[1:]):
     res = {}
     if mode == "idle":
         for h in hs:
