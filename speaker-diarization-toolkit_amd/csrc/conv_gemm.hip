@@ -17,6 +17,9 @@
 #include <type_traits>
 
 #include "common.hpp"
+#ifndef SDK_GEMM_CHAIN2
+#define SDK_GEMM_CHAIN2 2      // 256 x 256 K loop: each accumulator's two products of a K-step back to back; 2 (default): the pair's second MFMA at a raised wave
+#endif                         // priority; 1: plain priority; 0: the round-2 ... round-5 order (A/B builds: profiles/r05_gemm_chained_order.txt)
 
 namespace {
 
@@ -591,6 +594,94 @@ __global__ __launch_bounds__(NT2, 2) void conv_gemm256_kernel(Params p) {
     if (tid < BN2) { par[tid] = pb; par[BN2 + tid] = psc; par[2 * BN2 + tid] = psh; }
     __builtin_amdgcn_s_barrier();
     stamp();
+#if SDK_GEMM_CHAIN2
+    // Round 5, late: the K-step's 64 MFMAs ordered so that every accumulator tile takes its TWO products (k 0-31, k 32-63) back to back.  At the
+    // board's power cap the order is worth energy (tools/probe/mfma_energy.hip, bare loops on random operands, same 64 products per iteration):
+    // the order below delivers 6.6-7.3 % more FLOP/s than the (ks, mh, mi, ni) order this kernel used - as much as removing ALL operand toggling -
+    // because the second MFMA of a pair takes the accumulator from the matrix pipe instead of the register file (one other MFMA between the two and
+    // the gain is gone: probe variants 7 / 8).  In THIS kernel the two waves of a SIMD feed one pipe, and a pair is split whenever the partner's MFMA
+    // wins the slot in between: the plain chained order measured -0.6 % on the 3072^2 layer under sustained load and nothing on K = 1024; raising the
+    // wave's priority for the pair's second MFMA (s_setprio 3 ... 1 around it) -1.8 % and -1.1 % at a 1-2 % higher clock
+    // (profiles/r05_gemm_chained_order.txt).  Same sum order per element (k 0-31 before k 32-63): bit-identical output.  Four phases of two 16-row blocks each; the W fragments of both k-halves stay in registers for
+    // the whole K-step and are replaced column block by column block in the last phase, right after their last use, so the peak stays at 16
+    // fragments (8 W + 4 A in use + 4 A in flight), as before; 24 fragment reads per K-step, as before.
+    bf16x8 wf[2][4], aA[2][2], aB[2][2];
+    auto ldApair = [&](const char* st, bf16x8 (*dst)[2], int pr) {
+#pragma unroll
+      for (int j = 0; j < 2; ++j) {
+        dst[j][0] = *reinterpret_cast<const bf16x8*>(st + a_base + (pr * 2 + j) * 2048 + c0);
+        dst[j][1] = *reinterpret_cast<const bf16x8*>(st + a_base + (pr * 2 + j) * 2048 + c1);
+      }
+    };
+    auto ldWcol = [&](const char* st, int ni) {
+      wf[0][ni] = *reinterpret_cast<const bf16x8*>(st + b_base + ni * 2048 + c0);
+      wf[1][ni] = *reinterpret_cast<const bf16x8*>(st + b_base + ni * 2048 + c1);
+    };
+    auto mma_cols = [&](const bf16x8 (*af)[2], int pr, int n_lo, int n_hi) {   // column blocks [n_lo, n_hi) of row pair pr: per accumulator k 0-31 then k 32-63
+      __builtin_amdgcn_s_setprio(1);
+#pragma unroll
+      for (int ni = n_lo; ni < n_hi; ++ni)
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+          for (int ks = 0; ks < 2; ++ks) {
+#if SDK_GEMM_CHAIN2 == 2     // the pair's second MFMA at a raised priority: the partner wave's MFMA does not go between the two (see above)
+            if (ks == 1) __builtin_amdgcn_s_setprio(3);
+#endif
+            if constexpr (F16)
+              acc[pr * 2 + j][ni] = __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(f16x8_t, wf[ks][ni]), __builtin_bit_cast(f16x8_t, af[j][ks]), acc[pr * 2 + j][ni], 0, 0, 0);
+            else
+              acc[pr * 2 + j][ni] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[ks][ni], af[j][ks], acc[pr * 2 + j][ni], 0, 0, 0);
+#if SDK_GEMM_CHAIN2 == 2
+            if (ks == 1) __builtin_amdgcn_s_setprio(1);
+#endif
+          }
+      __builtin_amdgcn_s_setprio(0);
+    };
+    ldApair(smem, aA, 0);                                // (the order the last phase below issues them in: the counted wait at the head of the loop is the same on both edges)
+#pragma unroll
+    for (int ni = 0; ni < 4; ++ni) ldWcol(smem, ni);
+    for (int t = 0; t < nk; ++t) {
+      const char* st = smem + (t & 1) * STAGE2;
+      __builtin_amdgcn_sched_barrier(0);
+      mma_cols(aA, 0, 0, 2);                             // rows 0-31
+      __builtin_amdgcn_sched_barrier(0);
+      ldApair(st, aB, 1);
+      __builtin_amdgcn_sched_barrier(0);
+      mma_cols(aA, 0, 2, 4);
+      __builtin_amdgcn_sched_barrier(0);
+      mma_cols(aB, 1, 0, 2);                             // rows 32-63
+      __builtin_amdgcn_sched_barrier(0);
+      ldApair(st, aA, 2);
+      __builtin_amdgcn_sched_barrier(0);
+      mma_cols(aB, 1, 2, 4);
+      __builtin_amdgcn_sched_barrier(0);
+      mma_cols(aA, 2, 0, 2);                             // rows 64-95
+      __builtin_amdgcn_sched_barrier(0);
+      ldApair(st, aB, 3);
+      __builtin_amdgcn_sched_barrier(0);
+      mma_cols(aA, 2, 2, 4);
+      __builtin_amdgcn_sched_barrier(0);
+      if (t + 1 < nk) {
+        asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");      // own reads of stage t done, own DMA of step t + 1 landed (see the note in the other branch)
+        __builtin_amdgcn_s_barrier();
+        if (dma_early && t + 2 < nk) issue(t + 2, t & 1, kWhole);
+        ldApair(smem + ((t + 1) & 1) * STAGE2, aA, 0);
+      }
+      {
+        const char* sn = smem + ((t + 1) & 1) * STAGE2;  // (after the last K-step the reads below fetch fragments nobody uses: in bounds, no branch in the phase)
+#pragma unroll
+        for (int ni = 0; ni < 4; ++ni) {                 // rows 96-127, one column block at a time: its W fragments are free after it and take the next K-step's
+          __builtin_amdgcn_sched_barrier(0);
+          mma_cols(aB, 3, ni, ni + 1);
+          __builtin_amdgcn_sched_barrier(0);
+          ldWcol(sn, ni);
+        }
+      }
+      __builtin_amdgcn_sched_barrier(0);
+      if (!dma_early && t + 2 < nk) issue(t + 2, t & 1, kWhole);
+    }
+#else
     ldB(smem, b0, c0);
     ldA(smem, a0, 0, c0);
     for (int t = 0; t < nk; ++t) {
@@ -634,6 +725,7 @@ __global__ __launch_bounds__(NT2, 2) void conv_gemm256_kernel(Params p) {
       __builtin_amdgcn_sched_barrier(0);
       if (!dma_early && t + 2 < nk) issue(t + 2, t & 1, kWhole);
     }
+#endif
 
     stamp();
     // ------------------------------------------------------------------ epilogue

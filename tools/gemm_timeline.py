@@ -1,16 +1,19 @@
 #!/usr/bin/env python3
-"""Phase timeline of conv_gemm256 (workgroup 0): per tile, wait for K-step 0 | K loop | epilogue, for the v3 and v2 forms."""
+"""Phase timeline of conv_gemm256 (workgroup 0): per tile, wait for K-step 0 | K loop | epilogue.  $SDK_HIP_LIB selects the binary (two-binary A/B);
+usage: gemm_timeline.py [N K]"""
 import importlib, sys
 from pathlib import Path
 import numpy as np, torch
 sys.path.insert(0, str(Path(__file__).resolve().parent.parent))
 ops = importlib.import_module("speaker-diarization-toolkit_amd.ops")
 eng = ops.get_engine(0)
-M, N, K = 201 * 1000, 1024, 1024
+M = 201 * 1000
+N, K = (int(sys.argv[1]), int(sys.argv[2])) if len(sys.argv) > 2 else (1024, 1024)
 A = (torch.randn(M, K, device="cuda") * 0.5).bfloat16()
 W = (torch.randn(N, K, device="cuda") * 0.03).bfloat16()
 bias = torch.randn(N, device="cuda"); sc = torch.rand(N, device="cuda") + 0.5; sh = torch.randn(N, device="cuda")
-for variant, name in ((258, "v3 overlapped boundary"), (2, "v2")):
+import os
+for variant, name in ((2, os.path.basename(os.environ.get("SDK_HIP_LIB", "libsdk_hip.so"))),):
     eng.lib.sdk_set_gemm_variant(variant)
     for _ in range(3): eng.conv_gemm(A, W, N, K, T=201, bias=bias, scale=sc, shift=sh, relu=True)
     buf = torch.zeros(8192, dtype=torch.int64, device="cuda"); stamps = torch.zeros(4096, dtype=torch.int64, device="cuda")
@@ -25,7 +28,7 @@ for variant, name in ((258, "v3 overlapped boundary"), (2, "v2")):
     wait = st[1:, 0] - st[:-1, 2]; loop = st[:, 1] - st[:, 0]; epi = st[:, 2] - st[:, 1]
     clk = t[:512].reshape(256, 2); mhz = np.median(clk[:, 0] / np.maximum(clk[:, 1], 1)) * 100
     life = clk[:, 1] / 100.0
-    ntile = np.array([13 if b < 3144 - 12 * 256 else 12 for b in range(256)])
+    ntile = np.array([13 if b < 72 else 12 for b in range(256)])
     print(f"{name}: workgroup lifetimes (us): min {life.min():.1f} median {np.median(life):.1f} max {life.max():.1f}; 13-tile WGs median {np.median(life[ntile == 13]):.1f} max {life[ntile == 13].max():.1f}; "
           f"12-tile WGs median {np.median(life[ntile == 12]):.1f} max {life[ntile == 12].max():.1f}; per XCD class median " + " ".join(f"{np.median(life[x::8]):.0f}" for x in range(8)))
     print(f"{name}: {n} tiles by workgroup 0; per tile (us, median): boundary wait {np.median(wait):.2f}, K loop {np.median(loop):.2f} "
