@@ -618,7 +618,11 @@ __global__ __launch_bounds__(NT2, 2) void conv_gemm256_kernel(Params p) {
       wf[1][ni] = *reinterpret_cast<const bf16x8*>(st + b_base + ni * 2048 + c1);
     };
     auto mma_cols = [&](const bf16x8 (*af)[2], int pr, int n_lo, int n_hi) {   // column blocks [n_lo, n_hi) of row pair pr: per accumulator k 0-31 then k 32-63
-      __builtin_amdgcn_s_setprio(1);
+#ifndef SDK_GEMM_PRIO_CLUSTER
+#define SDK_GEMM_PRIO_CLUSTER 0        // the wave's priority inside an MFMA cluster beside the pair's 3 (outside a cluster: 0).  Rounds 2-5 ran clusters at 1; with the pairs
+                                       // at 3 the cluster level only costs: 0 measured -1.1 % / -0.4 % (3072^2 / K = 1024, sustained) against 1, and 2 the same as 1
+#endif
+      if (SDK_GEMM_PRIO_CLUSTER) __builtin_amdgcn_s_setprio(SDK_GEMM_PRIO_CLUSTER);
 #pragma unroll
       for (int ni = n_lo; ni < n_hi; ++ni)
 #pragma unroll
@@ -633,10 +637,10 @@ __global__ __launch_bounds__(NT2, 2) void conv_gemm256_kernel(Params p) {
             else
               acc[pr * 2 + j][ni] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[ks][ni], af[j][ks], acc[pr * 2 + j][ni], 0, 0, 0);
 #if SDK_GEMM_CHAIN2 == 2
-            if (ks == 1) __builtin_amdgcn_s_setprio(1);
+            if (ks == 1) __builtin_amdgcn_s_setprio(SDK_GEMM_PRIO_CLUSTER);
 #endif
           }
-      __builtin_amdgcn_s_setprio(0);
+      if (SDK_GEMM_PRIO_CLUSTER) __builtin_amdgcn_s_setprio(0);
     };
     ldApair(smem, aA, 0);                                // (the order the last phase below issues them in: the counted wait at the head of the loop is the same on both edges)
 #pragma unroll
