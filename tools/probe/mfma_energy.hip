@@ -11,6 +11,7 @@
 //   6  one accumulator for all 64 MFMAs (chain of 64), operands as 0
 //   7  pairs interleaved two by two: (X k0, Y k0, X k1, Y k1) - an accumulator's second product follows ONE other MFMA
 //   8  pairs interleaved four by four: (X, Y, Z, U) k0 then (X, Y, Z, U) k1 (one row block, all column blocks)
+//   9  as 4 with the k-halves snaking from pair to pair (X k0 k1, Y k1 k0): the W operand is held across every pair boundary
 // second argument 1: ONE wave per SIMD (256 threads per workgroup) - what a wave delivers while its partner is busy elsewhere
 // hipcc --offload-arch=gfx950 -O3 -o mfma_energy mfma_energy.hip ; ./mfma_energy [seconds per variant = 1.0]
 #include <hip/hip_runtime.h>
@@ -101,6 +102,19 @@ __global__ __launch_bounds__(512, 2) void probe(const bf16x8* __restrict__ in, f
 #pragma unroll
             for (int ni = 0; ni < 4; ++ni) MFMA(acc[mh * 4 + mi][ni], W[ks][ni], A[mh][ks][mi]);
     }
+    if constexpr (V == 9) {
+#pragma unroll
+      for (int ni = 0; ni < 4; ++ni)
+#pragma unroll
+        for (int mh = 0; mh < 2; ++mh)
+#pragma unroll
+          for (int mi = 0; mi < 4; ++mi)
+#pragma unroll
+            for (int kk = 0; kk < 2; ++kk) {
+              const int ks = (mi & 1) ? 1 - kk : kk;
+              MFMA(acc[mh * 4 + mi][ni], W[ks][ni], A[mh][ks][mi]);
+            }
+    }
     if constexpr (V == 4) {
 #pragma unroll
       for (int ni = 0; ni < 4; ++ni)
@@ -174,6 +188,7 @@ int main(int argc, char** argv) {
     run<6>("6 one accumulator for every MFMA (chain of 64)", in, out, clk, seconds, nt);
     run<7>("7 pairs interleaved two by two (X0 Y0 X1 Y1)", in, out, clk, seconds, nt);
     run<8>("8 pairs interleaved four by four (mh, mi, ks, ni)", in, out, clk, seconds, nt);
+    run<9>("9 as 4, k-halves snaking (W held across pair boundaries)", in, out, clk, seconds, nt);
   }
   return 0;
 }
