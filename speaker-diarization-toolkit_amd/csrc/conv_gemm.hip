@@ -455,6 +455,9 @@ __global__ __launch_bounds__(NT2, 2) void conv_gemm256_kernel(Params p) {
   // Fixed order throughout (reproducible); a half tile runs the same code for its 128 rows, so its partials equal the whole tile's.
   // mp = origin of the 256-row tile the rows belong to (segment slots and stats_part rows are per such tile), lo = first image row's offset in
   // it (0, or 128 for the lower half tile), nrows = rows in the image (256 / 128).  Every thread of the workgroup calls it (barriers inside).
+  // (Round 5, late: mode 2 with ONE barrier - sums of squares published in the same pass into a compact [8 + 2][256] buffer - measured the same tile
+  // period, 87.9 against 88.1 us on the 3072^2 layer: the barriers are not what the statistics cost; the waves that hold a segment boundary or the
+  // matrix edge run the masked path, ~2 x the vector work of the others, and everybody waits for them.  Not kept: 10 KB more LDS for nothing.)
   float* wst = reinterpret_cast<float*>(smem + LDS2_PAR);
   auto tile_stats = [&](int mp, int lo, int nrows, int n0) {
     const int sb1 = (mp / p.T + 1) * p.T - mp, sb2 = sb1 + p.T;          // tile-local rows where the tile's 2nd / 3rd segment start
@@ -558,6 +561,9 @@ __global__ __launch_bounds__(NT2, 2) void conv_gemm256_kernel(Params p) {
 #pragma unroll
       for (int ni = 0; ni < 4; ++ni) acc[mi][ni] = f32x4{0.f, 0.f, 0.f, 0.f};
 
+    // The WEIGHT fragment is the MFMA's row operand: a lane then holds 4 CONSECUTIVE output columns (fq*4 + r) of one output row (fr), which the
+    // epilogue packs into one 8-byte LDS write.
+#if !SDK_GEMM_CHAIN2
     bf16x8 b0[4], b1[4], a0[4], a1[4];
     auto ldA = [&](const char* st, bf16x8* dst, int mh, uint32_t coff) {
 #pragma unroll
@@ -579,6 +585,7 @@ __global__ __launch_bounds__(NT2, 2) void conv_gemm256_kernel(Params p) {
             acc[mh * 4 + mi][ni] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(bf[ni], af[mi], acc[mh * 4 + mi][ni], 0, 0, 0);
       __builtin_amdgcn_s_setprio(0);
     };
+#endif
 
     // Software pipeline over the K-tiles, one barrier per K-tile placed BEFORE the last MFMA sub-phase:
     //   P0 P1 P2 | own reads of tile t done, own DMA of tile t+1 landed, barrier |
