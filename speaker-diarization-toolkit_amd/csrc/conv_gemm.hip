@@ -493,13 +493,17 @@ __global__ __launch_bounds__(NT2, 2) void conv_gemm256_kernel(Params p) {
           const u32x4 v = *reinterpret_cast<const u32x4*>(base + i * (BN2 * 2) + ((cc ^ i) << 4));
           float f[8];
           unpack8t<F16>(v, f);
-          const bool keep = i < ni, inl = i < ti;
+          // branches, not selects (round 5, late): a row goes to ONE part, so the other part's adds are not issued at all where no lane of the
+          // wave needs them (execz skip), instead of three selects and both parts' arithmetic per element.  Adding nothing equals adding the
+          // 0.f the select form added: same sums.  (Rows below the matrix hold whatever the padded MFMA rows produced: skipped.)
+          if (i < ni) {
+            if (i < ti) {
 #pragma unroll
-          for (int e = 0; e < 8; ++e) {
-            const float x = keep ? f[e] : 0.f;                          // (rows below the matrix hold whatever the padded MFMA rows produced)
-            const float xl = inl ? x : 0.f, xu = inl ? 0.f : x;
-            L[e] += xl; U[e] += xu;
-            if (mode2) { LQ[e] = fmaf(xl, xl, LQ[e]); UQ[e] = fmaf(xu, xu, UQ[e]); }
+              for (int e = 0; e < 8; ++e) { L[e] += f[e]; if (mode2) LQ[e] = fmaf(f[e], f[e], LQ[e]); }
+            } else {
+#pragma unroll
+              for (int e = 0; e < 8; ++e) { U[e] += f[e]; if (mode2) UQ[e] = fmaf(f[e], f[e], UQ[e]); }
+            }
           }
         }
       }
